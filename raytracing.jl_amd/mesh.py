@@ -1,0 +1,192 @@
+"""Mesh ingest and the flattened (SoA) mesh the segmentize! path consumes.
+
+Host-side counterpart of the reference's ``Mesh`` adaptor (``src/mesh.jl:10-31``): the
+reference keeps a Gridap ``UnstructuredDiscreteModel`` plus a node kd-tree, the
+node->cells table (``get_faces(topology, 0, 2)``, ``src/mesh.jl:27``), the cell->nodes
+table (``get_cell_node_ids``, ``src/mesh.jl:28``) and the bounding box
+(``src/mesh.jl:53-69``).  Here the same information is held as flat arrays in exactly the
+form the C ABI (``include/rt_segmentize.h``, ``rt_mesh_create``) takes them:
+
+* ``x[n_nodes]``, ``y[n_nodes]``            float64 node coordinates
+* ``cell_nodes[n_cells, 3]``                int32, 1-based node ids, reference order
+* ``node_cells_ptrs[n_nodes+1]`` / ``node_cells_data[...]``  int32 CSR, 1-based cell ids,
+  ascending per node (Gridap fills the table in cell order)
+* ``bb = (xmin, ymin, xmax, ymax)``         true min/max of the node coordinates
+
+Two loaders stand in for ``Gridap.DiscreteModelFromFile`` (Gridap JSON v0.15, what
+``test/runtests.jl:5-6`` and ``demo/pincell.jl:6-7`` load) and ``GmshDiscreteModel``
+(gmsh 4.1 ASCII, ``demo/pincell-gmsh.jl``).  For the gmsh file the Gridap numbering is
+reproduced by keeping triangles in file order and sorting each cell's node ids ascending
+(verified against ``demo/pincell.json``: identical node order, cell order and per-cell ids).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+__all__ = [
+    "DiscreteModel",
+    "DiscreteModelFromFile",
+    "GmshDiscreteModel",
+    "Mesh",
+    "data_path",
+]
+
+
+def data_path(name: str) -> str:
+    """Path of a mesh fixture shipped with the package (``raytracing.jl_amd/data``)."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name)
+
+
+@dataclass
+class DiscreteModel:
+    """Minimal stand-in for Gridap's ``UnstructuredDiscreteModel`` (triangles only).
+
+    ``node_coordinates``: (n_nodes, 2) float64.  ``cell_node_ids``: (n_cells, 3) int32,
+    1-based, in the order ``get_cell_node_ids(grid)`` would return them.
+    """
+
+    node_coordinates: np.ndarray
+    cell_node_ids: np.ndarray
+
+    def __post_init__(self):
+        self.node_coordinates = np.ascontiguousarray(self.node_coordinates, dtype=np.float64)
+        self.cell_node_ids = np.ascontiguousarray(self.cell_node_ids, dtype=np.int32)
+        if self.node_coordinates.ndim != 2 or self.node_coordinates.shape[1] != 2:
+            raise ValueError("node_coordinates must have shape (n_nodes, 2)")
+        if self.cell_node_ids.ndim != 2 or self.cell_node_ids.shape[1] != 3:
+            # the reference only ever reads the first three node ids of a cell
+            # (src/mesh.jl:158-164); point_in_quadrangle (src/mesh.jl:184-201) is dead code.
+            raise ValueError("only triangular cells are supported (cell_node_ids must be (n_cells, 3))")
+        n = self.node_coordinates.shape[0]
+        if self.cell_node_ids.size and (self.cell_node_ids.min() < 1 or self.cell_node_ids.max() > n):
+            raise ValueError("cell_node_ids must be 1-based ids into node_coordinates")
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.node_coordinates.shape[0])
+
+    @property
+    def num_cells(self) -> int:
+        return int(self.cell_node_ids.shape[0])
+
+
+def DiscreteModelFromFile(jsonfile: str) -> DiscreteModel:
+    """Load a Gridap JSON (v0.15) discrete model: ``grid.node_coordinates`` is a flat
+    xy list, ``grid.cell_node_ids`` a 1-based ``{ptrs, data}`` table."""
+    with open(jsonfile, "r") as fh:
+        d = json.load(fh)
+    grid = d["grid"]
+    dp = int(grid.get("Dp", 2))
+    if dp != 2:
+        raise ValueError("only 2-D models are supported")
+    xy = np.asarray(grid["node_coordinates"], dtype=np.float64).reshape(-1, 2)
+    ptrs = np.asarray(grid["cell_node_ids"]["ptrs"], dtype=np.int64)
+    data = np.asarray(grid["cell_node_ids"]["data"], dtype=np.int32)
+    if not np.all(np.diff(ptrs) == 3):
+        raise ValueError("only triangular cells are supported")
+    return DiscreteModel(xy, data.reshape(-1, 3))
+
+
+def GmshDiscreteModel(mshfile: str, renumber: bool = True) -> DiscreteModel:
+    """Load the 2-D triangles of a gmsh 4.1 ASCII ``.msh`` file.
+
+    Nodes keep their gmsh tags as ids (tags must be 1..n, as gmsh writes them), triangles
+    (element type 2) keep file order, and each cell's node ids are sorted ascending, which
+    is what ``GmshDiscreteModel(msh; renumber=true)`` + Gridap's oriented grid store for
+    ``demo/pincell.msh`` (compare ``demo/pincell.json``).
+    """
+    with open(mshfile, "r") as fh:
+        lines = fh.read().split("\n")
+    pos = {ln.strip(): i for i, ln in enumerate(lines) if ln.startswith("$")}
+    if "$MeshFormat" not in pos or not lines[pos["$MeshFormat"] + 1].startswith("4.1"):
+        raise ValueError("expected a gmsh 4.1 ASCII file")
+    # ---- nodes
+    i = pos["$Nodes"] + 1
+    n_blocks, n_nodes, _mn, _mx = (int(t) for t in lines[i].split())
+    i += 1
+    xy = np.empty((n_nodes, 2), dtype=np.float64)
+    seen = np.zeros(n_nodes, dtype=bool)
+    for _ in range(n_blocks):
+        _dim, _tag, _par, nb = (int(t) for t in lines[i].split())
+        i += 1
+        tags = [int(lines[i + k]) for k in range(nb)]
+        i += nb
+        for k in range(nb):
+            c = lines[i + k].split()
+            t = tags[k]
+            if not (1 <= t <= n_nodes):
+                raise ValueError("node tags must be 1..n_nodes")
+            xy[t - 1, 0] = float(c[0])
+            xy[t - 1, 1] = float(c[1])
+            seen[t - 1] = True
+        i += nb
+    if not seen.all():
+        raise ValueError("missing node tags in $Nodes")
+    # ---- elements
+    i = pos["$Elements"] + 1
+    n_blocks, _n_el, _mn, _mx = (int(t) for t in lines[i].split())
+    i += 1
+    tris = []
+    for _ in range(n_blocks):
+        _dim, _tag, etype, nb = (int(t) for t in lines[i].split())
+        i += 1
+        if etype == 2:
+            for k in range(nb):
+                t = lines[i + k].split()
+                tris.append((int(t[1]), int(t[2]), int(t[3])))
+        i += nb
+    cells = np.asarray(tris, dtype=np.int32).reshape(-1, 3)
+    if renumber:
+        cells = np.sort(cells, axis=1)
+    return DiscreteModel(xy, cells)
+
+
+class Mesh:
+    """Flattened mesh for the segmentize! path (mirrors ``Mesh(model)``, ``src/mesh.jl:24-31``)."""
+
+    def __init__(self, model: DiscreteModel):
+        self.model = model
+        xy = model.node_coordinates
+        self.x = np.ascontiguousarray(xy[:, 0])
+        self.y = np.ascontiguousarray(xy[:, 1])
+        self.cell_nodes = model.cell_node_ids  # (n_cells, 3) int32, 1-based
+        self.node_cells_ptrs, self.node_cells_data = _node_cells(model.num_nodes, self.cell_nodes)
+        # bounding_box (src/mesh.jl:53-69): plain min / max over the node coordinates
+        self.bb_min = (float(self.x.min()), float(self.y.min()))
+        self.bb_max = (float(self.x.max()), float(self.y.max()))
+
+    @property
+    def num_nodes(self) -> int:
+        return self.model.num_nodes
+
+    @property
+    def num_cells(self) -> int:
+        return self.model.num_cells
+
+    @property
+    def bb(self) -> np.ndarray:
+        return np.array([self.bb_min[0], self.bb_min[1], self.bb_max[0], self.bb_max[1]], dtype=np.float64)
+
+    def width(self) -> float:  # src/mesh.jl:76
+        return self.bb_max[0] - self.bb_min[0]
+
+    def height(self) -> float:  # src/mesh.jl:83
+        return self.bb_max[1] - self.bb_min[1]
+
+
+def _node_cells(n_nodes: int, cell_nodes: np.ndarray):
+    """node -> incident cells CSR (1-based, cells ascending per node), the table
+    ``get_faces(get_grid_topology(model), 0, 2)`` holds (``src/mesh.jl:27``)."""
+    n_cells = cell_nodes.shape[0]
+    flat_nodes = cell_nodes.reshape(-1).astype(np.int64) - 1
+    flat_cells = np.repeat(np.arange(1, n_cells + 1, dtype=np.int32), 3)
+    order = np.argsort(flat_nodes, kind="stable")  # stable: cells stay ascending per node
+    counts = np.bincount(flat_nodes, minlength=n_nodes)
+    ptrs = np.zeros(n_nodes + 1, dtype=np.int32)
+    np.cumsum(counts, out=ptrs[1:])
+    data = np.ascontiguousarray(flat_cells[order], dtype=np.int32)
+    return ptrs, data
