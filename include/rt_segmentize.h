@@ -1,0 +1,140 @@
+/*
+ * rt_segmentize.h — C ABI of the MI355X-native segmentize! path.
+ *
+ * The reference (RayTracing.jl, pure Julia) has no FFI seam; its boundary for this path is
+ * the exported Julia function
+ *     segmentize!(t::TrackGenerator{T}; k::Int=5, rtol::Real=Base.rtoldefault(T)) -> t
+ *                                                   (src/trackgenerator.jl:357-369)
+ * which runs _segmentize_track! (src/track.jl:106-178) over `tracks_by_uid` and then
+ * fill_volumes (src/trackgenerator.jl:371-386).  A Julia shim binds the entry points below
+ * with `ccall` (julia/RayTracingAMD.jl); the Python host mirror binds the
+ * same symbols with ctypes (raytracing.jl_amd/_capi.py).
+ *
+ * Conventions: plain pointers and sizes only; every array argument is caller-owned host
+ * memory unless its name ends in `_dev`; the library copies what it needs and owns only the
+ * device memory behind its handles.  Ids are 1-based Int32 exactly as the reference holds
+ * them (cell_nodes, node_cells, segment.element).  All real data is IEEE double.
+ * Functions returning int32_t return RT_SUCCESS (0) or a negative RT_ERR_* code; the text
+ * of the last failure on the calling thread is rt_last_error().  One host thread per
+ * handle; work is enqueued on the handle's HIP stream.
+ */
+#ifndef RT_SEGMENTIZE_H
+#define RT_SEGMENTIZE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* return codes */
+#define RT_SUCCESS 0
+#define RT_ERR_INVALID (-1)         /* bad argument                                      */
+#define RT_ERR_HIP (-2)             /* a HIP runtime call failed (see rt_last_error)     */
+#define RT_ERR_NO_DEVICE (-3)       /* no usable GPU                                     */
+#define RT_ERR_NOT_SEGMENTIZED (-4) /* results requested before rt_segmentize            */
+
+/* per-track status codes (what the reference signals by throwing) */
+#define RT_TRACK_OK 0
+#define RT_TRACK_LOCATE_FAILED 1      /* error("Try increasing `k`. ...")      src/track.jl:141 */
+#define RT_TRACK_LENGTH_MISMATCH 2    /* error("Track with `uid` ... ")        src/track.jl:172 */
+#define RT_TRACK_UNDEF_INTERSECTION 3 /* UndefVarError in intersections  src/intersection.jl:82-94 */
+#define RT_TRACK_ITER_CAP 4           /* this library's guard on the reference's unbounded
+                                         `continue` paths (src/track.jl:126-130,147-150,156-159) */
+
+typedef struct rt_mesh rt_mesh;     /* device-resident flattened mesh + acceleration tables */
+typedef struct rt_tracks rt_tracks; /* device-resident track set + the results of segmentize */
+
+int32_t rt_abi_version(void);
+const char *rt_last_error(void);
+/* The message the reference throws for a per-track status (text of src/track.jl:141 / :172);
+ * for RT_TRACK_LENGTH_MISMATCH the caller substitutes the uid for "%d". */
+const char *rt_status_message(int32_t status);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int32_t rt_device_count(void);
+
+/*
+ * Mesh(model) — src/mesh.jl:24-31 (fields :10-17), consumed by find_element / inboundary
+ * (src/mesh.jl:91-146) and intersections (src/intersection.jl:34-119).
+ *   x, y[n_nodes]            get_node_coordinates(get_grid(model)), split into SoA
+ *   cell_nodes[3*n_cells]    get_cell_node_ids(grid), 1-based, reference order per cell
+ *   node_cells_ptrs[n_nodes+1], node_cells_data[ptrs[n_nodes]]
+ *                            get_faces(topology, 0, 2) as CSR; ptrs may be 0- or 1-based
+ *                            (Gridap's Table is 1-based), data are 1-based cell ids
+ *   bb[4]                    bb_min.x, bb_min.y, bb_max.x, bb_max.y (src/mesh.jl:53-69)
+ * The kd-tree (src/mesh.jl:38-42) is replaced by an exact nearest-node structure built
+ * here.  Returns NULL on failure.
+ */
+rt_mesh *rt_mesh_create(int32_t device, const double *x, const double *y, int32_t n_nodes,
+                        const int32_t *cell_nodes, int32_t n_cells, const int32_t *node_cells_ptrs,
+                        const int32_t *node_cells_data, const double *bb);
+void rt_mesh_destroy(rt_mesh *mesh);
+/* Enqueue all later work of this mesh's track sets on an existing hipStream_t (NULL = the
+ * library's own stream). */
+int32_t rt_mesh_set_stream(rt_mesh *mesh, void *hip_stream);
+void *rt_mesh_get_stream(rt_mesh *mesh);
+
+/*
+ * The per-track inputs of _segmentize_track! (src/track.jl:106-108: track.p, ϕ, ℓ, ABC),
+ * in uid order, as produced by trace! (src/trackgenerator.jl:179-273).  cos_phi / sin_phi
+ * are cos(ϕ), sin(ϕ) evaluated by the host (advance_step, src/point.jl:43, evaluates them
+ * with the host libm; the device never calls trig functions).  azim_idx is the 1-based
+ * track.azim_idx that fill_volumes uses (src/trackgenerator.jl:379).
+ */
+rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, const double *py,
+                            const double *phi, const double *cos_phi, const double *sin_phi,
+                            const double *A, const double *B, const double *C, const double *ell,
+                            const int32_t *azim_idx);
+void rt_tracks_destroy(rt_tracks *tracks);
+
+/*
+ * segmentize!(t; k, rtol) — src/trackgenerator.jl:357-369, including fill_volumes
+ * (:371-386; delta_s[n_azim_2] = azimuthal_quadrature.δs).  tiny_step = t.tiny_step.
+ * Runs every track's march on the device and leaves, behind `tracks`:
+ *   seg_offsets[n_tracks+1]  CSR offsets: track u owns segments [off[u], off[u+1]) in march order
+ *   status[n_tracks]         RT_TRACK_* per track
+ *   px,py,qx,qy,ell[total]   segment.p, segment.q, segment.ℓ   (src/segment.jl:23-33)
+ *   element[total]           segment.element, 1-based Int32
+ *   volumes[n_cells]         t.volumes
+ * Returns the total number of segments (>= 0) or a negative RT_ERR_* code.  A non-OK track
+ * status is not an error of this call: the caller decides (the shims throw the reference's
+ * message for the first failing uid).
+ */
+int64_t rt_segmentize(rt_tracks *tracks, double tiny_step, int32_t k, double rtol,
+                      const double *delta_s, int32_t n_azim_2);
+
+/* Number of tracks with status != RT_TRACK_OK after the last rt_segmentize, and the 1-based
+ * uid of the first one (0 if none). */
+int32_t rt_failed_tracks(rt_tracks *tracks, int64_t *n_failed, int64_t *first_uid, int32_t *first_status);
+
+/* Copy results into caller-allocated host buffers (any pointer may be NULL to skip it). */
+int32_t rt_fetch_offsets(rt_tracks *tracks, int64_t *seg_offsets, int32_t *status);
+int32_t rt_fetch_segments(rt_tracks *tracks, double *px, double *py, double *qx, double *qy,
+                          double *ell, int32_t *element);
+int32_t rt_fetch_volumes(rt_tracks *tracks, double *volumes);
+
+/*
+ * Device-resident results for consumers that stay on the GPU (RCCL all-gather of shards,
+ * a device-side transport sweep).  ptrs_dev[9] receives, in this order: seg_offsets (i64),
+ * status (i32), px, py, qx, qy, ell (f64), element (i32), volumes (f64).  The pointers stay
+ * valid until the next rt_segmentize / rt_tracks_destroy on this handle.
+ */
+int32_t rt_device_pointers(rt_tracks *tracks, void **ptrs_dev);
+
+/*
+ * HIP-event timings (milliseconds) of the last rt_segmentize on this handle, measured on
+ * the stream the kernels ran on: ms[0] whole call (device side), ms[1] plan (track
+ * binning), ms[2] march (the dominant kernel), ms[3] offsets scan, ms[4] compaction /
+ * fill, ms[5] volumes.  Unused slots are 0.  n = capacity of ms (>= 6).
+ */
+int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
+
+/* Tunables (name/value); unknown names return RT_ERR_INVALID.  See DESIGN.md. */
+int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_SEGMENTIZE_H */

@@ -12,10 +12,12 @@ from .mesh import DiscreteModel, DiscreteModelFromFile, GmshDiscreteModel, Mesh,
 from .quadrature import AzimuthalQuadrature
 from .trackgenerator import (Backward, Forward, Segment, Track, TrackGenerator, bc_bwd, bc_fwd,
                              dir_next_track_bwd, dir_next_track_fwd, trace)
+from .segmentize import RTOL_DEFAULT, SegmentStore, segmentize
 
 __all__ = [
     "BoundaryConditions", "BoundaryType", "Vacuum", "Reflective", "Periodic",
     "DiscreteModel", "DiscreteModelFromFile", "GmshDiscreteModel", "Mesh", "data_path",
-    "AzimuthalQuadrature", "TrackGenerator", "trace", "Track", "Segment",
+    "AzimuthalQuadrature", "TrackGenerator", "trace", "segmentize", "SegmentStore", "RTOL_DEFAULT",
+    "Track", "Segment",
     "Forward", "Backward", "bc_fwd", "bc_bwd", "dir_next_track_fwd", "dir_next_track_bwd",
 ]

@@ -1,0 +1,233 @@
+"""ctypes binding of the C ABI (``include/rt_segmentize.h``) — the same symbols a Julia
+``ccall`` shim binds (``julia/RayTracingAMD.jl``).  No CPU fallback: if the shared library
+is missing, or no GPU is visible, loading / compute raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librt_segmentize.so")
+
+# every symbol include/rt_segmentize.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = (
+    "rt_abi_version", "rt_last_error", "rt_status_message", "rt_device_count",
+    "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_set_stream", "rt_mesh_get_stream",
+    "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
+    "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_volumes", "rt_device_pointers",
+    "rt_last_timing", "rt_set_option",
+)
+
+RT_TRACK_OK = 0
+RT_TRACK_LOCATE_FAILED = 1
+RT_TRACK_LENGTH_MISMATCH = 2
+RT_TRACK_UNDEF_INTERSECTION = 3
+RT_TRACK_ITER_CAP = 4
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, extra: str = "") -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp", "Makefile"))]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "rt_segmentize.h"))
+    fresh = os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)
+    if force or not fresh:
+        cmd = ["make", "-C", _CSRC] + (["-B"] if force else []) + ([f"EXTRA={extra}"] if extra else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+def lib():
+    """Load ``librt_segmentize.so`` (raises ``RtError`` when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback for segmentize)")
+    L = C.CDLL(LIB_PATH)
+    L.rt_abi_version.restype = C.c_int32
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_status_message.restype = C.c_char_p
+    L.rt_status_message.argtypes = [C.c_int32]
+    L.rt_device_count.restype = C.c_int32
+    L.rt_mesh_create.restype = _vp
+    L.rt_mesh_create.argtypes = [C.c_int32, _dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp]
+    L.rt_mesh_destroy.argtypes = [_vp]
+    L.rt_mesh_set_stream.restype = C.c_int32
+    L.rt_mesh_set_stream.argtypes = [_vp, _vp]
+    L.rt_mesh_get_stream.restype = _vp
+    L.rt_mesh_get_stream.argtypes = [_vp]
+    L.rt_tracks_create.restype = _vp
+    L.rt_tracks_create.argtypes = [_vp, C.c_int64] + [_dp] * 9 + [_ip]
+    L.rt_tracks_destroy.argtypes = [_vp]
+    L.rt_segmentize.restype = C.c_int64
+    L.rt_segmentize.argtypes = [_vp, C.c_double, C.c_int32, C.c_double, _dp, C.c_int32]
+    L.rt_failed_tracks.restype = C.c_int32
+    L.rt_failed_tracks.argtypes = [_vp, _lp, _lp, _ip]
+    L.rt_fetch_offsets.restype = C.c_int32
+    L.rt_fetch_offsets.argtypes = [_vp, _lp, _ip]
+    L.rt_fetch_segments.restype = C.c_int32
+    L.rt_fetch_segments.argtypes = [_vp, _dp, _dp, _dp, _dp, _dp, _ip]
+    L.rt_fetch_volumes.restype = C.c_int32
+    L.rt_fetch_volumes.argtypes = [_vp, _dp]
+    L.rt_device_pointers.restype = C.c_int32
+    L.rt_device_pointers.argtypes = [_vp, C.POINTER(_vp)]
+    L.rt_last_timing.restype = C.c_int32
+    L.rt_last_timing.argtypes = [_vp, _dp, C.c_int32]
+    L.rt_set_option.restype = C.c_int32
+    L.rt_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
+    if L.rt_abi_version() != 1:
+        raise RtError("librt_segmentize.so: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().rt_last_error().decode("utf-8", "replace")
+
+
+def _check(rc: int):
+    if rc < 0:
+        raise RtError(f"rt error {rc}: {last_error()}")
+    return rc
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+class DeviceMesh:
+    """``rt_mesh`` handle: the flattened mesh resident in HBM."""
+
+    def __init__(self, mesh, device: int = 0):
+        L = lib()
+        keep = []
+        x, xp = _f64(mesh.x); y, yp = _f64(mesh.y)
+        cn, cnp = _i32(np.asarray(mesh.cell_nodes).reshape(-1))
+        ptr, ptrp = _i32(mesh.node_cells_ptrs); dat, datp = _i32(mesh.node_cells_data)
+        bb, bbp = _f64(mesh.bb)
+        keep += [x, y, cn, ptr, dat, bb]
+        self.n_nodes, self.n_cells, self.device = len(x), len(cn) // 3, device
+        self._h = L.rt_mesh_create(device, xp, yp, self.n_nodes, cnp, self.n_cells, ptrp, datp, bbp)
+        if not self._h:
+            raise RtError(f"rt_mesh_create failed: {last_error()}")
+
+    def set_stream(self, stream_ptr: int | None):
+        _check(lib().rt_mesh_set_stream(self._h, stream_ptr))
+
+    def get_stream(self) -> int:
+        return lib().rt_mesh_get_stream(self._h) or 0
+
+    def set_option(self, name: str, value: int):
+        _check(lib().rt_set_option(self._h, name.encode(), int(value)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceTracks:
+    """``rt_tracks`` handle: the per-track inputs resident in HBM + the results of segmentize."""
+
+    def __init__(self, dmesh: DeviceMesh, px, py, phi, cos_phi, sin_phi, A, B, Cc, ell, azim_idx):
+        L = lib()
+        self.dmesh = dmesh  # keeps the mesh alive
+        self.n = len(px)
+        arrs = [_f64(a) for a in (px, py, phi, cos_phi, sin_phi, A, B, Cc, ell)]
+        az, azp = _i32(azim_idx)
+        for a, _ in arrs:
+            if len(a) != self.n:
+                raise ValueError("track arrays must have equal lengths")
+        self._h = L.rt_tracks_create(dmesh._h, self.n, *[p for _, p in arrs], azp)
+        if not self._h:
+            raise RtError(f"rt_tracks_create failed: {last_error()}")
+        self.total = None
+
+    def segmentize(self, tiny_step: float, k: int, rtol: float, delta_s, n_azim_2: int) -> int:
+        ds, dsp = _f64(delta_s)
+        self.total = int(_check(lib().rt_segmentize(self._h, tiny_step, k, rtol, dsp, n_azim_2)))
+        return self.total
+
+    def failed(self):
+        n, u, st = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        _check(lib().rt_failed_tracks(self._h, C.byref(n), C.byref(u), C.byref(st)))
+        return n.value, u.value, st.value
+
+    def fetch_offsets(self):
+        off = np.zeros(self.n + 1, np.int64)
+        st = np.zeros(max(self.n, 1), np.int32)
+        _check(lib().rt_fetch_offsets(self._h, off.ctypes.data_as(_lp), st.ctypes.data_as(_ip)))
+        return off, st[: self.n]
+
+    def fetch_segments(self):
+        n = self.total
+        out = {k: np.zeros(n, np.float64) for k in ("px", "py", "qx", "qy", "ell")}
+        out["element"] = np.zeros(n, np.int32)
+        _check(lib().rt_fetch_segments(self._h, *[out[k].ctypes.data_as(_dp) for k in ("px", "py", "qx", "qy", "ell")],
+                                       out["element"].ctypes.data_as(_ip)))
+        return out
+
+    def fetch_volumes(self):
+        v = np.zeros(self.dmesh.n_cells, np.float64)
+        _check(lib().rt_fetch_volumes(self._h, v.ctypes.data_as(_dp)))
+        return v
+
+    def device_pointers(self):
+        """Raw device addresses: offsets, status, px, py, qx, qy, ell, element, volumes."""
+        arr = (_vp * 9)()
+        _check(lib().rt_device_pointers(self._h, arr))
+        names = ("offsets", "status", "px", "py", "qx", "qy", "ell", "element", "volumes")
+        return {k: (arr[i] or 0) for i, k in enumerate(names)}
+
+    def timing(self):
+        ms = np.zeros(8, np.float64)
+        _check(lib().rt_last_timing(self._h, ms.ctypes.data_as(_dp), 8))
+        return dict(total=ms[0], plan=ms[1], march=ms[2], scan=ms[3], fill=ms[4], volumes=ms[5])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_tracks_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def status_message(status: int, uid: int = 0) -> str:
+    msg = lib().rt_status_message(status).decode("utf-8")
+    return msg.replace("%d", str(uid)) if "%d" in msg else msg
+
+
+def device_count() -> int:
+    return int(lib().rt_device_count())

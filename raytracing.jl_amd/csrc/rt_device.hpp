@@ -1,0 +1,328 @@
+// rt_device.hpp — device-side geometry of the segmentize! march (gfx950, FP64, no MFMA).
+//
+// Exact-decision emulation of the reference's per-track march: every predicate below is
+// evaluated with the reference's own operation order in IEEE double (the TU is compiled
+// with -ffp-contract=off; f64 div/sqrt are correctly rounded), so element ids, segment
+// counts and skip/emit decisions follow the reference's tolerance- and order-dependent
+// rules, not "pure geometry".  Citations are into /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+constexpr double kRtolDefault = 1.4901161193847656e-8;  // sqrt(eps(Float64)) = Base.rtoldefault
+constexpr double kHalfPi = 1.5707963267948966;          // Float64(pi)/2, src/intersection.jl:153
+constexpr int kMaxIter = 10000;                         // const MAX_ITER, src/track.jl:104
+constexpr int kMaxK = 8;                                // cap on the knn fallback width `k`
+
+// Flattened mesh in HBM (SoA; all ids 0-based on the device, converted at upload).
+struct DMesh {
+    const double *__restrict__ x;        // [n_nodes]
+    const double *__restrict__ y;        // [n_nodes]
+    const int32_t *__restrict__ cn;      // [3*n_cells] cell -> nodes, reference order
+    const int32_t *__restrict__ ncp;     // [n_nodes+1] node -> cells CSR offsets
+    const int32_t *__restrict__ ncd;     // node -> cells, ascending cell id per node
+    const int32_t *__restrict__ gstart;  // [gnx*gny+1] uniform node grid CSR (row-major, y-major rows)
+    const int32_t *__restrict__ gnode;   // node ids grouped by bucket
+    double gx0, gy0, gh, ginv;           // grid origin, bucket size and its inverse
+    int32_t gnx, gny;
+    double bx0, by0, bx1, by1;           // bounding box (bb_min, bb_max)
+    int32_t n_nodes, n_cells;
+};
+
+// Per-track inputs in HBM (SoA, uid order) + the march order.
+struct DTracks {
+    const double *__restrict__ px, *__restrict__ py, *__restrict__ phi, *__restrict__ cs, *__restrict__ sn;
+    const double *__restrict__ A, *__restrict__ B, *__restrict__ C, *__restrict__ ell;
+    const int32_t *__restrict__ azim;    // 1-based azimuthal index
+    const int32_t *__restrict__ perm;    // march slot -> track (longest tracks first)
+    int64_t n;
+};
+
+struct DParams {
+    double tiny_step;
+    double rtol;
+    int32_t k;
+    int32_t n_azim_2;
+    int64_t iter_cap;
+};
+
+// ---------------------------------------------------------------- Base.isapprox ----------
+__device__ __forceinline__ bool isfin(double v) { return fabs(v) <= 1.7976931348623157e308; }
+
+// isapprox(x, y; rtol) scalar form with atol = 0
+__device__ __forceinline__ bool isapprox_s(double x, double y, double rtol) {
+    if (x == y) return true;
+    if (!(isfin(x) && isfin(y))) return false;
+    const double ax = fabs(x), ay = fabs(y);
+    return fabs(x - y) <= rtol * (ax > ay ? ax : ay);
+}
+__device__ __forceinline__ double norm2(double a, double b) { return sqrt(a * a + b * b); }
+
+// isapprox(p, q) for Point2D with default tolerances (array form: 2-norms)
+__device__ __forceinline__ bool isapprox_v2(double px, double py, double qx, double qy) {
+    const double d = norm2(px - qx, py - qy);
+    if (isfin(d)) {
+        const double np = norm2(px, py), nq = norm2(qx, qy);
+        return d <= kRtolDefault * (np > nq ? np : nq);
+    }
+    return isapprox_s(px, qx, kRtolDefault) && isapprox_s(py, qy, kRtolDefault);
+}
+
+// inboundary(mesh, x, atol) with atol = tiny_step > 0 (=> rtol = 0) — src/mesh.jl:91-95
+__device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
+    if (atol > 0.0) {
+        return (x == m.bx1 || fabs(x - m.bx1) <= atol) || (x == m.bx0 || fabs(x - m.bx0) <= atol) ||
+               (y == m.by1 || fabs(y - m.by1) <= atol) || (y == m.by0 || fabs(y - m.by0) <= atol);
+    }
+    return isapprox_s(x, m.bx1, kRtolDefault) || isapprox_s(x, m.bx0, kRtolDefault) ||
+           isapprox_s(y, m.by1, kRtolDefault) || isapprox_s(y, m.by0, kRtolDefault);
+}
+
+// ------------------------------------------------------- point_in_triangle ---------------
+// src/mesh.jl:158-176: λ = [x1 x2 x3; y1 y2 y3; 1 1 1] \ [x, y, 1] by the closed form
+// StaticArrays uses for 3x3 (cofactors / det, det = col1 · (col2 × col3)); inside iff every
+// λ ∈ [0 - tol, 1 + tol], tol = sqrt(eps).
+__device__ __forceinline__ bool point_in_triangle(const DMesh &m, int32_t cell, double x, double y) {
+    const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
+    const double x1 = m.x[n1], y1 = m.y[n1];
+    const double x2 = m.x[n2], y2 = m.y[n2];
+    const double x3 = m.x[n3], y3 = m.y[n3];
+    const double d = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
+    const double l1 = ((y2 - y3) * x + (x3 - x2) * y + (x2 * y3 - x3 * y2)) / d;
+    const double l2 = ((y3 - y1) * x + (x1 - x3) * y + (x3 * y1 - x1 * y3)) / d;
+    const double l3 = ((y1 - y2) * x + (x2 - x1) * y + (x1 * y2 - x2 * y1)) / d;
+    const double lo = 0.0 - kRtolDefault, hi = 1.0 + kRtolDefault;
+    return (lo <= l1 && l1 <= hi) && (lo <= l2 && l2 <= hi) && (lo <= l3 && l3 <= hi);
+}
+
+// ------------------------------------------------------- exact (k-)nearest nodes ---------
+// Replaces NearestNeighbors' kd-tree (src/mesh.jl:38-42,107,123) by an exact ring search on
+// a uniform bucket grid: rings of buckets around the query are visited until the k-th best
+// distance is provably smaller than the distance to anything unvisited.
+struct KBest {
+    double d2[kMaxK];
+    int32_t id[kMaxK];
+    int32_t n, k;
+};
+__device__ __forceinline__ void kbest_push(KBest &b, double d2, int32_t id) {
+    if (b.n == b.k && !(d2 < b.d2[b.n - 1])) return;
+    int i = (b.n < b.k) ? b.n++ : b.n - 1;
+    while (i > 0 && b.d2[i - 1] > d2) {
+        b.d2[i] = b.d2[i - 1];
+        b.id[i] = b.id[i - 1];
+        --i;
+    }
+    b.d2[i] = d2;
+    b.id[i] = id;
+}
+
+// Lower bound on the distance from (qx,qy) to any node outside the visited block of buckets
+// [ix-r, ix+r] x [iy-r, iy+r]; +inf once the block covers the whole grid.
+__device__ __forceinline__ double ring_bound(const DMesh &m, double qx, double qy, int ix, int iy, int r) {
+    const double inf = __builtin_huge_val();
+    double lb = inf;
+    if (ix - r > 0) lb = fmin(lb, qx - (m.gx0 + (double)(ix - r) * m.gh));
+    if (ix + r < m.gnx - 1) lb = fmin(lb, (m.gx0 + (double)(ix + r + 1) * m.gh) - qx);
+    if (iy - r > 0) lb = fmin(lb, qy - (m.gy0 + (double)(iy - r) * m.gh));
+    if (iy + r < m.gny - 1) lb = fmin(lb, (m.gy0 + (double)(iy + r + 1) * m.gh) - qy);
+    return lb;
+}
+
+__device__ __forceinline__ void bucket_of(const DMesh &m, double qx, double qy, int &ix, int &iy) {
+    double fx = floor((qx - m.gx0) * m.ginv), fy = floor((qy - m.gy0) * m.ginv);
+    fx = fx < 0.0 ? 0.0 : fx;
+    fy = fy < 0.0 ? 0.0 : fy;
+    ix = fx > (double)(m.gnx - 1) ? m.gnx - 1 : (int)fx;
+    iy = fy > (double)(m.gny - 1) ? m.gny - 1 : (int)fy;
+}
+
+// nn(kdtree, x): the nearest node (0-based id).
+__device__ __forceinline__ int32_t nearest_node(const DMesh &m, double qx, double qy) {
+    int ix, iy;
+    bucket_of(m, qx, qy, ix, iy);
+    double best = __builtin_huge_val();
+    int32_t best_id = -1;
+    const int rmax = m.gnx > m.gny ? m.gnx : m.gny;
+    for (int r = 0; r <= rmax; ++r) {
+        const int y0 = iy - r, y1 = iy + r;
+        for (int by = (y0 < 0 ? 0 : y0); by <= (y1 >= m.gny ? m.gny - 1 : y1); ++by) {
+            const int xl = ix - r < 0 ? 0 : ix - r, xr = ix + r >= m.gnx ? m.gnx - 1 : ix + r;
+            const bool full = (by == y0) || (by == y1);
+            // full rows: one contiguous CSR range; inner rows: only the two end buckets
+            for (int part = 0; part < (full ? 1 : 2); ++part) {
+                int b0, b1;
+                if (full) { b0 = by * m.gnx + xl; b1 = by * m.gnx + xr + 1; }
+                else {
+                    const int bx = part == 0 ? ix - r : ix + r;
+                    if (bx < 0 || bx >= m.gnx) continue;
+                    b0 = by * m.gnx + bx; b1 = b0 + 1;
+                }
+                for (int32_t s = m.gstart[b0]; s < m.gstart[b1]; ++s) {
+                    const int32_t id = m.gnode[s];
+                    const double dx = qx - m.x[id], dy = qy - m.y[id];
+                    const double d2 = dx * dx + dy * dy;
+                    if (d2 < best) { best = d2; best_id = id; }
+                }
+            }
+        }
+        const double lb = ring_bound(m, qx, qy, ix, iy, r) - 1e-9 * m.gh;
+        if (lb == __builtin_huge_val()) break;
+        if (best_id >= 0 && lb > 0.0 && best < lb * lb) break;
+    }
+    return best_id;
+}
+
+// knn(kdtree, x, k, true, i -> i == skip): the k nearest nodes other than `skip`, ascending.
+__device__ __noinline__ void knearest_nodes(const DMesh &m, double qx, double qy, int k, int32_t skip, KBest &kb) {
+    kb.n = 0;
+    kb.k = k > kMaxK ? kMaxK : k;
+    if (kb.k <= 0) return;
+    int ix, iy;
+    bucket_of(m, qx, qy, ix, iy);
+    const int rmax = m.gnx > m.gny ? m.gnx : m.gny;
+    for (int r = 0; r <= rmax; ++r) {
+        const int y0 = iy - r, y1 = iy + r;
+        for (int by = (y0 < 0 ? 0 : y0); by <= (y1 >= m.gny ? m.gny - 1 : y1); ++by) {
+            const int xl = ix - r < 0 ? 0 : ix - r, xr = ix + r >= m.gnx ? m.gnx - 1 : ix + r;
+            const bool full = (by == y0) || (by == y1);
+            for (int part = 0; part < (full ? 1 : 2); ++part) {
+                int b0, b1;
+                if (full) { b0 = by * m.gnx + xl; b1 = by * m.gnx + xr + 1; }
+                else {
+                    const int bx = part == 0 ? ix - r : ix + r;
+                    if (bx < 0 || bx >= m.gnx) continue;
+                    b0 = by * m.gnx + bx; b1 = b0 + 1;
+                }
+                for (int32_t s = m.gstart[b0]; s < m.gstart[b1]; ++s) {
+                    const int32_t id = m.gnode[s];
+                    if (id == skip) continue;
+                    const double dx = qx - m.x[id], dy = qy - m.y[id];
+                    kbest_push(kb, dx * dx + dy * dy, id);
+                }
+            }
+        }
+        const double lb = ring_bound(m, qx, qy, ix, iy, r) - 1e-9 * m.gh;
+        if (lb == __builtin_huge_val()) break;
+        if (kb.n == kb.k && lb > 0.0 && kb.d2[kb.n - 1] < lb * lb) break;
+    }
+}
+
+__device__ __forceinline__ int32_t first_cell_containing(const DMesh &m, int32_t node, double x, double y) {
+    for (int32_t s = m.ncp[node]; s < m.ncp[node + 1]; ++s) {
+        const int32_t c = m.ncd[s];
+        if (point_in_triangle(m, c, x, y)) return c;
+    }
+    return -1;
+}
+
+// The fallback half of find_element (src/mesh.jl:123-132) for find_element(mesh, xp) [k=2]
+// followed, on failure, by find_element(mesh, xp, k) (src/track.jl:122,139).  The second
+// call repeats the first one's tests and then looks at nodes 3..k of the same sorted list,
+// so one sorted list of max(2,k) nodes serves both.
+__device__ __noinline__ int32_t find_element_fallback(const DMesh &m, double x, double y, int k, int32_t nn_id) {
+    KBest kb;
+    const int kk = k > 2 ? k : 2;
+    knearest_nodes(m, x, y, kk, nn_id, kb);
+    const int first = kb.n < 2 ? kb.n : 2;
+    for (int j = 0; j < first; ++j) {
+        const int32_t c = first_cell_containing(m, kb.id[j], x, y);
+        if (c >= 0) return c;
+    }
+    const int lim = kb.n < k ? kb.n : k;  // second call: knn(k) — only new nodes can succeed
+    for (int j = first; j < lim; ++j) {
+        const int32_t c = first_cell_containing(m, kb.id[j], x, y);
+        if (c >= 0) return c;
+    }
+    return -1;
+}
+
+// find_element (src/mesh.jl:103-146), 0-based cell id or -1.
+__device__ __forceinline__ int32_t find_element(const DMesh &m, double x, double y, int k) {
+    const int32_t nn_id = nearest_node(m, x, y);
+    if (nn_id < 0) return -1;
+    const int32_t c = first_cell_containing(m, nn_id, x, y);
+    if (c >= 0) return c;
+    return find_element_fallback(m, x, y, k, nn_id);
+}
+
+// ------------------------------------------------------- intersections -------------------
+// general_form (src/intersection.jl:11-18) of edge p1->p2, intersection with the track line
+// (src/intersection.jl:127-138) and point_in_segment (src/segment.jl:39-44).
+// Returns 0 = no valid intersection, 1 = valid (x,y), 2 = parallel.
+__device__ __forceinline__ int edge_hit(double tA, double tB, double tC, double p1x, double p1y, double p2x,
+                                        double p2y, double &x, double &y) {
+    double eA = p1y - p2y;
+    double eB = p2x - p1x;
+    double eC = p1x * p2y - p2x * p1y;
+    const double nrm = sqrt(eA * eA + eB * eB + eC * eC);
+    eA = eA / nrm;
+    eB = eB / nrm;
+    eC = eC / nrm;
+    const double a = tB * eA;
+    const double b = eB * tA;
+    if (isapprox_s(a, b, kRtolDefault)) return 2;
+    const double det = a - b;
+    x = (tC * eB - eC * tB) / det;
+    y = (tA * eC - eA * tC) / det;
+    const double lpx = norm2(p1x - x, p1y - y);
+    const double lqx = norm2(p2x - x, p2y - y);
+    const double lpq = norm2(p1x - p2x, p1y - p2y);
+    return isapprox_s(lpx + lqx, lpq, kRtolDefault) ? 1 : 0;
+}
+
+// order_intersection_points (src/intersection.jl:151-159)
+__device__ __forceinline__ void order_points(double phi, double x1, double y1, double x2, double y2, double &px,
+                                             double &py, double &qx, double &qy) {
+    const bool first = (phi < kHalfPi) ? (x1 < x2) : (x1 > x2);
+    px = first ? x1 : x2;
+    py = first ? y1 : y2;
+    qx = first ? x2 : x1;
+    qy = first ? y2 : y1;
+}
+
+// intersections(mesh, cell_id, track) (src/intersection.jl:34-119).  Returns false for the
+// branch in which the reference reads an unassigned variable (n_int == 3, all coincident).
+__device__ __forceinline__ bool intersections(const DMesh &m, int32_t cell, double phi, double tA, double tB,
+                                              double tC, double &px, double &py, double &qx, double &qy) {
+    const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
+    const double x1 = m.x[n1], y1 = m.y[n1];
+    const double x2 = m.x[n2], y2 = m.y[n2];
+    const double x3 = m.x[n3], y3 = m.y[n3];
+    double ex0 = 0, ey0 = 0, ex1 = 0, ey1 = 0, ex2 = 0, ey2 = 0;
+    const int h0 = edge_hit(tA, tB, tC, x1, y1, x2, y2, ex0, ey0);
+    const int h1 = edge_hit(tA, tB, tC, x2, y2, x3, y3, ex1, ey1);
+    const int h2 = edge_hit(tA, tB, tC, x3, y3, x1, y1, ex2, ey2);
+    const bool v0 = h0 == 1, v1 = h1 == 1, v2 = h2 == 1;
+    const bool parallel_found = (h0 == 2) || (h1 == 2) || (h2 == 2);
+    const int n_int = (int)v0 + (int)v1 + (int)v2;
+    if (n_int == 3) {
+        // farthest pair over (1,2), (1,3), (2,3) with a strict `>` (src/intersection.jl:81-94)
+        double l = 0.0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
+        bool have = false;
+        double li = norm2(ex0 - ex1, ey0 - ey1);
+        if (li > l) { a1x = ex0; a1y = ey0; a2x = ex1; a2y = ey1; l = li; have = true; }
+        li = norm2(ex0 - ex2, ey0 - ey2);
+        if (li > l) { a1x = ex0; a1y = ey0; a2x = ex2; a2y = ey2; l = li; have = true; }
+        li = norm2(ex1 - ex2, ey1 - ey2);
+        if (li > l) { a1x = ex1; a1y = ey1; a2x = ex2; a2y = ey2; l = li; have = true; }
+        if (!have) return false;
+        order_points(phi, a1x, a1y, a2x, a2y, px, py, qx, qy);
+        return true;
+    }
+    if (n_int == 2) {
+        const double f_x = v0 ? ex0 : ex1, f_y = v0 ? ey0 : ey1;  // first valid edge in edge order
+        const double s_x = v2 ? ex2 : ex1, s_y = v2 ? ey2 : ey1;  // second valid edge
+        if (!parallel_found && isapprox_v2(f_x, f_y, s_x, s_y)) {
+            px = f_x; py = f_y; qx = s_x; qy = s_y;  // unordered; the caller skips it (src/intersection.jl:107-110)
+        } else {
+            order_points(phi, f_x, f_y, s_x, s_y, px, py, qx, qy);
+        }
+        return true;
+    }
+    px = py = qx = qy = 0.0;  // n_int in {0,1}: the caller moves a tiny step (src/intersection.jl:114-118)
+    return true;
+}
+
+}  // namespace rt
