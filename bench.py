@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the HIP segmentize! path — BASELINE.json's metric on BASELINE.json's config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full ``segmentize!`` (``rt_segmentize``: device march of every track, CSR
+offsets, compact segment records, fused ``fill_volumes``) over a batch of tracks that is
+already resident in HBM.  N=1: the headline configuration, ``demo/pincell.msh`` at nφ=128,
+δ=1e-3 (130,456 tracks, 9.32 M segments).  N>1 (launched by ``torch.distributed.run``, one
+rank per GPU): weak scaling — the global problem is the same mesh at nφ=128, δ=1e-3/N (≈N×
+the tracks), ``tracks_by_uid`` is split into N contiguous uid ranges balanced by Σℓ, every
+rank marches its own range, and the only data-path exchange of the reference's algorithm
+(``fill_volumes``' cross-track sum) is one RCCL all-reduce of ``n_cells`` doubles inside the
+timed step.  Reassembling the global segment list on every rank (an RCCL all-gather of the
+segment arrays) is measured after the timed region and reported under ``"allgather"``.
+
+The JSON line also carries ``roofline`` (dominant kernel, algorithmic bytes ÷ HIP-event
+duration against the 8 TB/s HBM peak) and, at N=1, ``cpu_baseline`` (the oracle — a C port
+of the reference's algorithm — timed on the host cores of the same box).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+BYTES_PER_SEGMENT = 45.0      # 44 B written + ≈1.3 B of amortised track input
+
+
+def cpu_baseline(tg, max_seconds=30.0):
+    """Oracle (C port of the reference's algorithm, libm trig per advance_step as the
+    reference does) on the host cores.  Checker code used as a reported baseline only."""
+    from oracle import oracle as orc
+
+    orc.build()
+    cores = orc.num_threads()
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    # all-core leg: the full workload once (≈10–30 core-seconds on this box class)
+    t0 = time.perf_counter()
+    r = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, tiny_step=tg.tiny_step, n_threads=0)
+    dt_all = time.perf_counter() - t0
+    # single-core leg: every 16th track (bounded)
+    sel = np.arange(0, tg.n_total_tracks, 16)
+    om1 = orc.OracleMesh.from_mesh(tg.mesh, omp=False)
+    t0 = time.perf_counter()
+    r1 = om1.segmentize(tg.px[sel], tg.py[sel], tg.phi[sel], tg.A[sel], tg.B[sel], tg.C[sel], tg.ell[sel],
+                        tiny_step=tg.tiny_step, n_threads=1)
+    dt_1 = time.perf_counter() - t0
+    return {
+        "value": r["total"] / dt_all, "unit": "segments/s", "cores": int(cores), "kind": "port",
+        "sample": "full workload once (%d tracks, %d segments), OpenMP over tracks, %.2f s wall"
+                  % (tg.n_total_tracks, r["total"], dt_all),
+        "single_core": {"value": r1["total"] / dt_1, "unit": "segments/s", "cores": 1,
+                        "sample": "every 16th track (%d tracks, %d segments), %.2f s" % (len(sel), r1["total"], dt_1)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-azim", type=int, default=128)
+    ap.add_argument("--delta", type=float, default=1e-3)
+    ap.add_argument("--mesh", default="pincell.msh")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raytracing_jl_amd as rt
+    from raytracing_jl_amd import _capi
+    from raytracing_jl_amd import distributed as rtd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload (deterministic, no RNG): host-side trace! then upload the rank's uid range
+    mesh_file = rt.data_path(args.mesh)
+    model = rt.GmshDiscreteModel(mesh_file) if mesh_file.endswith(".msh") else rt.DiscreteModelFromFile(mesh_file)
+    delta = args.delta / world
+    tg = rt.TrackGenerator(model, args.n_azim, delta)
+    rt.trace(tg)
+    aq = tg.azimuthal_quadrature
+    dmesh = _capi.DeviceMesh(tg.mesh, local_rank)
+    stream = torch.cuda.current_stream(dev)
+    dmesh.set_stream(stream.cuda_stream)  # kernels run on torch's current stream
+    dt, (lo, hi) = rtd.segmentize_shard(tg, rank, world, device=local_rank, dmesh=dmesh)
+
+    def step():
+        total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        if world > 1:
+            p = dt.device_pointers()
+            vol = torch.as_tensor(rtd.DevArray(p["volumes"], dmesh.n_cells, "<f8", dt), device=dev)
+            rtd.allreduce_volumes(vol)
+        return total
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        local_total = step()
+    sync()
+    kern = {"march": 0.0, "fill": 0.0, "scan": 0.0, "volumes": 0.0, "plan": 0.0, "total": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        local_total = step()
+        tm = dt.timing()  # HIP events recorded on the launch stream inside rt_segmentize
+        for k in kern:
+            kern[k] += tm[k]
+    sync()
+    elapsed = time.perf_counter() - t0
+    n_failed, _, _ = dt.failed()
+    if n_failed:
+        raise SystemExit(f"{n_failed} tracks failed on rank {rank}")
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(local_total)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    t_max = float(t_max.item())
+    global_segments = float(tot.item())
+
+    # ---- optional: reassemble the global segment list on every rank (RCCL all-gather)
+    allgather = None
+    if world > 1 and not args.no_allgather:
+        p = dt.device_pointers()
+        off = torch.as_tensor(rtd.DevArray(p["offsets"], dt.n + 1, "<i8", dt), device=dev)
+        local = {"counts": off[1:] - off[:-1]}
+        for name in ("px", "py", "qx", "qy", "ell"):
+            local[name] = torch.as_tensor(rtd.DevArray(p[name], local_total, "<f8", dt), device=dev)
+        local["element"] = torch.as_tensor(rtd.DevArray(p["element"], local_total, "<i4", dt), device=dev)
+        rtd.allgather_segments(local)  # warm-up
+        sync()
+        reps = 3
+        g0 = time.perf_counter()
+        for _ in range(reps):
+            g = rtd.allgather_segments(local)
+        sync()
+        g_ms = (time.perf_counter() - g0) / reps * 1e3
+        gt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        assert int(g["offsets"][-1].item()) == int(global_segments)
+        allgather = {"ms": float(gt.item()), "bytes_per_rank_received": 44.0 * global_segments,
+                     "segments_per_s_including_allgather": global_segments / (t_max / args.steps + float(gt.item()) / 1e3)}
+        del g
+
+    if rank == 0:
+        ms_per_step = t_max / args.steps * 1e3
+        dom = "fill" if kern["fill"] >= kern["march"] else "march"
+        dom_ms = kern[dom] / args.steps
+        achieved = BYTES_PER_SEGMENT * local_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "segments/sec (whole node)",
+            "value": global_segments * args.steps / t_max,
+            "unit": "segments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (deterministic tracks from trace! on the reference's demo/pincell.msh; no RNG)",
+            "config": {
+                "workload": "%s, nφ=%d, δ=%g (global), all tracks of tracks_by_uid; segmentize! = march + CSR offsets "
+                            "+ compact segment records + fill_volumes" % (args.mesh, args.n_azim, delta),
+                "tracks_global": int(tg.n_total_tracks), "segments_global": int(global_segments),
+                "tracks_rank0": int(hi - lo), "segments_rank0": int(local_total),
+                "sharding": "contiguous uid ranges balanced by Σℓ; all-reduce(sum) of volumes" if world > 1 else "none",
+                "tiny_step": tg.tiny_step, "k": 5, "rtol": rt.RTOL_DEFAULT,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_march<%s>" % ("true" if dom == "fill" else "false"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_segment": BYTES_PER_SEGMENT, "segments_per_launch": int(local_total),
+                "kernel_ms_avg": dom_ms,
+                "note": "FP64 traversal, not a streaming kernel: 45 B/segment of algorithmic traffic cannot approach the "
+                        "HBM roof; the limiter is the per-track dependent chain (see DESIGN.md)",
+            },
+            "kernel_ms": {k: v / args.steps for k, v in kern.items()},
+        }
+        if allgather is not None:
+            out["allgather"] = allgather
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tg)
+        print(json.dumps(out, ensure_ascii=False))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""Multi-GPU sharding of ``segmentize!``: one process per GPU, tracks partitioned by uid.
+
+Tracks are independent in the reference (``src/trackgenerator.jl:362-364``: each track only
+writes its own ``segments``), so the path shards without any data-path exchange: rank ``r``
+marches a contiguous uid range balanced by Σℓ (segments ∝ ℓ).  The only reduction the
+reference performs across tracks is ``fill_volumes`` (``src/trackgenerator.jl:378-386``),
+which becomes one all-reduce(sum) of ``n_cells`` doubles.  Reassembling the global segment
+list on every rank (``allgather_segments``) is optional: a consumer that stays sharded (a
+transport sweep over the rank's own tracks) does not need it.
+
+``torch.distributed`` is plumbing here (RCCL when the backend is ``nccl``; ``gloo`` in the
+CPU tests).  The compute function is injected so the CPU tests can exercise the partition /
+gather logic without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Tuple
+
+import numpy as np
+
+__all__ = ["shard_ranges", "shard_arrays", "segmentize_shard", "allreduce_volumes",
+           "allgather_segments", "DevArray", "TRACK_FIELDS"]
+
+TRACK_FIELDS = ("px", "py", "phi", "cos_phi", "sin_phi", "A", "B", "C", "ell", "azim_idx")
+
+
+def shard_ranges(ell: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous 0-based uid ranges ``[lo, hi)`` per rank with ≈ equal Σℓ."""
+    n = len(ell)
+    if world_size <= 0:
+        raise ValueError("world_size must be positive")
+    cum = np.concatenate(([0.0], np.cumsum(ell, dtype=np.float64)))
+    targets = cum[-1] * np.arange(1, world_size) / world_size
+    cuts = np.searchsorted(cum, targets, side="left")
+    cuts = np.clip(cuts, 0, n)
+    bounds = np.concatenate(([0], cuts, [n])).astype(np.int64)
+    bounds = np.maximum.accumulate(bounds)
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world_size)]
+
+
+def shard_arrays(tg, lo: int, hi: int) -> Dict[str, np.ndarray]:
+    """The per-track inputs of uid range ``[lo, hi)`` (0-based) as contiguous arrays."""
+    return {k: np.ascontiguousarray(getattr(tg, k)[lo:hi]) for k in TRACK_FIELDS}
+
+
+class DevArray:
+    """Zero-copy view of library-owned device memory for ``torch.as_tensor`` (exposes
+    ``__cuda_array_interface__``; the owner keeps the memory alive)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str, owner):
+        self.__cuda_array_interface__ = {
+            "shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None,
+        }
+        self._owner = owner
+
+
+def segmentize_shard(tg, rank: int, world_size: int, *, device: int = 0, k: int = 5, rtol: float | None = None,
+                     dmesh=None):
+    """Upload this rank's uid range and return ``(DeviceTracks, (lo, hi))`` ready for
+    ``DeviceTracks.segmentize`` (HIP path; raises without a GPU)."""
+    from . import _capi
+
+    lo, hi = shard_ranges(tg.ell, world_size)[rank]
+    a = shard_arrays(tg, lo, hi)
+    dm = dmesh if dmesh is not None else _capi.DeviceMesh(tg.mesh, device)
+    dt = _capi.DeviceTracks(dm, a["px"], a["py"], a["phi"], a["cos_phi"], a["sin_phi"], a["A"], a["B"], a["C"],
+                            a["ell"], a["azim_idx"])
+    return dt, (lo, hi)
+
+
+def allreduce_volumes(volumes, group=None):
+    """Sum the per-rank partial ``volumes`` (each already divided by ``n_azim_2``) in place."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(volumes, op=dist.ReduceOp.SUM, group=group)
+    return volumes
+
+
+def allgather_segments(local: dict, group=None) -> dict:
+    """Reassemble the global segment list on every rank.
+
+    ``local``: torch tensors of this rank's shard — ``counts`` (int64, per local track),
+    ``px, py, qx, qy, ell`` (float64) and ``element`` (int32), all on one device.  Ranks own
+    contiguous uid ranges in rank order, so concatenating shards in rank order is uid
+    order.  Two padded collectives move the payload (one f64 block of 5 rows, one i32 row);
+    RCCL has no all-gather-v.  Returns ``offsets`` (int64, n_tracks+1) and the six arrays.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dev = local["ell"].device
+    n_seg = int(local["ell"].numel())
+    n_trk = int(local["counts"].numel())
+    if world == 1:
+        counts = local["counts"]
+        out = {k: local[k] for k in ("px", "py", "qx", "qy", "ell", "element")}
+    else:
+        sizes = torch.tensor([n_seg, n_trk], dtype=torch.int64, device=dev)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        all_sizes = torch.stack(all_sizes).cpu().numpy()
+        max_seg, max_trk = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+        f = torch.zeros((5, max(max_seg, 1)), dtype=torch.float64, device=dev)
+        for i, name in enumerate(("px", "py", "qx", "qy", "ell")):
+            f[i, :n_seg] = local[name]
+        e = torch.zeros(max(max_seg, 1), dtype=torch.int32, device=dev)
+        e[:n_seg] = local["element"]
+        c = torch.zeros(max(max_trk, 1), dtype=torch.int64, device=dev)
+        c[:n_trk] = local["counts"]
+        gf = torch.empty((world,) + tuple(f.shape), dtype=f.dtype, device=dev)
+        ge = torch.empty((world, e.numel()), dtype=e.dtype, device=dev)
+        gc = torch.empty((world, c.numel()), dtype=c.dtype, device=dev)
+        dist.all_gather_into_tensor(gf, f, group=group)
+        dist.all_gather_into_tensor(ge, e, group=group)
+        dist.all_gather_into_tensor(gc, c, group=group)
+        out = {}
+        for i, name in enumerate(("px", "py", "qx", "qy", "ell")):
+            out[name] = torch.cat([gf[r, i, : int(all_sizes[r, 0])] for r in range(world)])
+        out["element"] = torch.cat([ge[r, : int(all_sizes[r, 0])] for r in range(world)])
+        counts = torch.cat([gc[r, : int(all_sizes[r, 1])] for r in range(world)])
+    offsets = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    out["offsets"] = offsets
+    return out
