@@ -109,12 +109,16 @@ def allgather_segments(local: dict, group=None) -> dict:
         e[:n_seg] = local["element"]
         c = torch.zeros(max(max_trk, 1), dtype=torch.int64, device=dev)
         c[:n_trk] = local["counts"]
-        gf = torch.empty((world,) + tuple(f.shape), dtype=f.dtype, device=dev)
-        ge = torch.empty((world, e.numel()), dtype=e.dtype, device=dev)
-        gc = torch.empty((world, c.numel()), dtype=c.dtype, device=dev)
+        # outputs in the concatenated form (world*rows, ...), which both RCCL and gloo accept
+        gf = torch.empty((world * 5, f.shape[1]), dtype=f.dtype, device=dev)
+        ge = torch.empty(world * e.numel(), dtype=e.dtype, device=dev)
+        gc = torch.empty(world * c.numel(), dtype=c.dtype, device=dev)
         dist.all_gather_into_tensor(gf, f, group=group)
         dist.all_gather_into_tensor(ge, e, group=group)
         dist.all_gather_into_tensor(gc, c, group=group)
+        gf = gf.view(world, 5, -1)
+        ge = ge.view(world, -1)
+        gc = gc.view(world, -1)
         out = {}
         for i, name in enumerate(("px", "py", "qx", "qy", "ell")):
             out[name] = torch.cat([gf[r, i, : int(all_sizes[r, 0])] for r in range(world)])
