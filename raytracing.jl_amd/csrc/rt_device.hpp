@@ -16,8 +16,22 @@ constexpr double kHalfPi = 1.5707963267948966;          // Float64(pi)/2, src/in
 constexpr int kMaxIter = 10000;                         // const MAX_ITER, src/track.jl:104
 constexpr int kMaxK = 8;                                // cap on the knn fallback width `k`
 
+// Per-cell record of the walk step (built on the host, rt_mesh_prep.hpp).  144 B, 16-B aligned:
+// one lane fetches its next cell with nine independent 16-B loads (one L2 round trip).
+struct __attribute__((aligned(16))) CellRec {
+    int32_t adj[3];  // neighbour across edge k = (v_k, v_{k+1 mod 3}); -1 on the domain boundary
+    int32_t meta;    // bits 0..7: bound on non-vertex nodes nearer than the nearest vertex; 255 = no walk
+    double vx[3], vy[3];           // vertex coordinates in the reference's per-cell node order
+    double eA[3], eB[3], eC[3];    // general_form of edge k (src/intersection.jl:11-18), precomputed bit-exactly
+    double pad;
+};
+static_assert(sizeof(CellRec) == 144, "CellRec layout");
+
 // Flattened mesh in HBM (SoA; all ids 0-based on the device, converted at upload).
 struct DMesh {
+    const CellRec *__restrict__ rec;     // [n_cells] walk records
+    double eps_iso, d_vertex, l_min;     // certificate margins of the walk step
+    int32_t walk_ok;
     const double *__restrict__ x;        // [n_nodes]
     const double *__restrict__ y;        // [n_nodes]
     const int32_t *__restrict__ cn;      // [3*n_cells] cell -> nodes, reference order
@@ -273,19 +287,23 @@ __device__ __forceinline__ int edge_hit(double tA, double tB, double tC, double 
 }
 
 // order_intersection_points (src/intersection.jl:151-159)
-__device__ __forceinline__ void order_points(double phi, double x1, double y1, double x2, double y2, double &px,
+__device__ __forceinline__ bool order_points(double phi, double x1, double y1, double x2, double y2, double &px,
                                              double &py, double &qx, double &qy) {
     const bool first = (phi < kHalfPi) ? (x1 < x2) : (x1 > x2);
     px = first ? x1 : x2;
     py = first ? y1 : y2;
     qx = first ? x2 : x1;
     qy = first ? y2 : y1;
+    return first;  // true: (x1,y1) is the entry point
 }
 
 // intersections(mesh, cell_id, track) (src/intersection.jl:34-119).  Returns false for the
 // branch in which the reference reads an unassigned variable (n_int == 3, all coincident).
+// `eq` receives the index (0..2) of the cell edge the exit point q lies on (-1 if q was not
+// produced): the walk step uses it to predict the next cell through the adjacency table.
 __device__ __forceinline__ bool intersections(const DMesh &m, int32_t cell, double phi, double tA, double tB,
-                                              double tC, double &px, double &py, double &qx, double &qy) {
+                                              double tC, double &px, double &py, double &qx, double &qy, int &eq) {
+    eq = -1;
     const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
     const double x1 = m.x[n1], y1 = m.y[n1];
     const double x2 = m.x[n2], y2 = m.y[n2];
@@ -301,28 +319,154 @@ __device__ __forceinline__ bool intersections(const DMesh &m, int32_t cell, doub
         // farthest pair over (1,2), (1,3), (2,3) with a strict `>` (src/intersection.jl:81-94)
         double l = 0.0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
         bool have = false;
+        int e1 = -1, e2 = -1;
         double li = norm2(ex0 - ex1, ey0 - ey1);
-        if (li > l) { a1x = ex0; a1y = ey0; a2x = ex1; a2y = ey1; l = li; have = true; }
+        if (li > l) { a1x = ex0; a1y = ey0; a2x = ex1; a2y = ey1; l = li; have = true; e1 = 0; e2 = 1; }
         li = norm2(ex0 - ex2, ey0 - ey2);
-        if (li > l) { a1x = ex0; a1y = ey0; a2x = ex2; a2y = ey2; l = li; have = true; }
+        if (li > l) { a1x = ex0; a1y = ey0; a2x = ex2; a2y = ey2; l = li; have = true; e1 = 0; e2 = 2; }
         li = norm2(ex1 - ex2, ey1 - ey2);
-        if (li > l) { a1x = ex1; a1y = ey1; a2x = ex2; a2y = ey2; l = li; have = true; }
+        if (li > l) { a1x = ex1; a1y = ey1; a2x = ex2; a2y = ey2; l = li; have = true; e1 = 1; e2 = 2; }
         if (!have) return false;
-        order_points(phi, a1x, a1y, a2x, a2y, px, py, qx, qy);
+        eq = order_points(phi, a1x, a1y, a2x, a2y, px, py, qx, qy) ? e2 : e1;
         return true;
     }
     if (n_int == 2) {
         const double f_x = v0 ? ex0 : ex1, f_y = v0 ? ey0 : ey1;  // first valid edge in edge order
         const double s_x = v2 ? ex2 : ex1, s_y = v2 ? ey2 : ey1;  // second valid edge
+        const int fe = v0 ? 0 : 1, se = v2 ? 2 : 1;
         if (!parallel_found && isapprox_v2(f_x, f_y, s_x, s_y)) {
             px = f_x; py = f_y; qx = s_x; qy = s_y;  // unordered; the caller skips it (src/intersection.jl:107-110)
         } else {
-            order_points(phi, f_x, f_y, s_x, s_y, px, py, qx, qy);
+            eq = order_points(phi, f_x, f_y, s_x, s_y, px, py, qx, qy) ? se : fe;
         }
         return true;
     }
     px = py = qx = qy = 0.0;  // n_int in {0,1}: the caller moves a tiny step (src/intersection.jl:114-118)
     return true;
+}
+
+// ======================================================================= walk step ========
+// After a segment has been emitted in cell T with its exit point q on edge `ko`, the reference
+// re-seeds at xp = q + tiny_step·(cos ϕ, sin ϕ) and locates from scratch (src/track.jl:165,
+// 122).  The walk step predicts the located cell as T' = adj[T][ko] and PROVES, with
+// certificates whose margins are orders of magnitude above the reference's tolerances and
+// above FP64 rounding, that the reference's own procedure returns T' (or returns T again and
+// takes its `prev_element == element` branch) and that `intersections(T')` yields exactly
+// (entry on the shared edge, exit on one other edge).  Everything that reaches the output or
+// the next state (λ of T at xp, q', ℓ', xp) is computed with the reference's formulas and
+// operation order; the certificates themselves may use any arithmetic.  When a certificate
+// fails the lane runs the generic step (find_element + intersections above) for that
+// iteration, so results never depend on which path was taken.
+//
+// Why only T and T' can contain xp (up to the √eps barycentric tolerance): xp lies within
+// tiny_step of the interior of the shared edge and, by the isolation certificate, at least
+// eps_iso (barycentric) away from the other two edges of T'; eps_iso is sized on the host so
+// that this distance exceeds every other cell's tolerance band.  find_element scans the cell
+// lists of nodes in order of distance and returns the first cell that passes; T' always
+// passes; T passes iff the exact λ below is ≥ -√eps ("shallow crossing").  T is scanned
+// before T' iff the nearest of {a, b, c, c'} is c, or it is a or b and T < T' (lists are
+// ascending in cell id).  `meta` bounds how many other nodes can precede, so the scan stays
+// inside the window find_element(xp) / find_element(xp, k) covers.
+struct Walk {
+    int32_t T;       // cell of the last emitted segment (prev_element), -1 at the start
+    int32_t pred;    // predicted next cell adj[T][ko], -1: no prediction
+    double ax, ay, bx, by;  // endpoints of T's exit edge, in T's edge orientation
+    double cx, cy;          // T's vertex opposite the exit edge
+    double dT;              // det of T's barycentric system in T's node order (exact reference ops)
+};
+
+// λ of T for the vertex opposite its exit edge, evaluated at (x, y) exactly as
+// point_in_triangle does (src/mesh.jl:166-168 via the 3x3 closed form).
+__device__ __forceinline__ double lambda_opposite(const Walk &w, double x, double y) {
+    return ((w.ay - w.by) * x + (w.bx - w.ax) * y + (w.ax * w.by - w.bx * w.ay)) / w.dT;
+}
+
+// Load the state the next walk step needs after a segment was emitted in `cell` with its exit
+// point on edge `ko` (0..2).  R must be rec[cell].
+__device__ __forceinline__ void walk_enter(Walk &w, const CellRec &R, int32_t cell, int ko) {
+    const double x1 = R.vx[0], y1 = R.vy[0], x2 = R.vx[1], y2 = R.vy[1], x3 = R.vx[2], y3 = R.vy[2];
+    w.T = cell;
+    w.dT = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
+    w.ax = ko == 0 ? x1 : (ko == 1 ? x2 : x3);
+    w.ay = ko == 0 ? y1 : (ko == 1 ? y2 : y3);
+    w.bx = ko == 0 ? x2 : (ko == 1 ? x3 : x1);
+    w.by = ko == 0 ? y2 : (ko == 1 ? y3 : y1);
+    w.cx = ko == 0 ? x3 : (ko == 1 ? x1 : x2);
+    w.cy = ko == 0 ? y3 : (ko == 1 ? y1 : y2);
+    w.pred = ko == 0 ? R.adj[0] : (ko == 1 ? R.adj[1] : R.adj[2]);
+}
+
+enum WalkResult { kWalkGeneric = 0, kWalkSkip = 1, kWalkEmit = 2 };
+
+// One walk step at xp for the lane's predicted cell.  On kWalkEmit: (qx,qy) is the exit point,
+// `ell` the segment length (entry point = previous exit point, bit-identical by symmetry of the
+// edge's general form), and `w` is advanced to the new cell.  On kWalkSkip the reference takes
+// its `prev_element == element` branch (src/track.jl:147-150).  kWalkGeneric: no decision.
+__device__ __forceinline__ WalkResult walk_step(const DMesh &m, Walk &w, int kk, double tA, double tB, double tC,
+                                                double xpx, double xpy, double ppx, double ppy, double &qx,
+                                                double &qy, double &ell) {
+    const int32_t Tn = w.pred;
+    const CellRec &R = m.rec[Tn];
+    const int32_t a0 = R.adj[0], a1 = R.adj[1], a2 = R.adj[2], meta = R.meta;
+    const double x0 = R.vx[0], x1 = R.vx[1], x2 = R.vx[2];
+    const double y0 = R.vy[0], y1 = R.vy[1], y2 = R.vy[2];
+    const int ki = a0 == w.T ? 0 : (a1 == w.T ? 1 : (a2 == w.T ? 2 : -1));
+    if (ki < 0 || (meta & 255) > kk) return kWalkGeneric;
+    // --- certificate 1: the track line clears every vertex of T' by d_vertex
+    const double s0 = tA * x0 + tB * y0 + tC, s1 = tA * x1 + tB * y1 + tC, s2 = tA * x2 + tB * y2 + tC;
+    if (!(fabs(s0) >= m.d_vertex && fabs(s1) >= m.d_vertex && fabs(s2) >= m.d_vertex)) return kWalkGeneric;
+    const bool p0 = s0 > 0, p1 = s1 > 0, p2 = s2 > 0;
+    const bool c0 = p0 != p1, c1 = p1 != p2, c2 = p2 != p0;  // edge k is crossed by the line
+    const bool cki = ki == 0 ? c0 : (ki == 1 ? c1 : c2);
+    if (!cki) return kWalkGeneric;
+    // exactly two edges are crossed; the exit edge is the crossed one that is not the entry edge
+    const int ko = ki == 0 ? (c1 ? 1 : 2) : (ki == 1 ? (c2 ? 2 : 0) : (c0 ? 0 : 1));
+    // --- certificate 2: xp is inside T', at least eps_iso (barycentric) from the two other edges
+    const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    const double w0 = ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0)) / area2;  // weight of v2 (edge 0)
+    const double w1 = ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1)) / area2;  // weight of v0 (edge 1)
+    const double w2 = ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2)) / area2;  // weight of v1 (edge 2)
+    const double wi = ki == 0 ? w0 : (ki == 1 ? w1 : w2);
+    const double wa = ki == 0 ? w1 : (ki == 1 ? w2 : w0);
+    const double wb = ki == 0 ? w2 : (ki == 1 ? w0 : w1);
+    if (!(wi >= -0.25 * kRtolDefault && wa >= m.eps_iso && wb >= m.eps_iso)) return kWalkGeneric;
+    // --- shallow crossing: does T still pass the reference's barycentric test at xp?
+    const double lamT = lambda_opposite(w, xpx, xpy);
+    if (lamT >= 0.0 - kRtolDefault) {
+        // scan order of find_element: nearest of {a, b, c, c'}
+        const double cpx = ki == 0 ? x2 : (ki == 1 ? x0 : x1), cpy = ki == 0 ? y2 : (ki == 1 ? y0 : y1);
+        const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
+        const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
+        const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
+        const double dcp = (xpx - cpx) * (xpx - cpx) + (xpy - cpy) * (xpy - cpy);
+        const double dab = da < db ? da : db;
+        // ties between exactly equidistant nodes are left to the generic step
+        if (dc == dab || dcp == dab || dc == dcp) return kWalkGeneric;
+        const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn);
+        if (t_first) return kWalkSkip;
+    }
+    // --- exit point on edge ko: intersection(track.ABC, ABC) — src/intersection.jl:127-138
+    const double eA = ko == 0 ? R.eA[0] : (ko == 1 ? R.eA[1] : R.eA[2]);
+    const double eB = ko == 0 ? R.eB[0] : (ko == 1 ? R.eB[1] : R.eB[2]);
+    const double eC = ko == 0 ? R.eC[0] : (ko == 1 ? R.eC[1] : R.eC[2]);
+    const double a = tB * eA;
+    const double b = eB * tA;
+    const double det = a - b;
+    qx = (tC * eB - eC * tB) / det;
+    qy = (tA * eC - eA * tC) / det;
+    ell = norm2(ppx - qx, ppy - qy);  // Segment ctor, src/segment.jl:31-33
+    if (!(ell >= m.l_min)) return kWalkGeneric;
+    // --- advance the state to T'
+    w.T = Tn;
+    w.dT = x0 * (y1 - y2) + y0 * (x2 - x1) + (x1 * y2 - y1 * x2);
+    w.ax = ko == 0 ? x0 : (ko == 1 ? x1 : x2);
+    w.ay = ko == 0 ? y0 : (ko == 1 ? y1 : y2);
+    w.bx = ko == 0 ? x1 : (ko == 1 ? x2 : x0);
+    w.by = ko == 0 ? y1 : (ko == 1 ? y2 : y0);
+    w.cx = ko == 0 ? x2 : (ko == 1 ? x0 : x1);
+    w.cy = ko == 0 ? y2 : (ko == 1 ? y0 : y1);
+    w.pred = ko == 0 ? a0 : (ko == 1 ? a1 : a2);
+    return kWalkEmit;
 }
 
 }  // namespace rt

@@ -21,6 +21,7 @@
 
 #include "../../include/rt_segmentize.h"
 #include "rt_device.hpp"
+#include "rt_mesh_prep.hpp"
 
 namespace {
 
@@ -75,16 +76,43 @@ struct DOut {
     int32_t *__restrict__ element;
     double *__restrict__ volumes;  // accumulated δs·ℓ per cell (un-normalised)
     const double *__restrict__ delta_s;
+    int32_t fused_volumes;  // 1: accumulate δs·ℓ with global f64 atomics inside the fill march
 };
 
-// One lane marches one track (_segmentize_track!, src/track.jl:106-178).  FILL=false counts
-// segments and sets the track status; FILL=true re-runs the identical march and writes the
-// records at the track's CSR offset (+ fused fill_volumes accumulation).
-template <bool FILL>
+// Staging of the single-pass march: a pool of chunks, each kChunkRows rows of 64 lanes, per
+// output array.  Lane l of a wave writes its i-th segment to row i of the wave's chunk list,
+// column l — lanes of a wave emit in near lockstep, so each store instruction writes whole
+// 512-B rows instead of 64 scattered 8-B pieces.  Chunks are handed out from one atomic
+// cursor, once per wave and chunk (wave-aggregated), and recorded in `ctab` for k_compact.
+constexpr int kChunkRows = 16;
+constexpr int kChunkLog2 = 4;
+constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
+
+struct DStage {
+    double *__restrict__ px, *__restrict__ py, *__restrict__ qx, *__restrict__ qy, *__restrict__ ell;
+    int32_t *__restrict__ element;
+    int32_t *__restrict__ ctab;     // [n_waves][kMaxChunks] chunk ids
+    int32_t *__restrict__ cursor;   // [0] chunks handed out, [1] overflow flag
+    int32_t pool_chunks;
+};
+
+enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
+
+// One lane marches one track (_segmentize_track!, src/track.jl:106-178); one wave per
+// workgroup.  kStage: single pass, records go to the wave-interleaved staging pool (then
+// k_compact).  kCount / kFill: the two-pass variant (count, scan, re-march writing at the CSR
+// offsets).  All modes set counts[] / status[] identically.
+template <int MODE>
 __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                               int32_t *__restrict__ status,
-                                              const int64_t *__restrict__ offsets, DOut out,
+                                              const int64_t *__restrict__ offsets, DOut out, DStage stg,
                                               unsigned long long *__restrict__ fail_info) {
+    __shared__ volatile int32_t chunk_lds[MODE == kStage ? kMaxChunks : 1];
+    const int lane = threadIdx.x;
+    if (MODE == kStage) {
+        for (int c = lane; c < kMaxChunks; c += 64) chunk_lds[c] = -1;
+        __syncthreads();
+    }
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= t.n) return;
     const int32_t u = t.perm[slot];
@@ -96,15 +124,21 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
     double xpx = t.px[u] + sx, xpy = t.py[u] + sy;  // src/track.jl:114
     int64_t base = 0;
     double w = 0.0;
-    if (FILL) {
+    if (MODE == kFill) {
         base = offsets[u];
         w = out.delta_s[t.azim[u] - 1];
     }
+    int32_t my_chunk = -1;
     int i = 0;
     int64_t it = 0;
     int32_t prev_element = -1;
     int st = RT_TRACK_OK;
     double sum_ell = 0.0;
+    Walk wk;
+    wk.T = -1; wk.pred = -1;
+    wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
+    const int kk = prm.k > 2 ? prm.k : 2;
+    double lqx = 0.0, lqy = 0.0;  // exit point of the last emitted segment
     while (i < kMaxIter) {  // :119
         if (++it > prm.iter_cap) { st = RT_TRACK_ITER_CAP; break; }
         // The reference locates first and tests the boundary second (:122-125); the locate
@@ -113,30 +147,86 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
             if (i == 0) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :126-129
             break;                                                      // :130-132
         }
-        const int32_t element = find_element(m, xpx, xpy, prm.k);  // :122 and :138-139
-        if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }   // :140-143
-        if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
-        double px, py, qx, qy;
-        if (!intersections(m, element, phi, tA, tB, tC, px, py, qx, qy)) {  // :153
-            st = RT_TRACK_UNDEF_INTERSECTION;
-            break;
+        double px, py, qx, qy, ell;
+        int32_t element = -1;
+        int res = kWalkGeneric;
+        if (m.walk_ok && wk.pred >= 0) {
+            res = walk_step(m, wk, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+#ifdef RT_STATS
+            if (MODE != kFill) atomicAdd(&fail_info[2 + res], 1ull);
+#endif
+            if (res == kWalkSkip) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
+            if (res == kWalkEmit) { px = lqx; py = lqy; element = wk.T; }
         }
-        if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :156-159
-        const double ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
-        if (FILL) {
+#ifdef RT_STATS
+        if (MODE != kFill) {
+            const unsigned long long any_gen = __ballot(res == kWalkGeneric);
+            if (lane == __ffsll((long long)__ballot(1)) - 1) {
+                atomicAdd(&fail_info[5], 1ull);                       // wave iterations reaching here
+                if (any_gen) atomicAdd(&fail_info[6], 1ull);          // ... with at least one generic lane
+            }
+        }
+#endif
+        if (res == kWalkGeneric) {
+            element = find_element(m, xpx, xpy, prm.k);               // :122 and :138-139
+            if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
+            if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
+            int eq;
+            if (!intersections(m, element, phi, tA, tB, tC, px, py, qx, qy, eq)) {  // :153
+                st = RT_TRACK_UNDEF_INTERSECTION;
+                break;
+            }
+            if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :156-159
+            ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
+            if (m.walk_ok && eq >= 0) walk_enter(wk, m.rec[element], element, eq);
+            else { wk.T = element; wk.pred = -1; }
+        }
+        if (MODE == kFill) {
             const int64_t o = base + i;
             out.px[o] = px; out.py[o] = py; out.qx[o] = qx; out.qy[o] = qy;
             out.ell[o] = ell;
             out.element[o] = element + 1;
-            unsafeAtomicAdd(&out.volumes[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382
-        } else {
-            sum_ell += ell;
+            if (out.fused_volumes) unsafeAtomicAdd(&out.volumes[element], w * ell);  // src/trackgenerator.jl:382
+        } else if (MODE == kStage) {
+            const int r = i & (kChunkRows - 1);
+            if (r == 0) {
+                // First row of a new chunk for this lane: wave-aggregated allocation among the
+                // lanes that are here.  chunk_lds[j] caches what the wave already owns.
+                const int j = i >> kChunkLog2;
+                bool pending = true;
+                my_chunk = -1;
+                for (;;) {
+                    const unsigned long long mask = __ballot(pending);
+                    if (!mask) break;
+                    const int L = __ffsll((long long)mask) - 1;
+                    const int jL = __shfl(j, L);
+                    int32_t c = chunk_lds[jL];
+                    if (c == -1) {
+                        if (lane == L) {
+                            c = atomicAdd(&stg.cursor[0], 1);
+                            if (c >= stg.pool_chunks) { c = -2; stg.cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
+                            else stg.ctab[(int64_t)blockIdx.x * kMaxChunks + jL] = c;
+                            chunk_lds[jL] = c;
+                        }
+                        c = __shfl(c, L);
+                    }
+                    if (pending && j == jL) { my_chunk = c; pending = false; }
+                }
+            }
+            if (my_chunk >= 0) {
+                const int64_t o = ((int64_t)my_chunk * kChunkRows + r) * 64 + lane;
+                stg.px[o] = px; stg.py[o] = py; stg.qx[o] = qx; stg.qy[o] = qy;
+                stg.ell[o] = ell;
+                stg.element[o] = element + 1;
+            }
         }
+        if (MODE != kFill) sum_ell += ell;
+        lqx = qx; lqy = qy;
         xpx = qx + sx; xpy = qy + sy;  // :165
         prev_element = element;        // :166
         ++i;                           // :168
     }
-    if (!FILL) {
+    if (MODE != kFill) {
         // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol)
         if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
         counts[u] = i;
@@ -144,6 +234,71 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
         if (st != RT_TRACK_OK) {
             atomicAdd(&fail_info[0], 1ull);
             atomicMin(&fail_info[1], (unsigned long long)(u + 1));
+        }
+    }
+}
+
+// Staging pool -> compact CSR records.  One wave per wave of tracks: rows are read coalesced
+// (512 B per row and array), transposed through an LDS tile, and written as runs of up to
+// kChunkRows consecutive records per track (4 tracks x 16 rows per store instruction).
+__global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__restrict__ counts,
+                                                const int64_t *__restrict__ offsets, DStage stg, DOut out) {
+    __shared__ double tile[kChunkRows * 65];
+    const int lane = threadIdx.x;
+    const int64_t wv = blockIdx.x;
+    const int64_t slot = wv * 64 + lane;
+    int32_t cnt = 0;
+    int64_t off = 0;
+    if (slot < t.n) {
+        const int32_t u = t.perm[slot];
+        cnt = counts[u];
+        off = offsets[u];
+    }
+    int32_t maxcnt = cnt;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t v = __shfl_xor(maxcnt, o, 64);
+        maxcnt = v > maxcnt ? v : maxcnt;
+    }
+    const int tsub = lane >> 4, r16 = lane & 15;
+    int32_t *itile = reinterpret_cast<int32_t *>(tile);
+    const double *src[5] = {stg.px, stg.py, stg.qx, stg.qy, stg.ell};
+    double *dst[5] = {out.px, out.py, out.qx, out.qy, out.ell};
+    for (int j = 0; j * kChunkRows < maxcnt; ++j) {
+        const int32_t c = stg.ctab[wv * kMaxChunks + j];
+        const int64_t s0 = ((int64_t)c * kChunkRows) * 64 + lane;
+        const int row = j * kChunkRows + r16;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            double v[kChunkRows];
+#pragma unroll
+            for (int r = 0; r < kChunkRows; ++r) v[r] = src[a][s0 + r * 64];
+#pragma unroll
+            for (int r = 0; r < kChunkRows; ++r) tile[r * 65 + lane] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int tt = g * 4 + tsub;
+                const int32_t ct = __shfl(cnt, tt, 64);
+                const int64_t ot = __shfl(off, tt, 64);
+                if (row < ct) dst[a][ot + row] = tile[r16 * 65 + tt];
+            }
+            __syncthreads();
+        }
+        {
+            int32_t v[kChunkRows];
+#pragma unroll
+            for (int r = 0; r < kChunkRows; ++r) v[r] = stg.element[s0 + r * 64];
+#pragma unroll
+            for (int r = 0; r < kChunkRows; ++r) itile[r * 65 + lane] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int tt = g * 4 + tsub;
+                const int32_t ct = __shfl(cnt, tt, 64);
+                const int64_t ot = __shfl(off, tt, 64);
+                if (row < ct) out.element[ot + row] = itile[r16 * 65 + tt];
+            }
+            __syncthreads();
         }
     }
 }
@@ -229,6 +384,51 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *total;
 }
 
+// fill_volumes (src/trackgenerator.jl:371-386) as its own pass over the compact records: each
+// workgroup owns a contiguous range of tracks (hence a contiguous range of segments, read
+// coalesced), accumulates δs[azim]·ℓ into an LDS-private copy of `volumes` with LDS atomics and
+// flushes it with coalesced global atomics.  Random global f64 atomics from the march itself
+// (64 lanes → 64 different lines) run ~17x below the coalesced rate and cost more than the march.
+__global__ __launch_bounds__(1024) void k_volumes(const int64_t *__restrict__ offsets, int64_t n_tracks,
+                                                  const int32_t *__restrict__ azim,
+                                                  const double *__restrict__ delta_s,
+                                                  const int32_t *__restrict__ element,
+                                                  const double *__restrict__ ell, double *__restrict__ volumes,
+                                                  int32_t n_cells, int32_t tpb, int32_t use_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *hist = reinterpret_cast<double *>(smem);
+    int32_t *rel = reinterpret_cast<int32_t *>(smem + (use_lds ? (size_t)n_cells * sizeof(double) : 0));
+    const int64_t u0 = (int64_t)blockIdx.x * tpb;
+    const int64_t u1 = u0 + tpb < n_tracks ? u0 + tpb : n_tracks;
+    if (u0 >= u1) return;
+    const int nt = (int)(u1 - u0);
+    const int64_t s0 = offsets[u0], s1 = offsets[u1];
+    if (use_lds)
+        for (int c = threadIdx.x; c < n_cells; c += blockDim.x) hist[c] = 0.0;
+    for (int j = threadIdx.x; j <= nt; j += blockDim.x) rel[j] = (int32_t)(offsets[u0 + j] - s0);
+    __syncthreads();
+    for (int64_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) {
+        const int32_t r = (int32_t)(s - s0);
+        int lo = 0, hi = nt;  // largest j with rel[j] <= r
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rel[mid] <= r) lo = mid; else hi = mid;
+        }
+        const double w = delta_s[azim[u0 + lo] - 1];
+        const double v = w * ell[s];
+        const int32_t e = element[s] - 1;
+        if (use_lds) atomicAdd(&hist[e], v);
+        else unsafeAtomicAdd(&volumes[e], v);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < n_cells; c += blockDim.x) {
+            const double v = hist[c];
+            if (v != 0.0) unsafeAtomicAdd(&volumes[c], v);
+        }
+    }
+}
+
 __global__ void k_scale_volumes(double *__restrict__ vol, int32_t n_cells, double n_azim_2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_cells) vol[i] = vol[i] / n_azim_2;  // volumes ./= n_azim_2, src/trackgenerator.jl:386
@@ -244,8 +444,14 @@ struct rt_mesh {
     int32_t n_nodes = 0, n_cells = 0;
     DevBuf<double> x, y;
     DevBuf<int32_t> cn, ncp, ncd, gstart, gnode;
+    DevBuf<rt::CellRec> rec;
     rt::DMesh d{};
     int64_t iter_cap = 4000000;
+    bool walk_available = false;
+    int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
+    int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
+    double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
+    std::string prep_note;
 };
 
 struct rt_tracks {
@@ -261,6 +467,11 @@ struct rt_tracks {
     DevBuf<int64_t> offsets, tile_sums, scalars;  // scalars[0] = total
     DevBuf<unsigned long long> fail_info;         // [0] n_failed, [1] first failing uid
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
+    // staging pool of the single-pass march
+    DevBuf<double> gpx, gpy, gqx, gqy, gell;
+    DevBuf<int32_t> gelement, ctab, cursor;
+    int64_t pool_chunks = 0, chunks_needed_last = 0;
+    double sum_ell = 0.0;
     hipEvent_t ev[8] = {};
     double ms[8] = {};
     int64_t n_failed = 0, first_failed_uid = 0;
@@ -299,27 +510,13 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
         if (v < 0 || v >= n_cells) { set_error("node_cells_data[%d] = %d out of range", i, ncd_in[i]); return RT_ERR_INVALID; }
         ncd[i] = v;
     }
-    // --- uniform node grid for exact nearest-node queries (replaces the kd-tree)
+    // --- node grid, per-cell walk records and certificate margins (rt_mesh_prep.hpp)
     const double W = bb[2] - bb[0], H = bb[3] - bb[1];
     if (!(W > 0) || !(H > 0)) { set_error("empty bounding box"); return RT_ERR_INVALID; }
-    double gh = std::sqrt(W * H / std::max(1, n_nodes));
-    int gnx = std::min(2048, std::max(1, (int)std::ceil(W / gh)));
-    int gny = std::min(2048, std::max(1, (int)std::ceil(H / gh)));
-    gh = std::max(W / gnx, H / gny);
-    const double ginv = 1.0 / gh;
-    std::vector<int32_t> gstart((size_t)gnx * gny + 1, 0), gnode(std::max(1, n_nodes)), bucket(n_nodes);
-    for (int32_t i = 0; i < n_nodes; ++i) {
-        double fx = std::floor((x[i] - bb[0]) * ginv), fy = std::floor((y[i] - bb[1]) * ginv);
-        int ix = fx < 0 ? 0 : (fx > gnx - 1 ? gnx - 1 : (int)fx);
-        int iy = fy < 0 ? 0 : (fy > gny - 1 ? gny - 1 : (int)fy);
-        bucket[i] = iy * gnx + ix;
-        gstart[bucket[i] + 1]++;
-    }
-    for (size_t b = 0; b < (size_t)gnx * gny; ++b) gstart[b + 1] += gstart[b];
-    {
-        std::vector<int32_t> cur(gstart.begin(), gstart.end() - 1);
-        for (int32_t i = 0; i < n_nodes; ++i) gnode[cur[bucket[i]]++] = i;
-    }
+    rtprep::Prep P = rtprep::prepare(x, y, n_nodes, cn.data(), n_cells, bb);
+    const std::vector<int32_t> &gstart = P.gstart, &gnode = P.gnode;
+    const double gh = P.gh, ginv = P.ginv;
+    const int gnx = P.gnx, gny = P.gny;
     hipStream_t s = m->stream;
     int rc;
     if ((rc = upload(m->x, x, n_nodes, s))) return rc;
@@ -329,6 +526,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     if ((rc = upload(m->ncd, ncd.data(), (size_t)nnz, s))) return rc;
     if ((rc = upload(m->gstart, gstart.data(), gstart.size(), s))) return rc;
     if ((rc = upload(m->gnode, gnode.data(), (size_t)n_nodes, s))) return rc;
+    if ((rc = upload(m->rec, reinterpret_cast<const rt::CellRec *>(P.rec.data()), P.rec.size(), s))) return rc;
     RT_HIP(hipStreamSynchronize(s));  // host vectors die at return
     m->n_nodes = n_nodes;
     m->n_cells = n_cells;
@@ -338,12 +536,17 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     d.gx0 = bb[0]; d.gy0 = bb[1]; d.gh = gh; d.ginv = ginv; d.gnx = gnx; d.gny = gny;
     d.bx0 = bb[0]; d.by0 = bb[1]; d.bx1 = bb[2]; d.by1 = bb[3];
     d.n_nodes = n_nodes; d.n_cells = n_cells;
+    d.rec = m->rec.p; d.eps_iso = P.eps_iso; d.d_vertex = P.d_vertex; d.l_min = P.l_min;
+    d.walk_ok = P.walk_ok ? 1 : 0;
+    m->walk_available = P.walk_ok;
+    m->kappa = P.kappa;
+    m->prep_note = P.note;
     return RT_SUCCESS;
 }
 
 void free_mesh(rt_mesh *m) {
     m->x.release(); m->y.release(); m->cn.release(); m->ncp.release(); m->ncd.release();
-    m->gstart.release(); m->gnode.release();
+    m->gstart.release(); m->gnode.release(); m->rec.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -355,6 +558,8 @@ void free_tracks(rt_tracks *t) {
     t->tile_sums.release(); t->scalars.release(); t->fail_info.release();
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->delta_s.release();
+    t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release(); t->gell.release();
+    t->gelement.release(); t->ctab.release(); t->cursor.release();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     delete t;
@@ -437,6 +642,12 @@ void *rt_mesh_get_stream(rt_mesh *mesh) { return mesh ? (void *)mesh->stream : n
 int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!mesh || !name) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!strcmp(name, "iter_cap")) { mesh->iter_cap = value > 0 ? value : 4000000; return RT_SUCCESS; }
+    if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
+        mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
+        return RT_SUCCESS;
+    }
     set_error("unknown option '%s'", name);
     return RT_ERR_INVALID;
 }
@@ -460,6 +671,7 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     std::vector<int32_t> perm(n);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
+    for (size_t i = 0; i < n; ++i) t->sum_ell += ell[i];
     bool ok = upload(t->px, px, n, s) == 0 && upload(t->py, py, n, s) == 0 && upload(t->phi, phi, n, s) == 0 &&
               upload(t->cs, cos_phi, n, s) == 0 && upload(t->sn, sin_phi, n, s) == 0 && upload(t->A, A, n, s) == 0 &&
               upload(t->B, B, n, s) == 0 && upload(t->C, C, n, s) == 0 && upload(t->ell, ell, n, s) == 0 &&
@@ -499,77 +711,151 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
 
     const int64_t n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
+    const int64_t n_waves = (n + 63) / 64;
     RT_HIP(t->counts.reserve(n + 1));
     RT_HIP(t->status.reserve(n + 1));
     RT_HIP(t->offsets.reserve(n + 1));
     RT_HIP(t->tile_sums.reserve(n_tiles + 1));
     RT_HIP(t->scalars.reserve(4));
-    RT_HIP(t->fail_info.reserve(2));
+    RT_HIP(t->fail_info.reserve(8));
+    RT_HIP(t->cursor.reserve(4));
     RT_HIP(t->volumes.reserve(m->n_cells));
     if (int rc = upload(t->delta_s, delta_s, (size_t)n_azim_2, s)) return rc;
-
-    const unsigned long long fi0[2] = {0ull, ~0ull};
-    RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
-    RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
 
     rt::DOut out{};
     out.volumes = t->volumes.p;
     out.delta_s = t->delta_s.p;
+    out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
+    rt::DStage stg{};
+    const unsigned grid = (unsigned)n_waves;
+    int64_t total = 0;
+    unsigned long long fi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float f = 0;
+
+    auto scan_counts = [&]() -> int {
+        if (n > 0) {
+            hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
+                               t->tile_sums.p);
+            hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, t->scalars.p);
+            hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
+                               t->tile_sums.p, t->scalars.p, t->offsets.p);
+        } else {
+            RT_HIP(hipMemsetAsync(t->scalars.p, 0, sizeof(int64_t), s));
+            RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
+        }
+        return RT_SUCCESS;
+    };
+    auto reserve_out = [&](int64_t tot) -> int {
+        const size_t cap = (size_t)(tot > 0 ? tot : 1);
+        RT_HIP(t->spx.reserve(cap)); RT_HIP(t->spy.reserve(cap)); RT_HIP(t->sqx.reserve(cap));
+        RT_HIP(t->sqy.reserve(cap)); RT_HIP(t->sell.reserve(cap)); RT_HIP(t->element.reserve(cap));
+        out.px = t->spx.p; out.py = t->spy.p; out.qx = t->sqx.p; out.qy = t->sqy.p; out.ell = t->sell.p;
+        out.element = t->element.p;
+        return RT_SUCCESS;
+    };
+    const unsigned long long fi0[8] = {0ull, ~0ull, 0, 0, 0, 0, 0, 0};
 
     RT_HIP(hipEventRecord(t->ev[0], s));
-    const unsigned grid = (unsigned)((n + 63) / 64);
-    if (n > 0) {
-        hipLaunchKernelGGL(rt::k_march<false>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p, t->status.p,
-                           (const int64_t *)nullptr, out, t->fail_info.p);
-    }
-    RT_HIP(hipEventRecord(t->ev[1], s));
-    // CSR offsets
-    if (n > 0) {
-        hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
-                           t->tile_sums.p);
-        hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, t->scalars.p);
-        hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
-                           t->tile_sums.p, t->scalars.p, t->offsets.p);
+    RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+    if (m->single_pass) {
+        // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
+        //      (or from what the previous call needed) and grown + re-run on overflow
+        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, n_waves) * rt::kMaxChunks));
+        int64_t want = t->chunks_needed_last > 0
+                           ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
+                           : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * n_waves + 64;
+        for (int attempt = 0;; ++attempt) {
+            if (want > t->pool_chunks) {
+                const size_t slots = (size_t)want * rt::kChunkRows * 64;
+                RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots));
+                RT_HIP(t->gqy.reserve(slots)); RT_HIP(t->gell.reserve(slots)); RT_HIP(t->gelement.reserve(slots));
+                t->pool_chunks = want;
+            }
+            stg.px = t->gpx.p; stg.py = t->gpy.p; stg.qx = t->gqx.p; stg.qy = t->gqy.p; stg.ell = t->gell.p;
+            stg.element = t->gelement.p; stg.ctab = t->ctab.p; stg.cursor = t->cursor.p;
+            stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
+            RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
+            RT_HIP(hipMemsetAsync(t->cursor.p, 0, 4 * sizeof(int32_t), s));
+            RT_HIP(hipEventRecord(t->ev[1], s));
+            if (n > 0)
+                hipLaunchKernelGGL(rt::k_march<rt::kStage>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
+                                   t->status.p, (const int64_t *)nullptr, out, stg, t->fail_info.p);
+            RT_HIP(hipEventRecord(t->ev[2], s));
+            if (int rc = scan_counts()) return rc;
+            RT_HIP(hipEventRecord(t->ev[3], s));
+            int32_t cur[4] = {0, 0, 0, 0};
+            RT_HIP(hipMemcpyAsync(&total, t->scalars.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            RT_HIP(hipMemcpyAsync(fi, t->fail_info.p, sizeof(fi), hipMemcpyDeviceToHost, s));
+            RT_HIP(hipMemcpyAsync(cur, t->cursor.p, sizeof(cur), hipMemcpyDeviceToHost, s));
+            RT_HIP(hipStreamSynchronize(s));
+            t->chunks_needed_last = cur[0];
+            if (!cur[1]) break;
+            if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
+            want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
+        }
+        if (int rc = reserve_out(total)) return rc;
+        RT_HIP(hipEventRecord(t->ev[4], s));
+        if (n > 0 && total > 0)
+            hipLaunchKernelGGL(rt::k_compact, dim3(grid), dim3(64), 0, s, t->d, (const int32_t *)t->counts.p,
+                               (const int64_t *)t->offsets.p, stg, out);
+        RT_HIP(hipEventRecord(t->ev[5], s));
     } else {
-        RT_HIP(hipMemsetAsync(t->scalars.p, 0, sizeof(int64_t), s));
-        RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
+        RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
+        RT_HIP(hipEventRecord(t->ev[1], s));
+        if (n > 0)
+            hipLaunchKernelGGL(rt::k_march<rt::kCount>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
+                               t->status.p, (const int64_t *)nullptr, out, stg, t->fail_info.p);
+        RT_HIP(hipEventRecord(t->ev[2], s));
+        if (int rc = scan_counts()) return rc;
+        RT_HIP(hipEventRecord(t->ev[3], s));
+        RT_HIP(hipMemcpyAsync(&total, t->scalars.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        RT_HIP(hipMemcpyAsync(fi, t->fail_info.p, sizeof(fi), hipMemcpyDeviceToHost, s));
+        RT_HIP(hipStreamSynchronize(s));
+        if (int rc = reserve_out(total)) return rc;
+        RT_HIP(hipEventRecord(t->ev[4], s));
+        if (n > 0)
+            hipLaunchKernelGGL(rt::k_march<rt::kFill>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
+                               t->status.p, (const int64_t *)t->offsets.p, out, stg, t->fail_info.p);
+        RT_HIP(hipEventRecord(t->ev[5], s));
     }
-    RT_HIP(hipEventRecord(t->ev[2], s));
-    int64_t total = 0;
-    unsigned long long fi[2] = {0, 0};
-    RT_HIP(hipMemcpyAsync(&total, t->scalars.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    RT_HIP(hipMemcpyAsync(fi, t->fail_info.p, sizeof(fi), hipMemcpyDeviceToHost, s));
-    RT_HIP(hipStreamSynchronize(s));
-    const size_t cap = (size_t)(total > 0 ? total : 1);
-    RT_HIP(t->spx.reserve(cap)); RT_HIP(t->spy.reserve(cap)); RT_HIP(t->sqx.reserve(cap));
-    RT_HIP(t->sqy.reserve(cap)); RT_HIP(t->sell.reserve(cap)); RT_HIP(t->element.reserve(cap));
-    out.px = t->spx.p; out.py = t->spy.p; out.qx = t->sqx.p; out.qy = t->sqy.p; out.ell = t->sell.p;
-    out.element = t->element.p;
-    RT_HIP(hipEventRecord(t->ev[3], s));
-    if (n > 0) {
-        hipLaunchKernelGGL(rt::k_march<true>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p, t->status.p,
-                           (const int64_t *)t->offsets.p, out, t->fail_info.p);
+    // ---- fill_volumes
+    if (m->volumes_mode == 2 && n > 0 && total > 0) {
+        const int64_t want_blocks = 512;
+        int32_t tpb = (int32_t)std::max<int64_t>(1, (n + want_blocks - 1) / want_blocks);
+        tpb = std::min(tpb, 4096);
+        const int64_t nb = (n + tpb - 1) / tpb;
+        const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
+        const size_t rel_bytes = ((size_t)tpb + 1) * sizeof(int32_t);
+        const int use_lds = hist_bytes + rel_bytes <= 150 * 1024 ? 1 : 0;
+        const size_t shmem = (use_lds ? hist_bytes : 0) + rel_bytes;
+        if (shmem > 48 * 1024)
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_volumes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(rt::k_volumes, dim3((unsigned)nb), dim3(1024), shmem, s, (const int64_t *)t->offsets.p, n,
+                           (const int32_t *)t->azim.p, (const double *)t->delta_s.p, (const int32_t *)t->element.p,
+                           (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds);
     }
-    RT_HIP(hipEventRecord(t->ev[4], s));
     hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
                        m->n_cells, (double)n_azim_2);
-    RT_HIP(hipEventRecord(t->ev[5], s));
+    RT_HIP(hipEventRecord(t->ev[6], s));
     RT_HIP(hipStreamSynchronize(s));
     RT_HIP(hipGetLastError());
-    float f = 0;
-    RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[5])); t->ms[0] = f;
-    RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[1])); t->ms[2] = f;   // count march
-    RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[3] = f;   // scan
-    RT_HIP(hipEventElapsedTime(&f, t->ev[3], t->ev[4])); t->ms[4] = f;   // fill march
-    RT_HIP(hipEventElapsedTime(&f, t->ev[4], t->ev[5])); t->ms[5] = f;   // volumes
+    RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[6])); t->ms[0] = f;   // whole call, device side
+    RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
+    RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan
+    RT_HIP(hipEventElapsedTime(&f, t->ev[4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
+    RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f;   // volumes
+#ifdef RT_STATS
+    fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
+            fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
+#endif
     t->total = total;
     t->n_failed = (int64_t)fi[0];
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
     t->first_failed_status = 0;
     if (fi[0]) {
-        int32_t st = 0;
-        RT_HIP(hipMemcpy(&st, t->status.p + (fi[1] - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
-        t->first_failed_status = st;
+        int32_t stt = 0;
+        RT_HIP(hipMemcpy(&stt, t->status.p + (fi[1] - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
+        t->first_failed_status = stt;
     }
     t->segmentized = true;
     return total;

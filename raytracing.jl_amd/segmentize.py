@@ -42,15 +42,20 @@ class SegmentStore:
 
 
 def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, device: int = 0,
-               fetch: bool = True) -> TrackGenerator:
+               fetch: bool = True, walk: bool = True, check: bool = True) -> TrackGenerator:
     """``segmentize!(t; k=5, rtol=√eps)``.  ``fetch=False`` leaves the results on the device
-    (``t.device_tracks.device_pointers()``) for consumers that stay on the GPU."""
+    (``t.device_tracks.device_pointers()``) for consumers that stay on the GPU.  ``walk=False``
+    disables the certified walk step of the device march (every iteration then runs the
+    literal locate + intersect step); results are identical either way.  ``check=False`` does
+    not raise for failed tracks (the reference would have thrown at the first one) and leaves
+    the per-track ``RT_TRACK_*`` codes in ``t.track_status`` instead."""
     if not t.traced:
         raise RuntimeError(NOT_TRACED_MSG)
     dm = getattr(t, "device_mesh", None)
     if dm is None or dm._h is None or dm.device != device:
         dm = _capi.DeviceMesh(t.mesh, device)
         t.device_mesh = dm
+    dm.set_option("walk", 1 if walk else 0)
     old = getattr(t, "device_tracks", None)
     if old is not None:
         old.close()
@@ -59,10 +64,10 @@ def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, dev
     aq = t.azimuthal_quadrature
     dt.segmentize(t.tiny_step, int(k), float(rtol), aq.delta_s, aq.n_azim_2)
     n_failed, uid, st = dt.failed()
-    if n_failed:
+    if n_failed and check:
         raise RuntimeError(_capi.status_message(st, uid))
     if fetch:
-        off, _status = dt.fetch_offsets()
+        off, t.track_status = dt.fetch_offsets()
         s = dt.fetch_segments()
         t.segments = SegmentStore(off, s["px"], s["py"], s["qx"], s["qy"], s["ell"], s["element"])
         t.volumes = dt.fetch_volumes()

@@ -6,10 +6,15 @@ import raytracing_jl_amd as rt
 from raytracing_jl_amd import _capi
 from oracle import oracle as orc
 
-model = rt.DiscreteModelFromFile(rt.data_path("pincell.json"))
-for na, d in [(8, 2e-2), (32, 5e-3), (128, 1e-3)]:
+pin = rt.DiscreteModelFromFile(rt.data_path("pincell.json"))
+bwr = rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
+for model, na, d in [(pin, 8, 2e-2), (pin, 32, 5e-3), (pin, 128, 1e-3), (bwr, 16, 0.02), (bwr, 64, 2e-3)]:
     tg = rt.TrackGenerator(model, na, d); rt.trace(tg)
-    t0 = time.time(); rt.segmentize(tg); t1 = time.time()
+    rt.segmentize(tg, walk=False, check=False)
+    for _ in range(2):
+        tg.device_tracks.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, tg.azimuthal_quadrature.delta_s, tg.azimuthal_quadrature.n_azim_2)
+    print("generic-only:", tg.device_tracks.timing())
+    t0 = time.time(); rt.segmentize(tg, check=False); t1 = time.time()
     tm = tg.device_tracks.timing()
     for _ in range(3):
         tg.device_tracks.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, tg.azimuthal_quadrature.delta_s, tg.azimuthal_quadrature.n_azim_2)
