@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "librt_segmentize.so")
+LIB_PATH = os.environ.get("RT_SEGMENTIZE_LIB") or os.path.join(_CSRC, "librt_segmentize.so")
 
 # every symbol include/rt_segmentize.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (

@@ -9,48 +9,61 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Device pointers carry the global address space explicitly: pointers that reach the march
+// through by-reference structs would otherwise be loaded with flat_* instructions (which wait
+// on both vmcnt and lgkmcnt) instead of global_load_*.
+#define RT_G __attribute__((address_space(1)))
+
 namespace rt {
+
+template <typename T>
+__host__ __device__ inline RT_G T *as_global(T *p) { return (RT_G T *)p; }
 
 constexpr double kRtolDefault = 1.4901161193847656e-8;  // sqrt(eps(Float64)) = Base.rtoldefault
 constexpr double kHalfPi = 1.5707963267948966;          // Float64(pi)/2, src/intersection.jl:153
 constexpr int kMaxIter = 10000;                         // const MAX_ITER, src/track.jl:104
 constexpr int kMaxK = 8;                                // cap on the knn fallback width `k`
 
-// Per-cell record of the walk step (built on the host, rt_mesh_prep.hpp).  144 B, 16-B aligned:
-// one lane fetches its next cell with nine independent 16-B loads (one L2 round trip).
-struct __attribute__((aligned(16))) CellRec {
-    int32_t adj[3];  // neighbour across edge k = (v_k, v_{k+1 mod 3}); -1 on the domain boundary
-    int32_t meta;    // bits 0..7: bound on non-vertex nodes nearer than the nearest vertex; 255 = no walk
-    double vx[3], vy[3];           // vertex coordinates in the reference's per-cell node order
-    double eA[3], eB[3], eC[3];    // general_form of edge k (src/intersection.jl:11-18), precomputed bit-exactly
-    double pad;
+// Walk record for (cell, entry edge): the cell's vertices rotated cyclically so that rotated
+// edge 0 = (v0, v1) is the entry edge, in the cell's own edge orientation (built on the host,
+// rt_mesh_prep.hpp).  128 B, 128-B aligned: one lane fetches its next cell with eight
+// independent 16-B loads of one cache line (one L2 round trip).
+struct __attribute__((aligned(128))) WalkRec {
+    int32_t next1, next2;  // record index (3*cell' + entry') across rotated edge 1 / 2; -1 on the boundary
+    int32_t cell;          // 0-based cell id
+    int32_t meta;          // bits 0..7: bound on non-vertex nodes nearer than the nearest vertex (255: no walk)
+    double dT;             // det of the barycentric system in the ORIGINAL node order, reference operation order
+    double pad0;
+    double x0, y0, x1, y1, x2, y2;         // rotated vertices; v2 is opposite the entry edge
+    double e1A, e1B, e1C, e2A, e2B, e2C;   // general_form (src/intersection.jl:11-18) of rotated edges 1, 2
 };
-static_assert(sizeof(CellRec) == 144, "CellRec layout");
+static_assert(sizeof(WalkRec) == 128, "WalkRec layout");
 
 // Flattened mesh in HBM (SoA; all ids 0-based on the device, converted at upload).
 struct DMesh {
-    const CellRec *__restrict__ rec;     // [n_cells] walk records
+    const RT_G WalkRec *wrec;    // [3*n_cells] rotated walk records
+    const RT_G int32_t *adjr;    // [3*n_cells] record index reached across edge k of cell c; -1 on the boundary
     double eps_iso, d_vertex, l_min;     // certificate margins of the walk step
     int32_t walk_ok;
-    const double *__restrict__ x;        // [n_nodes]
-    const double *__restrict__ y;        // [n_nodes]
-    const int32_t *__restrict__ cn;      // [3*n_cells] cell -> nodes, reference order
-    const int32_t *__restrict__ ncp;     // [n_nodes+1] node -> cells CSR offsets
-    const int32_t *__restrict__ ncd;     // node -> cells, ascending cell id per node
-    const int32_t *__restrict__ gstart;  // [gnx*gny+1] uniform node grid CSR (row-major, y-major rows)
-    const int32_t *__restrict__ gnode;   // node ids grouped by bucket
-    double gx0, gy0, gh, ginv;           // grid origin, bucket size and its inverse
+    const RT_G double *x;        // [n_nodes]
+    const RT_G double *y;        // [n_nodes]
+    const RT_G int32_t *cn;      // [3*n_cells] cell -> nodes, reference order
+    const RT_G int32_t *ncp;     // [n_nodes+1] node -> cells CSR offsets
+    const RT_G int32_t *ncd;     // node -> cells, ascending cell id per node
+    const RT_G int32_t *gstart;  // [gnx*gny+1] uniform node grid CSR (row-major, y-major rows)
+    const RT_G int32_t *gnode;   // node ids grouped by bucket
+    double gx0, gy0, gh, ginv;   // grid origin, bucket size and its inverse
     int32_t gnx, gny;
-    double bx0, by0, bx1, by1;           // bounding box (bb_min, bb_max)
+    double bx0, by0, bx1, by1;   // bounding box (bb_min, bb_max)
     int32_t n_nodes, n_cells;
 };
 
 // Per-track inputs in HBM (SoA, uid order) + the march order.
 struct DTracks {
-    const double *__restrict__ px, *__restrict__ py, *__restrict__ phi, *__restrict__ cs, *__restrict__ sn;
-    const double *__restrict__ A, *__restrict__ B, *__restrict__ C, *__restrict__ ell;
-    const int32_t *__restrict__ azim;    // 1-based azimuthal index
-    const int32_t *__restrict__ perm;    // march slot -> track (longest tracks first)
+    const RT_G double *px, *py, *phi, *cs, *sn;
+    const RT_G double *A, *B, *C, *ell;
+    const RT_G int32_t *azim;    // 1-based azimuthal index
+    const RT_G int32_t *perm;    // march slot -> track (longest tracks first)
     int64_t n;
 };
 
@@ -369,104 +382,112 @@ __device__ __forceinline__ bool intersections(const DMesh &m, int32_t cell, doub
 // inside the window find_element(xp) / find_element(xp, k) covers.
 struct Walk {
     int32_t T;       // cell of the last emitted segment (prev_element), -1 at the start
-    int32_t pred;    // predicted next cell adj[T][ko], -1: no prediction
+    int32_t pred;    // walk record index of the predicted next cell (3*cell' + entry edge), -1: none
     double ax, ay, bx, by;  // endpoints of T's exit edge, in T's edge orientation
     double cx, cy;          // T's vertex opposite the exit edge
     double dT;              // det of T's barycentric system in T's node order (exact reference ops)
 };
 
-// λ of T for the vertex opposite its exit edge, evaluated at (x, y) exactly as
-// point_in_triangle does (src/mesh.jl:166-168 via the 3x3 closed form).
-__device__ __forceinline__ double lambda_opposite(const Walk &w, double x, double y) {
-    return ((w.ay - w.by) * x + (w.bx - w.ax) * y + (w.ax * w.by - w.bx * w.ay)) / w.dT;
-}
-
-// Load the state the next walk step needs after a segment was emitted in `cell` with its exit
-// point on edge `ko` (0..2).  R must be rec[cell].
-__device__ __forceinline__ void walk_enter(Walk &w, const CellRec &R, int32_t cell, int ko) {
-    const double x1 = R.vx[0], y1 = R.vy[0], x2 = R.vx[1], y2 = R.vy[1], x3 = R.vx[2], y3 = R.vy[2];
+// State for the next walk step after a segment was emitted by the generic step in `cell` with
+// its exit point on edge `ko` (0..2).
+__device__ __forceinline__ void walk_enter(const DMesh &m, Walk &w, int32_t cell, int ko) {
+    const RT_G WalkRec *R = m.wrec + 3 * cell;  // entry edge 0 => vertices in the original node order
+    const double x1 = R->x0, y1 = R->y0, x2 = R->x1, y2 = R->y1, x3 = R->x2, y3 = R->y2;
     w.T = cell;
-    w.dT = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
+    w.dT = R->dT;
     w.ax = ko == 0 ? x1 : (ko == 1 ? x2 : x3);
     w.ay = ko == 0 ? y1 : (ko == 1 ? y2 : y3);
     w.bx = ko == 0 ? x2 : (ko == 1 ? x3 : x1);
     w.by = ko == 0 ? y2 : (ko == 1 ? y3 : y1);
     w.cx = ko == 0 ? x3 : (ko == 1 ? x1 : x2);
     w.cy = ko == 0 ? y3 : (ko == 1 ? y1 : y2);
-    w.pred = ko == 0 ? R.adj[0] : (ko == 1 ? R.adj[1] : R.adj[2]);
+    w.pred = m.adjr[3 * cell + ko];
 }
 
 enum WalkResult { kWalkGeneric = 0, kWalkSkip = 1, kWalkEmit = 2 };
 
-// One walk step at xp for the lane's predicted cell.  On kWalkEmit: (qx,qy) is the exit point,
+// Register copy of the walk record the lane needs next.
+struct NextRec {
+    int32_t n1, n2, cell, meta;
+    double dT, x0, y0, x1, y1, x2, y2, e1A, e1B, e1C, e2A, e2B, e2C;
+};
+__device__ __forceinline__ void load_next(const DMesh &m, int32_t pred, NextRec &r) {
+    const RT_G WalkRec *R = m.wrec + (pred >= 0 ? pred : 0);
+    r.n1 = R->next1; r.n2 = R->next2; r.cell = R->cell; r.meta = R->meta;
+    r.dT = R->dT;
+    r.x0 = R->x0; r.y0 = R->y0; r.x1 = R->x1; r.y1 = R->y1; r.x2 = R->x2; r.y2 = R->y2;
+    r.e1A = R->e1A; r.e1B = R->e1B; r.e1C = R->e1C; r.e2A = R->e2A; r.e2B = R->e2B; r.e2C = R->e2C;
+}
+
+// One walk step at xp for the lane's predicted record.  On kWalkEmit: (qx,qy) is the exit point,
 // `ell` the segment length (entry point = previous exit point, bit-identical by symmetry of the
 // edge's general form), and `w` is advanced to the new cell.  On kWalkSkip the reference takes
 // its `prev_element == element` branch (src/track.jl:147-150).  kWalkGeneric: no decision.
-__device__ __forceinline__ WalkResult walk_step(const DMesh &m, Walk &w, int kk, double tA, double tB, double tC,
-                                                double xpx, double xpy, double ppx, double ppy, double &qx,
-                                                double &qy, double &ell) {
-    const int32_t Tn = w.pred;
-    const CellRec &R = m.rec[Tn];
-    const int32_t a0 = R.adj[0], a1 = R.adj[1], a2 = R.adj[2], meta = R.meta;
-    const double x0 = R.vx[0], x1 = R.vx[1], x2 = R.vx[2];
-    const double y0 = R.vy[0], y1 = R.vy[1], y2 = R.vy[2];
-    const int ki = a0 == w.T ? 0 : (a1 == w.T ? 1 : (a2 == w.T ? 2 : -1));
-    if (ki < 0 || (meta & 255) > kk) return kWalkGeneric;
-    // --- certificate 1: the track line clears every vertex of T' by d_vertex
+// Written straight-line (all certificates are folded into one predicate; a lane without a
+// prediction reads record 0 and is masked out) except for the rare exact shallow-crossing test:
+// on a 64-wide wave, selects are cheaper than divergent early exits.
+__device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, double tA, double tB,
+                                         double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
+                                         double &qy, double &ell) {
+    const bool has = m.walk_ok && w.pred >= 0;
+    const int32_t n1 = nr.n1, n2 = nr.n2, Tn = nr.cell, meta = nr.meta;
+    const double dTn = nr.dT;
+    const double x0 = nr.x0, y0 = nr.y0, x1 = nr.x1, y1 = nr.y1, x2 = nr.x2, y2 = nr.y2;
+    const double e1A = nr.e1A, e1B = nr.e1B, e1C = nr.e1C, e2A = nr.e2A, e2B = nr.e2B, e2C = nr.e2C;
+    bool ok = has && (meta & 255) <= kk;
+    // --- certificate 1: the track line clears every vertex of T' by d_vertex and crosses the entry edge
     const double s0 = tA * x0 + tB * y0 + tC, s1 = tA * x1 + tB * y1 + tC, s2 = tA * x2 + tB * y2 + tC;
-    if (!(fabs(s0) >= m.d_vertex && fabs(s1) >= m.d_vertex && fabs(s2) >= m.d_vertex)) return kWalkGeneric;
+    ok = ok && fabs(s0) >= m.d_vertex && fabs(s1) >= m.d_vertex && fabs(s2) >= m.d_vertex;
     const bool p0 = s0 > 0, p1 = s1 > 0, p2 = s2 > 0;
-    const bool c0 = p0 != p1, c1 = p1 != p2, c2 = p2 != p0;  // edge k is crossed by the line
-    const bool cki = ki == 0 ? c0 : (ki == 1 ? c1 : c2);
-    if (!cki) return kWalkGeneric;
-    // exactly two edges are crossed; the exit edge is the crossed one that is not the entry edge
-    const int ko = ki == 0 ? (c1 ? 1 : 2) : (ki == 1 ? (c2 ? 2 : 0) : (c0 ? 0 : 1));
-    // --- certificate 2: xp is inside T', at least eps_iso (barycentric) from the two other edges
+    ok = ok && (p0 != p1);
+    const bool exit1 = p1 != p2;  // the line leaves through rotated edge 1 = (v1,v2), else edge 2 = (v2,v0)
+    // --- certificate 2: xp is inside T', at least eps_iso (barycentric) from edges 1 and 2
     const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-    const double w0 = ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0)) / area2;  // weight of v2 (edge 0)
-    const double w1 = ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1)) / area2;  // weight of v0 (edge 1)
-    const double w2 = ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2)) / area2;  // weight of v1 (edge 2)
-    const double wi = ki == 0 ? w0 : (ki == 1 ? w1 : w2);
-    const double wa = ki == 0 ? w1 : (ki == 1 ? w2 : w0);
-    const double wb = ki == 0 ? w2 : (ki == 1 ? w0 : w1);
-    if (!(wi >= -0.25 * kRtolDefault && wa >= m.eps_iso && wb >= m.eps_iso)) return kWalkGeneric;
-    // --- shallow crossing: does T still pass the reference's barycentric test at xp?
-    const double lamT = lambda_opposite(w, xpx, xpy);
-    if (lamT >= 0.0 - kRtolDefault) {
-        // scan order of find_element: nearest of {a, b, c, c'}
-        const double cpx = ki == 0 ? x2 : (ki == 1 ? x0 : x1), cpy = ki == 0 ? y2 : (ki == 1 ? y0 : y1);
-        const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
-        const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
-        const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
-        const double dcp = (xpx - cpx) * (xpx - cpx) + (xpy - cpy) * (xpy - cpy);
-        const double dab = da < db ? da : db;
-        // ties between exactly equidistant nodes are left to the generic step
-        if (dc == dab || dcp == dab || dc == dcp) return kWalkGeneric;
-        const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn);
-        if (t_first) return kWalkSkip;
-    }
-    // --- exit point on edge ko: intersection(track.ABC, ABC) — src/intersection.jl:127-138
-    const double eA = ko == 0 ? R.eA[0] : (ko == 1 ? R.eA[1] : R.eA[2]);
-    const double eB = ko == 0 ? R.eB[0] : (ko == 1 ? R.eB[1] : R.eB[2]);
-    const double eC = ko == 0 ? R.eC[0] : (ko == 1 ? R.eC[1] : R.eC[2]);
+    const double sg = area2 > 0 ? 1.0 : -1.0;
+    const double aa = fabs(area2);
+    const double c0 = sg * ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0));  // ~ distance from the entry edge
+    const double c1 = sg * ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1));
+    const double c2 = sg * ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2));
+    ok = ok && c0 >= -0.25 * kRtolDefault * aa && c1 >= m.eps_iso * aa && c2 >= m.eps_iso * aa;
+    // --- exit point: intersection(track.ABC, ABC) — src/intersection.jl:127-138
+    const double eA = exit1 ? e1A : e2A, eB = exit1 ? e1B : e2B, eC = exit1 ? e1C : e2C;
     const double a = tB * eA;
     const double b = eB * tA;
     const double det = a - b;
     qx = (tC * eB - eC * tB) / det;
     qy = (tA * eC - eA * tC) / det;
     ell = norm2(ppx - qx, ppy - qy);  // Segment ctor, src/segment.jl:31-33
-    if (!(ell >= m.l_min)) return kWalkGeneric;
-    // --- advance the state to T'
-    w.T = Tn;
-    w.dT = x0 * (y1 - y2) + y0 * (x2 - x1) + (x1 * y2 - y1 * x2);
-    w.ax = ko == 0 ? x0 : (ko == 1 ? x1 : x2);
-    w.ay = ko == 0 ? y0 : (ko == 1 ? y1 : y2);
-    w.bx = ko == 0 ? x1 : (ko == 1 ? x2 : x0);
-    w.by = ko == 0 ? y1 : (ko == 1 ? y2 : y0);
-    w.cx = ko == 0 ? x2 : (ko == 1 ? x0 : x1);
-    w.cy = ko == 0 ? y2 : (ko == 1 ? y0 : y1);
-    w.pred = ko == 0 ? a0 : (ko == 1 ? a1 : a2);
-    return kWalkEmit;
+    ok = ok && ell >= m.l_min;
+    // --- shallow crossing: does T still pass the reference's barycentric test at xp?  λ of T for the
+    //     vertex opposite its exit edge, exactly as point_in_triangle evaluates it (src/mesh.jl:166-168);
+    //     the division is skipped when the quotient is clearly below -√eps
+    const double numT = (w.ay - w.by) * xpx + (w.bx - w.ax) * xpy + (w.ax * w.by - w.bx * w.ay);
+    const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
+    int res = ok ? kWalkEmit : kWalkGeneric;
+    if (ok && !clearly_out) {
+        const double lamT = numT / w.dT;
+        if (lamT >= 0.0 - kRtolDefault) {
+            // scan order of find_element: nearest of {a, b, c, c'}; T is met before T' iff that is c,
+            // or it is a or b and T < T' (node -> cells lists ascend in cell id)
+            const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
+            const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
+            const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
+            const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
+            const double dab = da < db ? da : db;
+            const bool tie = dc == dab || dcp == dab || dc == dcp;  // exactly equidistant nodes: generic step
+            const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn);
+            res = tie ? kWalkGeneric : (t_first ? kWalkSkip : kWalkEmit);
+        }
+    }
+    // --- advance the state to T' (only when emitting)
+    const bool em = res == kWalkEmit;
+    w.T = em ? Tn : w.T;
+    w.dT = em ? dTn : w.dT;
+    w.ax = em ? (exit1 ? x1 : x2) : w.ax; w.ay = em ? (exit1 ? y1 : y2) : w.ay;
+    w.bx = em ? (exit1 ? x2 : x0) : w.bx; w.by = em ? (exit1 ? y2 : y0) : w.by;
+    w.cx = em ? (exit1 ? x0 : x1) : w.cx; w.cy = em ? (exit1 ? y0 : y1) : w.cy;
+    w.pred = em ? (exit1 ? n1 : n2) : w.pred;
+    return res;
 }
 
 }  // namespace rt

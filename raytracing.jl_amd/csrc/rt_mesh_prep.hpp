@@ -31,7 +31,23 @@ struct CellRecHost {  // must match rt::CellRec (rt_device.hpp): 144 bytes
 };
 static_assert(sizeof(CellRecHost) == 144, "CellRec layout");
 
+// Rotated walk record for (cell, entry edge e): vertices rotated cyclically so that rotated
+// edge 0 = (v0, v1) is the entry edge, in the cell's own edge orientation.  Must match
+// rt::WalkRec (rt_device.hpp): 128 bytes.
+struct WalkRecHost {
+    int32_t next1, next2;  // record index 3*cell' + entry' across rotated edge 1 / 2, -1 on the boundary
+    int32_t cell;          // 0-based cell id
+    int32_t meta;          // bits 0..7 extras bound (255: no walk), bit 8: a vertex lies near the domain boundary
+    double dT;             // det of the barycentric system in the ORIGINAL node order (reference operation order)
+    double pad0;
+    double x0, y0, x1, y1, x2, y2;
+    double e1A, e1B, e1C, e2A, e2B, e2C;  // general_form of rotated edges 1 = (v1,v2) and 2 = (v2,v0)
+};
+static_assert(sizeof(WalkRecHost) == 128, "WalkRec layout");
+
 struct Prep {
+    std::vector<WalkRecHost> wrec;  // [3*n_cells]
+    std::vector<int32_t> adjr;      // [3*n_cells] record index reached across edge k of cell c, -1 on the boundary
     // node grid
     int gnx = 1, gny = 1;
     double gh = 1.0, ginv = 1.0;
@@ -190,6 +206,47 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                 if (poly.size() >= 1) ++extras;
             }
         R.meta = extras > 254 ? 254 : extras;
+    }
+    // ---- rotated walk records
+    P.wrec.assign((size_t)3 * n_cells, WalkRecHost{});
+    P.adjr.assign((size_t)3 * n_cells, -1);
+    for (int32_t c = 0; c < n_cells; ++c)
+        for (int k = 0; k < 3; ++k) {
+            const int32_t nb = P.rec[c].adj[k];
+            if (nb < 0) continue;
+            int ki = -1;
+            for (int q = 0; q < 3; ++q)
+                if (P.rec[nb].adj[q] == c) {
+                    // the shared edge: same node pair
+                    const int32_t a = cn[3 * c + k], b = cn[3 * c + (k + 1) % 3];
+                    const int32_t a2 = cn[3 * nb + q], b2 = cn[3 * nb + (q + 1) % 3];
+                    if ((a == a2 && b == b2) || (a == b2 && b == a2)) ki = q;
+                }
+            P.adjr[3 * c + k] = ki >= 0 ? 3 * nb + ki : -1;
+        }
+    const double near_b = 1e-6 * std::max(W, H);
+    for (int32_t c = 0; c < n_cells; ++c) {
+        const CellRecHost &R = P.rec[c];
+        const double x1 = R.vx[0], y1 = R.vy[0], x2 = R.vx[1], y2 = R.vy[1], x3 = R.vx[2], y3 = R.vy[2];
+        // det of [x1 x2 x3; y1 y2 y3; 1 1 1] as StaticArrays evaluates it (src/mesh.jl:166-168)
+        const double dT = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
+        bool near = false;
+        for (int k = 0; k < 3; ++k)
+            near = near || R.vx[k] - bb[0] < near_b || bb[2] - R.vx[k] < near_b || R.vy[k] - bb[1] < near_b ||
+                   bb[3] - R.vy[k] < near_b;
+        for (int e = 0; e < 3; ++e) {
+            WalkRecHost &Wr = P.wrec[3 * c + e];
+            const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+            Wr.next1 = P.adjr[3 * c + i1];
+            Wr.next2 = P.adjr[3 * c + i2];
+            Wr.cell = c;
+            Wr.meta = (R.meta & 255) | (near ? 256 : 0);
+            Wr.dT = dT;
+            Wr.pad0 = 0.0;
+            Wr.x0 = R.vx[i0]; Wr.y0 = R.vy[i0]; Wr.x1 = R.vx[i1]; Wr.y1 = R.vy[i1]; Wr.x2 = R.vx[i2]; Wr.y2 = R.vy[i2];
+            Wr.e1A = R.eA[i1]; Wr.e1B = R.eB[i1]; Wr.e1C = R.eC[i1];
+            Wr.e2A = R.eA[i2]; Wr.e2B = R.eB[i2]; Wr.e2C = R.eC[i2];
+        }
     }
     return P;
 }

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -72,10 +73,10 @@ struct DevBuf {
 namespace rt {
 
 struct DOut {
-    double *__restrict__ px, *__restrict__ py, *__restrict__ qx, *__restrict__ qy, *__restrict__ ell;
-    int32_t *__restrict__ element;
-    double *__restrict__ volumes;  // accumulated δs·ℓ per cell (un-normalised)
-    const double *__restrict__ delta_s;
+    RT_G double *px, *py, *qx, *qy, *ell;
+    RT_G int32_t *element;
+    RT_G double *volumes;  // accumulated δs·ℓ per cell (un-normalised)
+    const RT_G double *delta_s;
     int32_t fused_volumes;  // 1: accumulate δs·ℓ with global f64 atomics inside the fill march
 };
 
@@ -89,10 +90,10 @@ constexpr int kChunkLog2 = 4;
 constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
 
 struct DStage {
-    double *__restrict__ px, *__restrict__ py, *__restrict__ qx, *__restrict__ qy, *__restrict__ ell;
-    int32_t *__restrict__ element;
-    int32_t *__restrict__ ctab;     // [n_waves][kMaxChunks] chunk ids
-    int32_t *__restrict__ cursor;   // [0] chunks handed out, [1] overflow flag
+    RT_G double *px, *py, *qx, *qy, *ell;
+    RT_G int32_t *element;
+    RT_G int32_t *ctab;     // [n_waves][kMaxChunks] chunk ids
+    RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
 };
 
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
     }
     int32_t my_chunk = -1;
     int i = 0;
-    int64_t it = 0;
+    int32_t it = 0;
+    const int32_t cap = (int32_t)(prm.iter_cap < 0x7fffffff ? prm.iter_cap : 0x7fffffff);
     int32_t prev_element = -1;
     int st = RT_TRACK_OK;
     double sum_ell = 0.0;
@@ -139,25 +141,54 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
     wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
     const int kk = prm.k > 2 ? prm.k : 2;
     double lqx = 0.0, lqy = 0.0;  // exit point of the last emitted segment
-    while (i < kMaxIter) {  // :119
-        if (++it > prm.iter_cap) { st = RT_TRACK_ITER_CAP; break; }
+    NextRec nr;
+    load_next(m, -1, nr);
+    // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
+    // band.  Run as its own loop so that the 64 lanes of the wave, whose bands differ in length
+    // (≈1/sin ϕ or 1/|cos ϕ| steps), reach their first locate together.
+    while (st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
+        if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
+        xpx = xpx + sx; xpy = xpy + sy;
+    }
+#ifdef RT_STATS
+    unsigned long long tk_walk = 0, tk_gen = 0, tk_emit = 0, tk_band = 0, n_gen = 0;
+    const unsigned long long tk_begin = __builtin_amdgcn_s_memtime();
+#endif
+    while (st == RT_TRACK_OK && i < kMaxIter) {  // :119
+#ifdef RT_STATS
+        const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
         // The reference locates first and tests the boundary second (:122-125); the locate
         // result is unused on both boundary branches, so the order is swapped here.
         if (inboundary(m, xpx, xpy, prm.tiny_step)) {  // :125
-            if (i == 0) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :126-129
-            break;                                                      // :130-132
+            if (i == 0) {
+                xpx = xpx + sx; xpy = xpy + sy;
+#ifdef RT_STATS
+                tk_band += __builtin_amdgcn_s_memtime() - tk0;
+#endif
+                continue;  // :126-129
+            }
+            break;  // :130-132
         }
         double px, py, qx, qy, ell;
         int32_t element = -1;
-        int res = kWalkGeneric;
-        if (m.walk_ok && wk.pred >= 0) {
-            res = walk_step(m, wk, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
-#ifdef RT_STATS
-            if (MODE != kFill) atomicAdd(&fail_info[2 + res], 1ull);
+#ifdef RT_NO_PREFETCH
+        load_next(m, wk.pred, nr);
 #endif
-            if (res == kWalkSkip) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
-            if (res == kWalkEmit) { px = lqx; py = lqy; element = wk.T; }
-        }
+        const int res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+#ifndef RT_NO_PREFETCH
+        if (res == kWalkEmit) load_next(m, wk.pred, nr);  // one iteration ahead, before this iteration's stores
+#endif
+#ifdef RT_STATS
+        if (MODE != kFill) atomicAdd(&fail_info[2 + res], 1ull);
+#endif
+        if (res == kWalkSkip) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
+        px = lqx; py = lqy; element = wk.T;  // valid when res == kWalkEmit
+#ifdef RT_STATS
+        const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+        tk_walk += tk1 - tk0;
+#endif
 #ifdef RT_STATS
         if (MODE != kFill) {
             const unsigned long long any_gen = __ballot(res == kWalkGeneric);
@@ -178,15 +209,22 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
             }
             if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :156-159
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
-            if (m.walk_ok && eq >= 0) walk_enter(wk, m.rec[element], element, eq);
+            if (m.walk_ok && eq >= 0) walk_enter(m, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
+#ifndef RT_NO_PREFETCH
+            load_next(m, wk.pred, nr);
+#endif
         }
+#ifdef RT_STATS
+        const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+        if (__ballot(res == kWalkGeneric)) { tk_gen += tk2 - tk1; n_gen++; }
+#endif
         if (MODE == kFill) {
             const int64_t o = base + i;
             out.px[o] = px; out.py[o] = py; out.qx[o] = qx; out.qy[o] = qy;
             out.ell[o] = ell;
             out.element[o] = element + 1;
-            if (out.fused_volumes) unsafeAtomicAdd(&out.volumes[element], w * ell);  // src/trackgenerator.jl:382
+            if (out.fused_volumes) unsafeAtomicAdd((double *)&out.volumes[element], w * ell);  // src/trackgenerator.jl:382
         } else if (MODE == kStage) {
             const int r = i & (kChunkRows - 1);
             if (r == 0) {
@@ -203,7 +241,7 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
                     int32_t c = chunk_lds[jL];
                     if (c == -1) {
                         if (lane == L) {
-                            c = atomicAdd(&stg.cursor[0], 1);
+                            c = atomicAdd((int32_t *)&stg.cursor[0], 1);
                             if (c >= stg.pool_chunks) { c = -2; stg.cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
                             else stg.ctab[(int64_t)blockIdx.x * kMaxChunks + jL] = c;
                             chunk_lds[jL] = c;
@@ -225,7 +263,17 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
         xpx = qx + sx; xpy = qy + sy;  // :165
         prev_element = element;        // :166
         ++i;                           // :168
+#ifdef RT_STATS
+        tk_emit += __builtin_amdgcn_s_memtime() - tk2;
+#endif
     }
+#ifdef RT_STATS
+    if (MODE != kFill && lane == __ffsll((long long)__ballot(1)) - 1) {
+        atomicAdd(&fail_info[8], tk_walk); atomicAdd(&fail_info[9], tk_gen); atomicAdd(&fail_info[10], tk_emit);
+        atomicAdd(&fail_info[11], tk_band); atomicAdd(&fail_info[12], __builtin_amdgcn_s_memtime() - tk_begin);
+        atomicAdd(&fail_info[13], n_gen);
+    }
+#endif
     if (MODE != kFill) {
         // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol)
         if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
@@ -261,8 +309,8 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
     }
     const int tsub = lane >> 4, r16 = lane & 15;
     int32_t *itile = reinterpret_cast<int32_t *>(tile);
-    const double *src[5] = {stg.px, stg.py, stg.qx, stg.qy, stg.ell};
-    double *dst[5] = {out.px, out.py, out.qx, out.qy, out.ell};
+    const RT_G double *src[5] = {stg.px, stg.py, stg.qx, stg.qy, stg.ell};
+    RT_G double *dst[5] = {out.px, out.py, out.qx, out.qy, out.ell};
     for (int j = 0; j * kChunkRows < maxcnt; ++j) {
         const int32_t c = stg.ctab[wv * kMaxChunks + j];
         const int64_t s0 = ((int64_t)c * kChunkRows) * 64 + lane;
@@ -444,7 +492,8 @@ struct rt_mesh {
     int32_t n_nodes = 0, n_cells = 0;
     DevBuf<double> x, y;
     DevBuf<int32_t> cn, ncp, ncd, gstart, gnode;
-    DevBuf<rt::CellRec> rec;
+    DevBuf<rt::WalkRec> wrec;
+    DevBuf<int32_t> adjr;
     rt::DMesh d{};
     int64_t iter_cap = 4000000;
     bool walk_available = false;
@@ -526,17 +575,19 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     if ((rc = upload(m->ncd, ncd.data(), (size_t)nnz, s))) return rc;
     if ((rc = upload(m->gstart, gstart.data(), gstart.size(), s))) return rc;
     if ((rc = upload(m->gnode, gnode.data(), (size_t)n_nodes, s))) return rc;
-    if ((rc = upload(m->rec, reinterpret_cast<const rt::CellRec *>(P.rec.data()), P.rec.size(), s))) return rc;
+    if ((rc = upload(m->wrec, reinterpret_cast<const rt::WalkRec *>(P.wrec.data()), P.wrec.size(), s))) return rc;
+    if ((rc = upload(m->adjr, P.adjr.data(), P.adjr.size(), s))) return rc;
     RT_HIP(hipStreamSynchronize(s));  // host vectors die at return
     m->n_nodes = n_nodes;
     m->n_cells = n_cells;
     rt::DMesh &d = m->d;
-    d.x = m->x.p; d.y = m->y.p; d.cn = m->cn.p; d.ncp = m->ncp.p; d.ncd = m->ncd.p;
-    d.gstart = m->gstart.p; d.gnode = m->gnode.p;
+    using rt::as_global;
+    d.x = as_global(m->x.p); d.y = as_global(m->y.p); d.cn = as_global(m->cn.p); d.ncp = as_global(m->ncp.p);
+    d.ncd = as_global(m->ncd.p); d.gstart = as_global(m->gstart.p); d.gnode = as_global(m->gnode.p);
     d.gx0 = bb[0]; d.gy0 = bb[1]; d.gh = gh; d.ginv = ginv; d.gnx = gnx; d.gny = gny;
     d.bx0 = bb[0]; d.by0 = bb[1]; d.bx1 = bb[2]; d.by1 = bb[3];
     d.n_nodes = n_nodes; d.n_cells = n_cells;
-    d.rec = m->rec.p; d.eps_iso = P.eps_iso; d.d_vertex = P.d_vertex; d.l_min = P.l_min;
+    d.wrec = as_global(m->wrec.p); d.adjr = as_global(m->adjr.p); d.eps_iso = P.eps_iso; d.d_vertex = P.d_vertex; d.l_min = P.l_min;
     d.walk_ok = P.walk_ok ? 1 : 0;
     m->walk_available = P.walk_ok;
     m->kappa = P.kappa;
@@ -546,7 +597,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
 
 void free_mesh(rt_mesh *m) {
     m->x.release(); m->y.release(); m->cn.release(); m->ncp.release(); m->ncd.release();
-    m->gstart.release(); m->gnode.release(); m->rec.release();
+    m->gstart.release(); m->gnode.release(); m->wrec.release(); m->adjr.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -623,6 +674,19 @@ rt_mesh *rt_mesh_create(int32_t device, const double *x, const double *y, int32_
         free_mesh(m);
         return nullptr;
     }
+    // development knob: RT_OPTIONS="name=value,name=value" applies rt_set_option at creation
+    if (const char *env = getenv("RT_OPTIONS")) {
+        std::string e(env);
+        size_t pos = 0;
+        while (pos < e.size()) {
+            size_t end = e.find(',', pos);
+            if (end == std::string::npos) end = e.size();
+            const std::string kv = e.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) (void)rt_set_option(m, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1));
+            pos = end + 1;
+        }
+    }
     return m;
 }
 
@@ -685,8 +749,10 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
         return nullptr;
     }
     rt::DTracks &d = t->d;
-    d.px = t->px.p; d.py = t->py.p; d.phi = t->phi.p; d.cs = t->cs.p; d.sn = t->sn.p;
-    d.A = t->A.p; d.B = t->B.p; d.C = t->C.p; d.ell = t->ell.p; d.azim = t->azim.p; d.perm = t->perm.p;
+    using rt::as_global;
+    d.px = as_global(t->px.p); d.py = as_global(t->py.p); d.phi = as_global(t->phi.p); d.cs = as_global(t->cs.p);
+    d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
+    d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
     d.n = n_tracks;
     return t;
 }
@@ -717,19 +783,20 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     RT_HIP(t->offsets.reserve(n + 1));
     RT_HIP(t->tile_sums.reserve(n_tiles + 1));
     RT_HIP(t->scalars.reserve(4));
-    RT_HIP(t->fail_info.reserve(8));
+    RT_HIP(t->fail_info.reserve(16));
     RT_HIP(t->cursor.reserve(4));
     RT_HIP(t->volumes.reserve(m->n_cells));
     if (int rc = upload(t->delta_s, delta_s, (size_t)n_azim_2, s)) return rc;
 
     rt::DOut out{};
-    out.volumes = t->volumes.p;
-    out.delta_s = t->delta_s.p;
+    using rt::as_global;
+    out.volumes = as_global(t->volumes.p);
+    out.delta_s = as_global(t->delta_s.p);
     out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
     rt::DStage stg{};
     const unsigned grid = (unsigned)n_waves;
     int64_t total = 0;
-    unsigned long long fi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long fi[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float f = 0;
 
     auto scan_counts = [&]() -> int {
@@ -749,11 +816,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         const size_t cap = (size_t)(tot > 0 ? tot : 1);
         RT_HIP(t->spx.reserve(cap)); RT_HIP(t->spy.reserve(cap)); RT_HIP(t->sqx.reserve(cap));
         RT_HIP(t->sqy.reserve(cap)); RT_HIP(t->sell.reserve(cap)); RT_HIP(t->element.reserve(cap));
-        out.px = t->spx.p; out.py = t->spy.p; out.qx = t->sqx.p; out.qy = t->sqy.p; out.ell = t->sell.p;
-        out.element = t->element.p;
+        out.px = as_global(t->spx.p); out.py = as_global(t->spy.p); out.qx = as_global(t->sqx.p);
+        out.qy = as_global(t->sqy.p); out.ell = as_global(t->sell.p); out.element = as_global(t->element.p);
         return RT_SUCCESS;
     };
-    const unsigned long long fi0[8] = {0ull, ~0ull, 0, 0, 0, 0, 0, 0};
+    const unsigned long long fi0[16] = {0ull, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     RT_HIP(hipEventRecord(t->ev[0], s));
     RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
@@ -771,8 +838,9 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                 RT_HIP(t->gqy.reserve(slots)); RT_HIP(t->gell.reserve(slots)); RT_HIP(t->gelement.reserve(slots));
                 t->pool_chunks = want;
             }
-            stg.px = t->gpx.p; stg.py = t->gpy.p; stg.qx = t->gqx.p; stg.qy = t->gqy.p; stg.ell = t->gell.p;
-            stg.element = t->gelement.p; stg.ctab = t->ctab.p; stg.cursor = t->cursor.p;
+            stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
+            stg.qy = as_global(t->gqy.p); stg.ell = as_global(t->gell.p); stg.element = as_global(t->gelement.p);
+            stg.ctab = as_global(t->ctab.p); stg.cursor = as_global(t->cursor.p);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
             RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemsetAsync(t->cursor.p, 0, 4 * sizeof(int32_t), s));
@@ -847,6 +915,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
 #ifdef RT_STATS
     fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
             fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
+    fprintf(stderr, "[rt stats] memtime ticks (last lane alive per wave): walk=%llu generic=%llu (n=%llu) emit=%llu band=%llu lifetime=%llu\n",
+            fi[8], fi[9], fi[13], fi[10], fi[11], fi[12]);
 #endif
     t->total = total;
     t->n_failed = (int64_t)fi[0];
