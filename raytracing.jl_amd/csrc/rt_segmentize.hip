@@ -93,6 +93,7 @@ struct DStage {
     RT_G double *px, *py, *qx, *qy, *ell;
     RT_G int32_t *element;
     RT_G int32_t *ctab;     // [n_waves][kMaxChunks] chunk ids
+    RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
 };
@@ -173,12 +174,12 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
         }
         double px, py, qx, qy, ell;
         int32_t element = -1;
-#ifdef RT_NO_PREFETCH
+#ifndef RT_PREFETCH
         load_next(m, wk.pred, nr);
 #endif
         const int res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
-#ifndef RT_NO_PREFETCH
-        if (res == kWalkEmit) load_next(m, wk.pred, nr);  // one iteration ahead, before this iteration's stores
+#ifdef RT_PREFETCH  // loading the next record one iteration ahead measured 2-3 % slower (253 VGPRs)
+        if (res == kWalkEmit) load_next(m, wk.pred, nr);
 #endif
 #ifdef RT_STATS
         if (MODE != kFill) atomicAdd(&fail_info[2 + res], 1ull);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
             if (m.walk_ok && eq >= 0) walk_enter(m, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
-#ifndef RT_NO_PREFETCH
+#ifdef RT_PREFETCH
             load_next(m, wk.pred, nr);
 #endif
         }
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
                         if (lane == L) {
                             c = atomicAdd((int32_t *)&stg.cursor[0], 1);
                             if (c >= stg.pool_chunks) { c = -2; stg.cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
-                            else stg.ctab[(int64_t)blockIdx.x * kMaxChunks + jL] = c;
+                            else {
+                                stg.ctab[(int64_t)blockIdx.x * kMaxChunks + jL] = c;
+                                stg.cowner[c] = (int32_t)(blockIdx.x * kMaxChunks + jL);
+                            }
                             chunk_lds[jL] = c;
                         }
                         c = __shfl(c, L);
@@ -286,14 +290,25 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
     }
 }
 
-// Staging pool -> compact CSR records.  One wave per wave of tracks: rows are read coalesced
-// (512 B per row and array), transposed through an LDS tile, and written as runs of up to
-// kChunkRows consecutive records per track (4 tracks x 16 rows per store instruction).
+// Staging pool -> compact CSR records.  One wave per CHUNK (16 rows x 64 tracks x 6 arrays):
+// rows are read coalesced (512 B per row and array), transposed through an LDS tile (row
+// pitch 66 doubles: conflict-free for both the row-wise writes and the column-wise reads),
+// and written as runs of up to 16 consecutive records per track (4 tracks x 16 rows per
+// store instruction).  The grid covers the whole pool; workgroups past the cursor exit.
+constexpr int kTilePitch = 66;
+// grid = (pool chunks, 6 arrays): one wave moves one array of one chunk, so no wave ever queues
+// a load behind its own stores (gfx950 retires loads and stores through one in-order vmcnt
+// queue) and the chip sees ~6x more independent waves.
 __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__restrict__ counts,
                                                 const int64_t *__restrict__ offsets, DStage stg, DOut out) {
-    __shared__ double tile[kChunkRows * 65];
+    __shared__ double tile[kChunkRows * kTilePitch];
+    const int32_t c = blockIdx.x;
+    if (c >= stg.cursor[0]) return;
+    const int a = blockIdx.y;
     const int lane = threadIdx.x;
-    const int64_t wv = blockIdx.x;
+    const int32_t owner = stg.cowner[c];
+    const int64_t wv = owner / kMaxChunks;
+    const int j = owner % kMaxChunks;
     const int64_t slot = wv * 64 + lane;
     int32_t cnt = 0;
     int64_t off = 0;
@@ -302,51 +317,39 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
         cnt = counts[u];
         off = offsets[u];
     }
-    int32_t maxcnt = cnt;
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t v = __shfl_xor(maxcnt, o, 64);
-        maxcnt = v > maxcnt ? v : maxcnt;
-    }
     const int tsub = lane >> 4, r16 = lane & 15;
-    int32_t *itile = reinterpret_cast<int32_t *>(tile);
-    const RT_G double *src[5] = {stg.px, stg.py, stg.qx, stg.qy, stg.ell};
-    RT_G double *dst[5] = {out.px, out.py, out.qx, out.qy, out.ell};
-    for (int j = 0; j * kChunkRows < maxcnt; ++j) {
-        const int32_t c = stg.ctab[wv * kMaxChunks + j];
-        const int64_t s0 = ((int64_t)c * kChunkRows) * 64 + lane;
-        const int row = j * kChunkRows + r16;
+    const int64_t s0 = ((int64_t)c * kChunkRows) * 64 + lane;
+    const int row = j * kChunkRows + r16;
+    if (a < 5) {
+        const RT_G double *src = a == 0 ? stg.px : a == 1 ? stg.py : a == 2 ? stg.qx : a == 3 ? stg.qy : stg.ell;
+        RT_G double *dst = a == 0 ? out.px : a == 1 ? out.py : a == 2 ? out.qx : a == 3 ? out.qy : out.ell;
+        double v[kChunkRows];
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
-            double v[kChunkRows];
+        for (int r = 0; r < kChunkRows; ++r) v[r] = src[s0 + r * 64];
 #pragma unroll
-            for (int r = 0; r < kChunkRows; ++r) v[r] = src[a][s0 + r * 64];
+        for (int r = 0; r < kChunkRows; ++r) tile[r * kTilePitch + lane] = v[r];
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < kChunkRows; ++r) tile[r * 65 + lane] = v[r];
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int tt = g * 4 + tsub;
-                const int32_t ct = __shfl(cnt, tt, 64);
-                const int64_t ot = __shfl(off, tt, 64);
-                if (row < ct) dst[a][ot + row] = tile[r16 * 65 + tt];
-            }
-            __syncthreads();
+        for (int g = 0; g < 16; ++g) {  // this lane writes row `row` of track tt = 4 g + tsub
+            const int tt = g * 4 + tsub;
+            const int32_t ct = __shfl(cnt, tt, 64);
+            const int64_t ot = __shfl(off, tt, 64);
+            if (row < ct) dst[ot + row] = tile[r16 * kTilePitch + tt];
         }
-        {
-            int32_t v[kChunkRows];
+    } else {
+        int32_t *itile = reinterpret_cast<int32_t *>(tile);
+        int32_t v[kChunkRows];
 #pragma unroll
-            for (int r = 0; r < kChunkRows; ++r) v[r] = stg.element[s0 + r * 64];
+        for (int r = 0; r < kChunkRows; ++r) v[r] = stg.element[s0 + r * 64];
 #pragma unroll
-            for (int r = 0; r < kChunkRows; ++r) itile[r * 65 + lane] = v[r];
-            __syncthreads();
+        for (int r = 0; r < kChunkRows; ++r) itile[r * kTilePitch + lane] = v[r];
+        __syncthreads();
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int tt = g * 4 + tsub;
-                const int32_t ct = __shfl(cnt, tt, 64);
-                const int64_t ot = __shfl(off, tt, 64);
-                if (row < ct) out.element[ot + row] = itile[r16 * 65 + tt];
-            }
-            __syncthreads();
+        for (int g = 0; g < 16; ++g) {
+            const int tt = g * 4 + tsub;
+            const int32_t ct = __shfl(cnt, tt, 64);
+            const int64_t ot = __shfl(off, tt, 64);
+            if (row < ct) out.element[ot + row] = itile[r16 * kTilePitch + tt];
         }
     }
 }
@@ -499,6 +502,7 @@ struct rt_mesh {
     bool walk_available = false;
     int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
+    int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
 };
@@ -518,7 +522,7 @@ struct rt_tracks {
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy, gell;
-    DevBuf<int32_t> gelement, ctab, cursor;
+    DevBuf<int32_t> gelement, ctab, cowner, cursor;
     int64_t pool_chunks = 0, chunks_needed_last = 0;
     double sum_ell = 0.0;
     hipEvent_t ev[8] = {};
@@ -610,7 +614,7 @@ void free_tracks(rt_tracks *t) {
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->delta_s.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release(); t->gell.release();
-    t->gelement.release(); t->ctab.release(); t->cursor.release();
+    t->gelement.release(); t->ctab.release(); t->cowner.release(); t->cursor.release();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     delete t;
@@ -708,6 +712,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "iter_cap")) { mesh->iter_cap = value > 0 ? value : 4000000; return RT_SUCCESS; }
     if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
         mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
         return RT_SUCCESS;
@@ -730,11 +735,25 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     t->n = n_tracks;
     hipStream_t s = mesh->stream;
     const size_t n = (size_t)n_tracks;
-    // march order: longest tracks first, so the waves that take longest start first and the
-    // 64 lanes of a wave carry tracks with similar segment counts
+    // march order (default 2): waves of 64 CONSECUTIVE uids, longest wave first.  Neighbouring
+    // tracks of one angle cross the same cells at the same time (shared walk records, coherent
+    // branches) and have nearly equal lengths; sorting individual tracks by length measured 20 %
+    // slower because it scatters the lanes of a wave over the whole mesh.
     std::vector<int32_t> perm(n);
     std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
+    if (mesh->sort_mode == 1) {
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
+    } else if (mesh->sort_mode == 2) {
+        const size_t nw = (n + 63) / 64;
+        std::vector<double> wmax(nw, 0.0);
+        for (size_t i = 0; i < n; ++i) wmax[i / 64] = std::max(wmax[i / 64], ell[i]);
+        std::vector<int32_t> worder(nw);
+        std::iota(worder.begin(), worder.end(), 0);
+        std::stable_sort(worder.begin(), worder.end(), [&](int32_t a, int32_t b) { return wmax[a] > wmax[b]; });
+        size_t k2 = 0;
+        for (size_t w = 0; w < nw; ++w)
+            for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
+    }
     for (size_t i = 0; i < n; ++i) t->sum_ell += ell[i];
     bool ok = upload(t->px, px, n, s) == 0 && upload(t->py, py, n, s) == 0 && upload(t->phi, phi, n, s) == 0 &&
               upload(t->cs, cos_phi, n, s) == 0 && upload(t->sn, sin_phi, n, s) == 0 && upload(t->A, A, n, s) == 0 &&
@@ -820,6 +839,27 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         out.qy = as_global(t->sqy.p); out.ell = as_global(t->sell.p); out.element = as_global(t->element.p);
         return RT_SUCCESS;
     };
+    // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
+    auto launch_volumes = [&]() -> int {
+        if (m->volumes_mode == 2 && n > 0) {
+            const int64_t want_blocks = 512;
+            int32_t tpb = (int32_t)std::max<int64_t>(1, (n + want_blocks - 1) / want_blocks);
+            tpb = std::min(tpb, 4096);
+            const int64_t nb = (n + tpb - 1) / tpb;
+            const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
+            const size_t rel_bytes = ((size_t)tpb + 1) * sizeof(int32_t);
+            const int use_lds = hist_bytes + rel_bytes <= 150 * 1024 ? 1 : 0;
+            const size_t shmem = (use_lds ? hist_bytes : 0) + rel_bytes;
+            if (shmem > 48 * 1024)
+                RT_HIP(hipFuncSetAttribute((const void *)rt::k_volumes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL(rt::k_volumes, dim3((unsigned)nb), dim3(1024), shmem, s, (const int64_t *)t->offsets.p, n,
+                               (const int32_t *)t->azim.p, (const double *)t->delta_s.p, (const int32_t *)t->element.p,
+                               (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds);
+        }
+        hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
+                           m->n_cells, (double)n_azim_2);
+        return RT_SUCCESS;
+    };
     const unsigned long long fi0[16] = {0ull, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     RT_HIP(hipEventRecord(t->ev[0], s));
@@ -836,14 +876,19 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                 const size_t slots = (size_t)want * rt::kChunkRows * 64;
                 RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots));
                 RT_HIP(t->gqy.reserve(slots)); RT_HIP(t->gell.reserve(slots)); RT_HIP(t->gelement.reserve(slots));
+                RT_HIP(t->cowner.reserve((size_t)want));
                 t->pool_chunks = want;
             }
+            // the compact records can never outnumber the pool's slots: sizing the outputs by the
+            // pool lets march -> scan -> compaction -> volumes run back to back without a host sync
+            if (int rc = reserve_out(t->pool_chunks * rt::kChunkRows * 64)) return rc;
             stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
             stg.qy = as_global(t->gqy.p); stg.ell = as_global(t->gell.p); stg.element = as_global(t->gelement.p);
-            stg.ctab = as_global(t->ctab.p); stg.cursor = as_global(t->cursor.p);
+            stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(t->cursor.p);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
             RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemsetAsync(t->cursor.p, 0, 4 * sizeof(int32_t), s));
+            RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
             RT_HIP(hipEventRecord(t->ev[1], s));
             if (n > 0)
                 hipLaunchKernelGGL(rt::k_march<rt::kStage>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
@@ -851,6 +896,13 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             RT_HIP(hipEventRecord(t->ev[2], s));
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
+            RT_HIP(hipEventRecord(t->ev[4], s));
+            if (n > 0)
+                hipLaunchKernelGGL(rt::k_compact, dim3((unsigned)stg.pool_chunks, 6), dim3(64), 0, s, t->d,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out);
+            RT_HIP(hipEventRecord(t->ev[5], s));
+            if (int rc = launch_volumes()) return rc;
+            RT_HIP(hipEventRecord(t->ev[6], s));
             int32_t cur[4] = {0, 0, 0, 0};
             RT_HIP(hipMemcpyAsync(&total, t->scalars.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
             RT_HIP(hipMemcpyAsync(fi, t->fail_info.p, sizeof(fi), hipMemcpyDeviceToHost, s));
@@ -861,12 +913,6 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
         }
-        if (int rc = reserve_out(total)) return rc;
-        RT_HIP(hipEventRecord(t->ev[4], s));
-        if (n > 0 && total > 0)
-            hipLaunchKernelGGL(rt::k_compact, dim3(grid), dim3(64), 0, s, t->d, (const int32_t *)t->counts.p,
-                               (const int64_t *)t->offsets.p, stg, out);
-        RT_HIP(hipEventRecord(t->ev[5], s));
     } else {
         RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
         RT_HIP(hipEventRecord(t->ev[1], s));
@@ -885,27 +931,10 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             hipLaunchKernelGGL(rt::k_march<rt::kFill>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
                                t->status.p, (const int64_t *)t->offsets.p, out, stg, t->fail_info.p);
         RT_HIP(hipEventRecord(t->ev[5], s));
+        if (int rc = launch_volumes()) return rc;
+        RT_HIP(hipEventRecord(t->ev[6], s));
+        RT_HIP(hipStreamSynchronize(s));
     }
-    // ---- fill_volumes
-    if (m->volumes_mode == 2 && n > 0 && total > 0) {
-        const int64_t want_blocks = 512;
-        int32_t tpb = (int32_t)std::max<int64_t>(1, (n + want_blocks - 1) / want_blocks);
-        tpb = std::min(tpb, 4096);
-        const int64_t nb = (n + tpb - 1) / tpb;
-        const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
-        const size_t rel_bytes = ((size_t)tpb + 1) * sizeof(int32_t);
-        const int use_lds = hist_bytes + rel_bytes <= 150 * 1024 ? 1 : 0;
-        const size_t shmem = (use_lds ? hist_bytes : 0) + rel_bytes;
-        if (shmem > 48 * 1024)
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_volumes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(rt::k_volumes, dim3((unsigned)nb), dim3(1024), shmem, s, (const int64_t *)t->offsets.p, n,
-                           (const int32_t *)t->azim.p, (const double *)t->delta_s.p, (const int32_t *)t->element.p,
-                           (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds);
-    }
-    hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
-                       m->n_cells, (double)n_azim_2);
-    RT_HIP(hipEventRecord(t->ev[6], s));
-    RT_HIP(hipStreamSynchronize(s));
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[6])); t->ms[0] = f;   // whole call, device side
     RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
