@@ -33,7 +33,27 @@ if ROOT not in sys.path:
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
-BYTES_PER_SEGMENT = 45.0      # 44 B written + ≈1.3 B of amortised track input
+# Algorithmic bytes per segment of each kernel of a step.  The march's figure is
+# SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input.  The compaction
+# reads each 44-B record from the staging pool and writes it to its CSR position.
+KERNELS = {
+    "march": ("rt::k_march<2>", 45.0),
+    "compact": ("rt::k_compact", 88.0),
+    "volumes": ("rt::k_volumes", 12.0),
+}
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+
+
+def hbm_traffic_per_launch(kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01): FETCH_SIZE and
+    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads and is
+    doubled (MI355X_MICROARCH.md §HBM).  None when no profile of this build is committed."""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+        k = d["kernels"][kernel_name]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 
 
 def cpu_baseline(tg, max_seconds=30.0):
@@ -48,8 +68,8 @@ def cpu_baseline(tg, max_seconds=30.0):
     t0 = time.perf_counter()
     r = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, tiny_step=tg.tiny_step, n_threads=0)
     dt_all = time.perf_counter() - t0
-    # single-core leg: every 16th track (bounded)
-    sel = np.arange(0, tg.n_total_tracks, 16)
+    # single-core leg: every 4th track (bounded)
+    sel = np.arange(0, tg.n_total_tracks, 4)
     om1 = orc.OracleMesh.from_mesh(tg.mesh, omp=False)
     t0 = time.perf_counter()
     r1 = om1.segmentize(tg.px[sel], tg.py[sel], tg.phi[sel], tg.A[sel], tg.B[sel], tg.C[sel], tg.ell[sel],
@@ -60,7 +80,7 @@ def cpu_baseline(tg, max_seconds=30.0):
         "sample": "full workload once (%d tracks, %d segments), OpenMP over tracks, %.2f s wall"
                   % (tg.n_total_tracks, r["total"], dt_all),
         "single_core": {"value": r1["total"] / dt_1, "unit": "segments/s", "cores": 1,
-                        "sample": "every 16th track (%d tracks, %d segments), %.2f s" % (len(sel), r1["total"], dt_1)},
+                        "sample": "every 4th track (%d tracks, %d segments), %.2f s" % (len(sel), r1["total"], dt_1)},
     }
 
 
@@ -126,7 +146,7 @@ def main():
     for _ in range(args.warmup):
         local_total = step()
     sync()
-    kern = {"march": 0.0, "fill": 0.0, "scan": 0.0, "volumes": 0.0, "plan": 0.0, "total": 0.0}
+    kern = {"march": 0.0, "compact": 0.0, "scan": 0.0, "volumes": 0.0, "plan": 0.0, "total": 0.0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         local_total = step()
@@ -173,9 +193,14 @@ def main():
 
     if rank == 0:
         ms_per_step = t_max / args.steps * 1e3
-        dom = "fill" if kern["fill"] >= kern["march"] else "march"
-        dom_ms = kern[dom] / args.steps
-        achieved = BYTES_PER_SEGMENT * local_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        per_kernel = []
+        for key, (kname, bps) in KERNELS.items():
+            ms = kern[key] / args.steps
+            per_kernel.append({"kernel": kname, "ms_avg": ms, "bytes_per_segment": bps,
+                               "achieved_GBs": bps * local_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                               "traffic": hbm_traffic_per_launch(kname)})
+        dom_k = max(per_kernel, key=lambda k: k["ms_avg"])
+        achieved = dom_k["achieved_GBs"]
         out = {
             "metric": "segments/sec (whole node)",
             "value": global_segments * args.steps / t_max,
@@ -198,14 +223,15 @@ def main():
                 "tiny_step": tg.tiny_step, "k": 5, "rtol": rt.RTOL_DEFAULT,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_march<%s>" % ("true" if dom == "fill" else "false"),
+                "bound": "hbm", "kernel": dom_k["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "bytes_per_segment": BYTES_PER_SEGMENT, "segments_per_launch": int(local_total),
-                "kernel_ms_avg": dom_ms,
-                "note": "FP64 traversal, not a streaming kernel: 45 B/segment of algorithmic traffic cannot approach the "
-                        "HBM roof; the limiter is the per-track dependent chain (see DESIGN.md)",
+                "traffic": dom_k["traffic"],
+                "bytes_per_segment": dom_k["bytes_per_segment"], "segments_per_launch": int(local_total),
+                "kernel_ms_avg": dom_k["ms_avg"],
+                "note": "dominant kernel by HIP-event duration; algorithmic bytes = bytes_per_segment x segments per launch "
+                        "(DESIGN.md §4).  The march is FP64 traversal bound by its per-track dependent chain, not by HBM",
             },
+            "kernels": per_kernel,
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},
         }
         if allgather is not None:

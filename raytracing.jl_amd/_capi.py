@@ -210,7 +210,9 @@ class DeviceTracks:
     def timing(self):
         ms = np.zeros(8, np.float64)
         _check(lib().rt_last_timing(self._h, ms.ctypes.data_as(_dp), 8))
-        return dict(total=ms[0], plan=ms[1], march=ms[2], scan=ms[3], fill=ms[4], volumes=ms[5])
+        # compact: staging -> CSR compaction (single-pass mode) or the second, writing march (two-pass mode)
+        return dict(total=float(ms[0]), plan=float(ms[1]), march=float(ms[2]), scan=float(ms[3]), compact=float(ms[4]),
+                    volumes=float(ms[5]))
 
     def close(self):
         if getattr(self, "_h", None):
