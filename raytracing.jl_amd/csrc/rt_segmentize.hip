@@ -85,8 +85,11 @@ struct DOut {
 // column l — lanes of a wave emit in near lockstep, so each store instruction writes whole
 // 512-B rows instead of 64 scattered 8-B pieces.  Chunks are handed out from one atomic
 // cursor, once per wave and chunk (wave-aggregated), and recorded in `ctab` for k_compact.
-constexpr int kChunkRows = 16;
-constexpr int kChunkLog2 = 4;
+#ifndef RT_CHUNK_LOG2
+#define RT_CHUNK_LOG2 5  // 32 rows per chunk measured best (8: -18 %, 16: -6 % vs 32 at C3)
+#endif
+constexpr int kChunkLog2 = RT_CHUNK_LOG2;
+constexpr int kChunkRows = 1 << kChunkLog2;
 constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
 
 struct DStage {
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
 // pitch 66 doubles: conflict-free for both the row-wise writes and the column-wise reads),
 // and written as runs of up to 16 consecutive records per track (4 tracks x 16 rows per
 // store instruction).  The grid covers the whole pool; workgroups past the cursor exit.
-constexpr int kTilePitch = 66;
+constexpr int kTilePitch = kChunkRows == 16 ? 66 : 65;  // conflict-free column reads for 4 (resp. 2) tracks per instruction
+constexpr int kTracksPerStore = 64 / kChunkRows;
 // grid = (pool chunks, 6 arrays): one wave moves one array of one chunk, so no wave ever queues
 // a load behind its own stores (gfx950 retires loads and stores through one in-order vmcnt
 // queue) and the chip sees ~6x more independent waves.
@@ -317,7 +321,13 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
         cnt = counts[u];
         off = offsets[u];
     }
-    const int tsub = lane >> 4, r16 = lane & 15;
+    int32_t maxcnt = cnt;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t v = __shfl_xor(maxcnt, o, 64);
+        maxcnt = v > maxcnt ? v : maxcnt;
+    }
+    const int nrows = min(kChunkRows, maxcnt - j * kChunkRows);  // rows of this chunk any lane used (wave-uniform)
+    const int tsub = lane >> kChunkLog2, r16 = lane & (kChunkRows - 1);
     const int64_t s0 = ((int64_t)c * kChunkRows) * 64 + lane;
     const int row = j * kChunkRows + r16;
     if (a < 5) {
@@ -325,13 +335,13 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
         RT_G double *dst = a == 0 ? out.px : a == 1 ? out.py : a == 2 ? out.qx : a == 3 ? out.qy : out.ell;
         double v[kChunkRows];
 #pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) v[r] = src[s0 + r * 64];
+        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? src[s0 + r * 64] : 0.0;
 #pragma unroll
         for (int r = 0; r < kChunkRows; ++r) tile[r * kTilePitch + lane] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {  // this lane writes row `row` of track tt = 4 g + tsub
-            const int tt = g * 4 + tsub;
+        for (int g = 0; g < 64 / kTracksPerStore; ++g) {  // this lane writes row `row` of track tt
+            const int tt = g * kTracksPerStore + tsub;
             const int32_t ct = __shfl(cnt, tt, 64);
             const int64_t ot = __shfl(off, tt, 64);
             if (row < ct) dst[ot + row] = tile[r16 * kTilePitch + tt];
@@ -340,13 +350,13 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
         int32_t *itile = reinterpret_cast<int32_t *>(tile);
         int32_t v[kChunkRows];
 #pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) v[r] = stg.element[s0 + r * 64];
+        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? stg.element[s0 + r * 64] : 0;
 #pragma unroll
         for (int r = 0; r < kChunkRows; ++r) itile[r * kTilePitch + lane] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int tt = g * 4 + tsub;
+        for (int g = 0; g < 64 / kTracksPerStore; ++g) {
+            const int tt = g * kTracksPerStore + tsub;
             const int32_t ct = __shfl(cnt, tt, 64);
             const int64_t ot = __shfl(off, tt, 64);
             if (row < ct) out.element[ot + row] = itile[r16 * kTilePitch + tt];
