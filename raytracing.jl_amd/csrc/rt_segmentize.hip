@@ -307,7 +307,9 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
                                                 const int64_t *__restrict__ offsets, DStage stg, DOut out) {
     __shared__ double tile[kChunkRows * kTilePitch];
     const int32_t c = blockIdx.x;
-    if (c >= stg.cursor[0]) return;
+    // cursor[1] != 0: the pool overflowed, the records are incomplete and the CSR offsets exceed
+    // the output buffers — the host grows the pool and re-runs the whole call
+    if (stg.cursor[1] != 0 || c >= stg.cursor[0]) return;
     const int a = blockIdx.y;
     const int lane = threadIdx.x;
     const int32_t owner = stg.cowner[c];
@@ -455,8 +457,10 @@ __global__ __launch_bounds__(1024) void k_volumes(const int64_t *__restrict__ of
                                                   const double *__restrict__ delta_s,
                                                   const int32_t *__restrict__ element,
                                                   const double *__restrict__ ell, double *__restrict__ volumes,
-                                                  int32_t n_cells, int32_t tpb, int32_t use_lds) {
+                                                  int32_t n_cells, int32_t tpb, int32_t use_lds,
+                                                  const int32_t *__restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (overflow && *overflow) return;  // staging pool overflowed: this attempt's records are void
     double *hist = reinterpret_cast<double *>(smem);
     int32_t *rel = reinterpret_cast<int32_t *>(smem + (use_lds ? (size_t)n_cells * sizeof(double) : 0));
     const int64_t u0 = (int64_t)blockIdx.x * tpb;
@@ -512,6 +516,7 @@ struct rt_mesh {
     bool walk_available = false;
     int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
+    int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
@@ -722,6 +727,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "iter_cap")) { mesh->iter_cap = value > 0 ? value : 4000000; return RT_SUCCESS; }
     if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
         mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
@@ -864,7 +870,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                 RT_HIP(hipFuncSetAttribute((const void *)rt::k_volumes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             hipLaunchKernelGGL(rt::k_volumes, dim3((unsigned)nb), dim3(1024), shmem, s, (const int64_t *)t->offsets.p, n,
                                (const int32_t *)t->azim.p, (const double *)t->delta_s.p, (const int32_t *)t->element.p,
-                               (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds);
+                               (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds,
+                               m->single_pass ? (const int32_t *)(t->cursor.p + 1) : (const int32_t *)nullptr);
         }
         hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
                            m->n_cells, (double)n_azim_2);
@@ -881,6 +888,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         int64_t want = t->chunks_needed_last > 0
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
                            : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * n_waves + 64;
+        if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
                 const size_t slots = (size_t)want * rt::kChunkRows * 64;

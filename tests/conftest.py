@@ -67,3 +67,27 @@ def oracle_run(orc):
         return cache[key]
 
     return run
+
+
+def make_grid_model(rt, nx, ny, x0=0.0, y0=0.0, hx=1.0, hy=1.0, flip=False):
+    """Structured right-triangle mesh (every square cut along one diagonal): many parallel and
+    collinear edges; with 45-degree tracks the rays pass exactly through vertices."""
+    import numpy as np
+
+    xs, ys = np.meshgrid(np.arange(nx + 1) * hx + x0, np.arange(ny + 1) * hy + y0, indexing="xy")
+    xy = np.column_stack((xs.ravel(), ys.ravel()))
+    cells = []
+    for j in range(ny):
+        for i in range(nx):
+            a = j * (nx + 1) + i + 1
+            b, c, d = a + 1, a + nx + 1, a + nx + 2
+            if flip and (i + j) % 2:
+                cells += [sorted((a, b, d)), sorted((a, d, c))]
+            else:
+                cells += [sorted((a, b, c)), sorted((b, d, c))]
+    return rt.DiscreteModel(xy, np.asarray(cells, dtype=np.int32))
+
+
+@pytest.fixture(scope="session")
+def grid_model(rt):
+    return lambda *a, **k: make_grid_model(rt, *a, **k)

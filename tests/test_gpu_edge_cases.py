@@ -1,0 +1,139 @@
+"""Edge cases of the HIP path against the oracle (GPU only): parameters the reference exposes
+(k, rtol, tiny_step), shifted / anisotropic domains, structured meshes whose tracks run through
+vertices and along edges, tiny batches, and the library's internal modes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("px", "py", "qx", "qy", "ell")
+
+
+def _oracle(orc, tg, **kw):
+    om = orc.OracleMesh.from_mesh(tg.mesh)
+    r = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                      tiny_step=tg.tiny_step, iter_cap=4000000, **kw)
+    aq = tg.azimuthal_quadrature
+    r["volumes"] = om.fill_volumes(r["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
+    return r
+
+
+def _same(tg, ref, check_volumes=True):
+    s = tg.segments
+    assert np.array_equal(tg.track_status, ref["status"]), "per-track status differs"
+    assert np.array_equal(s.offsets, ref["offsets"]), "segment counts differ"
+    assert np.array_equal(s.element, ref["element"]), "element ids differ"
+    for k in FIELDS:
+        a, b = getattr(s, k), ref[k]
+        assert np.all(np.abs(a - b) <= 1e-10 * np.maximum(np.abs(b), 1e-300)), k
+    if check_volumes:
+        assert np.allclose(tg.volumes, ref["volumes"], rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 8])
+def test_knn_width(rt, orc, traced, k):
+    tg = traced(16, 0.02)
+    rt.segmentize(tg, k=k, check=False)
+    _same(tg, _oracle(orc, tg, k=k))
+
+
+@pytest.mark.parametrize("tiny", [1e-7, 1e-9])
+def test_tiny_step(rt, orc, pincell, tiny):
+    tg = rt.TrackGenerator(pincell, 8, 0.03, tiny_step=tiny)
+    rt.trace(tg)
+    rt.segmentize(tg, check=False)
+    _same(tg, _oracle(orc, tg))
+
+
+def test_rtol_controls_length_check(rt, orc, pincell):
+    tg = rt.TrackGenerator(pincell, 8, 0.05)
+    rt.trace(tg)
+    tg.ell = tg.ell.copy()
+    tg.ell[7] *= 1.0 + 1e-6
+    with pytest.raises(RuntimeError, match="Track with `uid` 8 has a length"):
+        rt.segmentize(tg)
+    rt.segmentize(tg, rtol=1e-5)
+    rt.segmentize(tg, check=False)
+    assert tg.track_status[7] == 2 and np.count_nonzero(tg.track_status) == 1
+
+
+def test_shifted_anisotropic_domain(rt, orc, pincell):
+    xy = pincell.node_coordinates * np.array([1.7, 0.6]) + np.array([3.25, -2.5])
+    model = rt.DiscreteModel(xy, pincell.cell_node_ids)
+    tg = rt.TrackGenerator(model, 16, 0.02)
+    rt.trace(tg)
+    rt.segmentize(tg, check=False)
+    ref = _oracle(orc, tg)
+    _same(tg, ref)
+    assert abs(tg.volumes.sum() - tg.mesh.width() * tg.mesh.height()) < 1e-9
+
+
+@pytest.mark.parametrize("n_azim,delta,flip", [(4, 0.25, False), (4, 0.5, True), (8, 0.13, False), (16, 0.07, True),
+                                               (4, 0.8, False), (4, 0.8, True), (8, 0.8, False)])
+def test_structured_grid_vertex_and_edge_grazing(rt, orc, grid_model, n_azim, delta, flip):
+    """Right-triangle grid: 45-degree tracks run along diagonals and through vertices, so the
+    n_int ∈ {0,1,3}, parallel-edge and vertex-skip branches of the reference all fire.  Whatever
+    the reference's procedure does (including failing a track), the device must do the same."""
+    model = grid_model(8, 8, hx=0.5, hy=0.5, flip=flip)
+    tg = rt.TrackGenerator(model, n_azim, delta)
+    rt.trace(tg)
+    rt.segmentize(tg, check=False)
+    ref = _oracle(orc, tg)
+    _same(tg, ref, check_volumes=False)
+    ok = ref["status"] == 0
+    print(f"grid nφ={n_azim} δ={delta} flip={flip}: {ok.sum()}/{len(ok)} tracks ok, {ref['total']} segments")
+
+
+def test_single_track_and_empty_batch(rt, orc, traced):
+    from raytracing_jl_amd import _capi
+
+    tg = traced(8, 0.02)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    aq = tg.azimuthal_quadrature
+    one = _capi.DeviceTracks(dm, tg.px[:1], tg.py[:1], tg.phi[:1], tg.cos_phi[:1], tg.sin_phi[:1], tg.A[:1], tg.B[:1],
+                             tg.C[:1], tg.ell[:1], tg.azim_idx[:1])
+    n = one.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    om = orc.OracleMesh.from_mesh(tg.mesh)
+    ref = om.segmentize(tg.px[:1], tg.py[:1], tg.phi[:1], tg.A[:1], tg.B[:1], tg.C[:1], tg.ell[:1])
+    assert n == ref["total"] and np.array_equal(one.fetch_segments()["element"], ref["element"])
+    empty = _capi.DeviceTracks(dm, *([np.zeros(0)] * 9), np.zeros(0, np.int32))
+    assert empty.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == 0
+    off, st = empty.fetch_offsets()
+    assert off.tolist() == [0] and len(st) == 0
+    assert np.all(empty.fetch_volumes() == 0)
+
+
+@pytest.mark.parametrize("opts", [dict(single_pass=0), dict(single_pass=0, volumes_mode=1), dict(walk=0),
+                                  dict(sort_mode=0), dict(sort_mode=1)])
+def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    for k, v in opts.items():
+        dm.set_option(k, v)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    off, st = dt.fetch_offsets()
+    s = dt.fetch_segments()
+    assert np.array_equal(off, ref["offsets"]) and st.max() == 0
+    assert np.array_equal(s["element"], ref["element"])
+    for k in FIELDS:
+        assert np.array_equal(s[k], ref[k]), k
+    assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
+
+
+def test_staging_pool_overflow_is_recovered(rt, traced, oracle_run):
+    """Force the first pool to be far too small: the call must grow it and re-run."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("pool_chunks_hint", 8)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    assert np.array_equal(dt.fetch_segments()["element"], ref["element"])
