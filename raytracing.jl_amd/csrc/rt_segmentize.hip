@@ -532,14 +532,17 @@ struct rt_tracks {
     bool segmentized = false;
     int64_t total = 0;
     DevBuf<int32_t> counts, status, element;
-    DevBuf<int64_t> offsets, tile_sums, scalars;  // scalars[0] = total
-    DevBuf<unsigned long long> fail_info;         // [0] n_failed, [1] first failing uid
+    DevBuf<int64_t> offsets, tile_sums;
+    // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag
+    DevBuf<unsigned long long> ctl;
+    unsigned long long *h_ctl = nullptr;  // pinned: [0..31] init image, [32..63] read-back
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy, gell;
-    DevBuf<int32_t> gelement, ctab, cowner, cursor;
+    DevBuf<int32_t> gelement, ctab, cowner;
     int64_t pool_chunks = 0, chunks_needed_last = 0;
     double sum_ell = 0.0;
+    std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     hipEvent_t ev[8] = {};
     double ms[8] = {};
     int64_t n_failed = 0, first_failed_uid = 0;
@@ -625,11 +628,12 @@ void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
-    t->tile_sums.release(); t->scalars.release(); t->fail_info.release();
+    t->tile_sums.release(); t->ctl.release();
+    if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->delta_s.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release(); t->gell.release();
-    t->gelement.release(); t->ctab.release(); t->cowner.release(); t->cursor.release();
+    t->gelement.release(); t->ctab.release(); t->cowner.release();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     delete t;
@@ -817,11 +821,21 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     RT_HIP(t->status.reserve(n + 1));
     RT_HIP(t->offsets.reserve(n + 1));
     RT_HIP(t->tile_sums.reserve(n_tiles + 1));
-    RT_HIP(t->scalars.reserve(4));
-    RT_HIP(t->fail_info.reserve(16));
-    RT_HIP(t->cursor.reserve(4));
+    RT_HIP(t->ctl.reserve(32));
+    if (!t->h_ctl) {
+        RT_HIP(hipHostMalloc((void **)&t->h_ctl, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+        for (int i = 0; i < 64; ++i) t->h_ctl[i] = 0;
+        t->h_ctl[1] = ~0ull;  // first failing uid: atomicMin target
+    }
+    unsigned long long *const d_fail = t->ctl.p;
+    int64_t *const d_total = reinterpret_cast<int64_t *>(t->ctl.p + 16);
+    int32_t *const d_cursor = reinterpret_cast<int32_t *>(t->ctl.p + 18);
+    unsigned long long *const h_res = t->h_ctl + 32;
     RT_HIP(t->volumes.reserve(m->n_cells));
-    if (int rc = upload(t->delta_s, delta_s, (size_t)n_azim_2, s)) return rc;
+    if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
+        t->h_delta_s.assign(delta_s, delta_s + n_azim_2);
+        if (int rc = upload(t->delta_s, t->h_delta_s.data(), (size_t)n_azim_2, s)) return rc;
+    }
 
     rt::DOut out{};
     using rt::as_global;
@@ -838,11 +852,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         if (n > 0) {
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p);
-            hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, t->scalars.p);
+            hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, d_total);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
-                               t->tile_sums.p, t->scalars.p, t->offsets.p);
+                               t->tile_sums.p, d_total, t->offsets.p);
         } else {
-            RT_HIP(hipMemsetAsync(t->scalars.p, 0, sizeof(int64_t), s));
+            RT_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
             RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
         }
         return RT_SUCCESS;
@@ -871,13 +885,12 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             hipLaunchKernelGGL(rt::k_volumes, dim3((unsigned)nb), dim3(1024), shmem, s, (const int64_t *)t->offsets.p, n,
                                (const int32_t *)t->azim.p, (const double *)t->delta_s.p, (const int32_t *)t->element.p,
                                (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds,
-                               m->single_pass ? (const int32_t *)(t->cursor.p + 1) : (const int32_t *)nullptr);
+                               m->single_pass ? (const int32_t *)(d_cursor + 1) : (const int32_t *)nullptr);
         }
         hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
                            m->n_cells, (double)n_azim_2);
         return RT_SUCCESS;
     };
-    const unsigned long long fi0[16] = {0ull, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     RT_HIP(hipEventRecord(t->ev[0], s));
     RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
@@ -902,15 +915,14 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (int rc = reserve_out(t->pool_chunks * rt::kChunkRows * 64)) return rc;
             stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
             stg.qy = as_global(t->gqy.p); stg.ell = as_global(t->gell.p); stg.element = as_global(t->gelement.p);
-            stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(t->cursor.p);
+            stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
-            RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
-            RT_HIP(hipMemsetAsync(t->cursor.p, 0, 4 * sizeof(int32_t), s));
+            RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
             RT_HIP(hipEventRecord(t->ev[1], s));
             if (n > 0)
                 hipLaunchKernelGGL(rt::k_march<rt::kStage>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
-                                   t->status.p, (const int64_t *)nullptr, out, stg, t->fail_info.p);
+                                   t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
             RT_HIP(hipEventRecord(t->ev[2], s));
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
@@ -922,32 +934,34 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (int rc = launch_volumes()) return rc;
             RT_HIP(hipEventRecord(t->ev[6], s));
             int32_t cur[4] = {0, 0, 0, 0};
-            RT_HIP(hipMemcpyAsync(&total, t->scalars.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            RT_HIP(hipMemcpyAsync(fi, t->fail_info.p, sizeof(fi), hipMemcpyDeviceToHost, s));
-            RT_HIP(hipMemcpyAsync(cur, t->cursor.p, sizeof(cur), hipMemcpyDeviceToHost, s));
+            RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             RT_HIP(hipStreamSynchronize(s));
+            memcpy(fi, h_res, sizeof(fi));
+            memcpy(&total, h_res + 16, sizeof(total));
+            memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
             if (!cur[1]) break;
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
         }
     } else {
-        RT_HIP(hipMemcpyAsync(t->fail_info.p, fi0, sizeof(fi0), hipMemcpyHostToDevice, s));
+        RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         RT_HIP(hipEventRecord(t->ev[1], s));
         if (n > 0)
             hipLaunchKernelGGL(rt::k_march<rt::kCount>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
-                               t->status.p, (const int64_t *)nullptr, out, stg, t->fail_info.p);
+                               t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
         RT_HIP(hipEventRecord(t->ev[2], s));
         if (int rc = scan_counts()) return rc;
         RT_HIP(hipEventRecord(t->ev[3], s));
-        RT_HIP(hipMemcpyAsync(&total, t->scalars.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        RT_HIP(hipMemcpyAsync(fi, t->fail_info.p, sizeof(fi), hipMemcpyDeviceToHost, s));
+        RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RT_HIP(hipStreamSynchronize(s));
+        memcpy(fi, h_res, sizeof(fi));
+        memcpy(&total, h_res + 16, sizeof(total));
         if (int rc = reserve_out(total)) return rc;
         RT_HIP(hipEventRecord(t->ev[4], s));
         if (n > 0)
             hipLaunchKernelGGL(rt::k_march<rt::kFill>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
-                               t->status.p, (const int64_t *)t->offsets.p, out, stg, t->fail_info.p);
+                               t->status.p, (const int64_t *)t->offsets.p, out, stg, d_fail);
         RT_HIP(hipEventRecord(t->ev[5], s));
         if (int rc = launch_volumes()) return rc;
         RT_HIP(hipEventRecord(t->ev[6], s));
