@@ -131,6 +131,42 @@ int32_t rt_device_pointers(rt_tracks *tracks, void **ptrs_dev);
  */
 int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
 
+/* ---------------------------------------------------------------------------------------
+ * Host-side rows around the hot path: they run on the CPU, like in the
+ * reference, but natively — no Julia or Python needed to produce the device path's inputs.
+ * --------------------------------------------------------------------------------------- */
+
+/* TrackGenerator ctor, src/trackgenerator.jl:96-110 (+ argument checks of AzimuthalQuadrature,
+ * src/azimuthal_quad.jl:21-25): per-angle track counts n_tracks_x / n_tracks_y [n_azim/2] for a
+ * width x height domain.  Returns n_total_tracks, or RT_ERR_INVALID (DomainError text in
+ * rt_last_error). */
+int64_t rt_trace_counts(double width, double height, int32_t n_azim, double delta, int64_t *n_tracks_x,
+                        int64_t *n_tracks_y);
+
+/* trace!(t) + next_tracks, src/trackgenerator.jl:134-348.  bb = bb_min.x, bb_min.y, bb_max.x,
+ * bb_max.y; bcs = {top, bottom, right, left} with 0 Vacuum, 1 Reflective, 2 Periodic
+ * (src/boundary.jl:12-16).  Per-angle outputs [n_azim/2]: phis (ϕs), delta_s (δs), omega (ωₐ).
+ * Per-track outputs in uid order [n_total_tracks]: azim_idx, track_idx (1-based), p, q, ϕ, cos ϕ,
+ * sin ϕ, ℓ, ABC, bc_fwd / bc_bwd, dir_next_track_fwd / _bwd (0 Forward, 1 Backward), and the
+ * 1-based uids of next_track_fwd / next_track_bwd.  Errors reproduce the reference's:
+ * DomainError("could not found track exit point."), "Boundaries do not match!". */
+int32_t rt_trace(const double *bb, int32_t n_azim, const int64_t *n_tracks_x, const int64_t *n_tracks_y,
+                 const int32_t *bcs, double *phis, double *delta_s, double *omega, int32_t *azim_idx,
+                 int32_t *track_idx, double *px, double *py, double *qx, double *qy, double *phi, double *cos_phi,
+                 double *sin_phi, double *ell, double *A, double *B, double *C, int8_t *bc_fwd, int8_t *bc_bwd,
+                 int8_t *dir_fwd, int8_t *dir_bwd, int64_t *next_fwd, int64_t *next_bwd);
+
+/* Mesh ingest, replaces GmshDiscreteModel + Mesh(model) (src/mesh.jl:24-69) for gmsh 4.1 ASCII
+ * files: node coordinates, cell->nodes (1-based, ascending per cell as Gridap's oriented grid
+ * stores them), node->cells CSR (0-based ptrs, 1-based ascending cell ids) and the bounding box —
+ * exactly the arrays rt_mesh_create takes.  Returns NULL on failure. */
+typedef struct rt_msh rt_msh;
+rt_msh *rt_msh_load(const char *path);
+int32_t rt_msh_sizes(rt_msh *msh, int32_t *n_nodes, int32_t *n_cells, int32_t *nnz);
+int32_t rt_msh_fetch(rt_msh *msh, double *x, double *y, int32_t *cell_nodes, int32_t *node_cells_ptrs,
+                     int32_t *node_cells_data, double *bb);
+void rt_msh_free(rt_msh *msh);
+
 /* Tunables (name/value); unknown names return RT_ERR_INVALID.  See DESIGN.md. */
 int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value);
 

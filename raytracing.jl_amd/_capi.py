@@ -20,6 +20,7 @@ SYMBOLS = (
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option",
+    "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
 )
 
 RT_TRACK_OK = 0
@@ -91,6 +92,18 @@ def lib():
     L.rt_last_timing.argtypes = [_vp, _dp, C.c_int32]
     L.rt_set_option.restype = C.c_int32
     L.rt_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
+    _bp = C.POINTER(C.c_int8)
+    L.rt_trace_counts.restype = C.c_int64
+    L.rt_trace_counts.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_double, _lp, _lp]
+    L.rt_trace.restype = C.c_int32
+    L.rt_trace.argtypes = [_dp, C.c_int32, _lp, _lp, _ip, _dp, _dp, _dp, _ip, _ip] + [_dp] * 11 + [_bp] * 4 + [_lp, _lp]
+    L.rt_msh_load.restype = _vp
+    L.rt_msh_load.argtypes = [C.c_char_p]
+    L.rt_msh_sizes.restype = C.c_int32
+    L.rt_msh_sizes.argtypes = [_vp, _ip, _ip, _ip]
+    L.rt_msh_fetch.restype = C.c_int32
+    L.rt_msh_fetch.argtypes = [_vp, _dp, _dp, _ip, _ip, _ip, _dp]
+    L.rt_msh_free.argtypes = [_vp]
     if L.rt_abi_version() != 1:
         raise RtError("librt_segmentize.so: ABI version mismatch")
     _lib = L
@@ -233,3 +246,62 @@ def status_message(status: int, uid: int = 0) -> str:
 
 def device_count() -> int:
     return int(lib().rt_device_count())
+
+
+# ---- native host rows (CPU only; they work without a GPU) ---------------------------------
+
+def native_trace_counts(width: float, height: float, n_azim: int, delta: float):
+    n2 = max(n_azim // 2, 1)
+    ntx = np.zeros(n2, np.int64)
+    nty = np.zeros(n2, np.int64)
+    total = lib().rt_trace_counts(width, height, n_azim, delta, ntx.ctypes.data_as(_lp), nty.ctypes.data_as(_lp))
+    if total < 0:
+        raise ValueError(last_error())
+    return int(total), ntx[: n_azim // 2], nty[: n_azim // 2]
+
+
+def native_trace(bb, n_azim: int, ntx, nty, bcs):
+    """``rt_trace``: dict of per-angle and per-track arrays (uid order)."""
+    n2 = n_azim // 2
+    ntx = np.ascontiguousarray(ntx, np.int64)
+    nty = np.ascontiguousarray(nty, np.int64)
+    total = int((ntx + nty).sum())
+    f = lambda n=total: np.zeros(n, np.float64)
+    out = dict(phis=f(n2), delta_s=f(n2), omega=f(n2), azim_idx=np.zeros(total, np.int32),
+               track_idx=np.zeros(total, np.int32), px=f(), py=f(), qx=f(), qy=f(), phi=f(), cos_phi=f(), sin_phi=f(),
+               ell=f(), A=f(), B=f(), C=f(), bc_fwd=np.zeros(total, np.int8), bc_bwd=np.zeros(total, np.int8),
+               dir_fwd=np.zeros(total, np.int8), dir_bwd=np.zeros(total, np.int8),
+               next_fwd=np.zeros(total, np.int64), next_bwd=np.zeros(total, np.int64))
+    bb_a, bbp = _f64(bb)
+    bc_a, bcp = _i32(bcs)
+    d = lambda k: out[k].ctypes.data_as(_dp)
+    b = lambda k: out[k].ctypes.data_as(C.POINTER(C.c_int8))
+    rc = lib().rt_trace(bbp, n_azim, ntx.ctypes.data_as(_lp), nty.ctypes.data_as(_lp), bcp, d("phis"), d("delta_s"),
+                        d("omega"), out["azim_idx"].ctypes.data_as(_ip), out["track_idx"].ctypes.data_as(_ip),
+                        d("px"), d("py"), d("qx"), d("qy"), d("phi"), d("cos_phi"), d("sin_phi"), d("ell"), d("A"),
+                        d("B"), d("C"), b("bc_fwd"), b("bc_bwd"), b("dir_fwd"), b("dir_bwd"),
+                        out["next_fwd"].ctypes.data_as(_lp), out["next_bwd"].ctypes.data_as(_lp))
+    if rc != 0:
+        msg = last_error()
+        raise (ValueError if "DomainError" in msg else RuntimeError)(msg)
+    return out
+
+
+def native_load_msh(path: str):
+    """``rt_msh_load``: (x, y, cell_nodes[n,3], nc_ptrs, nc_data, bb) straight from a gmsh 4.1 file."""
+    L = lib()
+    h = L.rt_msh_load(os.fsencode(path))
+    if not h:
+        raise RtError(last_error())
+    try:
+        nn, nc, nnz = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(L.rt_msh_sizes(h, C.byref(nn), C.byref(nc), C.byref(nnz)))
+        x, y = np.zeros(nn.value), np.zeros(nn.value)
+        cells = np.zeros(3 * nc.value, np.int32)
+        ptrs, data = np.zeros(nn.value + 1, np.int32), np.zeros(nnz.value, np.int32)
+        bb = np.zeros(4)
+        _check(L.rt_msh_fetch(h, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), cells.ctypes.data_as(_ip),
+                              ptrs.ctypes.data_as(_ip), data.ctypes.data_as(_ip), bb.ctypes.data_as(_dp)))
+    finally:
+        L.rt_msh_free(h)
+    return x, y, cells.reshape(-1, 3), ptrs, data, bb

@@ -24,11 +24,10 @@
 #include "rt_device.hpp"
 #include "rt_mesh_prep.hpp"
 
-namespace {
-
+namespace rthost {
 thread_local std::string g_last_error;
 
-void set_error(const char *fmt, ...) {
+void set_error(const char *fmt, ...) {  // shared with rt_host.cpp
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -36,6 +35,11 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
     g_last_error = buf;
 }
+}  // namespace rthost
+using rthost::g_last_error;
+using rthost::set_error;
+
+namespace {
 
 #define RT_HIP(call)                                                                          \
     do {                                                                                      \

@@ -148,6 +148,20 @@ def GmshDiscreteModel(mshfile: str, renumber: bool = True) -> DiscreteModel:
 class Mesh:
     """Flattened mesh for the segmentize! path (mirrors ``Mesh(model)``, ``src/mesh.jl:24-31``)."""
 
+    @classmethod
+    def from_msh(cls, mshfile: str) -> "Mesh":
+        """Native ingest (``rt_msh_load`` of the C-ABI library): gmsh 4.1 ASCII straight to the
+        flat arrays, without going through the Python parser."""
+        from . import _capi
+
+        x, y, cells, ptrs, data, bb = _capi.native_load_msh(mshfile)
+        m = cls.__new__(cls)
+        m.model = DiscreteModel(np.column_stack((x, y)), cells)
+        m.x, m.y, m.cell_nodes = x, y, cells
+        m.node_cells_ptrs, m.node_cells_data = ptrs, data
+        m.bb_min, m.bb_max = (float(bb[0]), float(bb[1])), (float(bb[2]), float(bb[3]))
+        return m
+
     def __init__(self, model: DiscreteModel):
         self.model = model
         xy = model.node_coordinates

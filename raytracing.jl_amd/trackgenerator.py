@@ -118,8 +118,16 @@ def _boundary_condition(x, sides, bcs):
     return out
 
 
-def trace(t: TrackGenerator) -> TrackGenerator:
-    """``trace!(t)`` (``src/trackgenerator.jl:134-280``) + ``next_tracks`` (``:282-348``)."""
+def trace(t: TrackGenerator, backend: str = "native") -> TrackGenerator:
+    """``trace!(t)`` (``src/trackgenerator.jl:134-280``) + ``next_tracks`` (``:282-348``).
+
+    ``backend="native"`` runs ``rt_trace`` of the C-ABI library (host C++, works without a GPU);
+    ``backend="numpy"`` is the vectorised Python restatement below.  Both give bit-identical
+    arrays (``tests/test_native_host.py``)."""
+    if backend == "native":
+        return _trace_native(t)
+    if backend != "numpy":
+        raise ValueError("backend must be 'native' or 'numpy'")
     mesh, bcs, aq = t.mesh, t.bcs, t.azimuthal_quadrature
     n2, n4 = aq.n_azim_2, aq.n_azim_4
     ntx, nty, nt = t.n_tracks_x, t.n_tracks_y, t.n_tracks
@@ -228,6 +236,27 @@ def trace(t: TrackGenerator) -> TrackGenerator:
     t.dir_next_bwd = dirb.astype(np.int8)
     t.next_fwd_uid = nf.astype(np.int64)
     t.next_bwd_uid = nb.astype(np.int64)
+    t.segments = None
+    t.traced = True
+    return t
+
+
+def _trace_native(t: TrackGenerator) -> TrackGenerator:
+    from . import _capi
+
+    bcs, aq = t.bcs, t.azimuthal_quadrature
+    o = _capi.native_trace(t.mesh.bb, aq.n_azim, t.n_tracks_x, t.n_tracks_y,
+                           (int(bcs.top), int(bcs.bottom), int(bcs.right), int(bcs.left)))
+    aq.phis[:] = o["phis"]
+    aq.delta_s[:] = o["delta_s"]
+    aq.omega_a[:] = o["omega"]
+    t.azim_idx, t.track_idx = o["azim_idx"], o["track_idx"]
+    t.px, t.py, t.qx, t.qy = o["px"], o["py"], o["qx"], o["qy"]
+    t.phi, t.cos_phi, t.sin_phi, t.ell = o["phi"], o["cos_phi"], o["sin_phi"], o["ell"]
+    t.A, t.B, t.C = o["A"], o["B"], o["C"]
+    t.bc_fwd, t.bc_bwd = o["bc_fwd"], o["bc_bwd"]
+    t.dir_next_fwd, t.dir_next_bwd = o["dir_fwd"], o["dir_bwd"]
+    t.next_fwd_uid, t.next_bwd_uid = o["next_fwd"], o["next_bwd"]
     t.segments = None
     t.traced = True
     return t

@@ -1,0 +1,102 @@
+"""Native host rows of the C-ABI library: rt_trace_counts / rt_trace against the
+reference's known answers, the oracle's restatement and the numpy mirror; rt_msh_load against the
+Python loader.  CPU only — these entry points do not need a GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
+BC = {"Vacuum": 0, "Reflective": 1, "Periodic": 2}
+DIR = {"Forward": 0, "Backward": 1}
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from raytracing_jl_amd import _capi
+
+    _capi.build()
+    return _capi
+
+
+def test_counts_known_answers(capi):  # test/runtests.jl:14-19
+    k = KATS["main"]
+    total, ntx, nty = capi.native_trace_counts(1.6, 1.6, k["n_azim"], k["delta"])
+    assert total == k["n_total_tracks"]
+    assert ntx.tolist() == k["n_tracks_x"] and nty.tolist() == k["n_tracks_y"]
+    for bad in ((0, 0.1), (6, 0.1), (8, 0.0)):
+        with pytest.raises(ValueError, match="DomainError"):
+            capi.native_trace_counts(1.6, 1.6, *bad)
+
+
+@pytest.mark.parametrize("n_azim,delta", [(8, 0.02), (32, 5e-3), (4, 0.8), (128, 1e-3)])
+def test_native_numpy_and_oracle_agree_bitwise(rt, orc, pincell, n_azim, delta):
+    a = rt.TrackGenerator(pincell, n_azim, delta)
+    b = rt.TrackGenerator(pincell, n_azim, delta)
+    rt.trace(a, backend="native")
+    rt.trace(b, backend="numpy")
+    o = orc.trace(a.mesh.bb, n_azim, delta)
+    for name in ("px", "py", "qx", "qy", "phi", "cos_phi", "sin_phi", "ell", "A", "B", "C", "azim_idx", "track_idx",
+                 "bc_fwd", "bc_bwd", "dir_next_fwd", "dir_next_bwd", "next_fwd_uid", "next_bwd_uid"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    for no, na in (("px", "px"), ("qy", "qy"), ("ell", "ell"), ("A", "A"), ("C", "C"), ("next_fwd", "next_fwd_uid")):
+        assert np.array_equal(o[no], getattr(a, na)), no
+    for name in ("phis", "delta_s", "omega_a"):
+        assert np.array_equal(getattr(a.azimuthal_quadrature, name), getattr(b.azimuthal_quadrature, name))
+
+
+def test_quadrature_known_answers(rt, pincell):  # test/runtests.jl:21-28
+    k = KATS["main"]
+    tg = rt.TrackGenerator(pincell, k["n_azim"], k["delta"])
+    rt.trace(tg)
+    aq = tg.azimuthal_quadrature
+    assert np.allclose(aq.delta_s, k["delta_s"], rtol=1.5e-8, atol=0)
+    assert np.allclose(aq.phis, k["phis"], rtol=1.5e-8, atol=0)
+
+
+@pytest.mark.parametrize("case", KATS["reflection"], ids=lambda c: "nphi%d" % c["n_azim"])
+def test_reflection_linking_native(rt, pincell, case):  # test/runtests.jl:46-334
+    b = case["bcs"]
+    bcs = rt.BoundaryConditions(**{side: getattr(rt, b[side]) for side in ("top", "bottom", "left", "right")})
+    tg = rt.TrackGenerator(pincell, case["n_azim"], case["delta"], bcs=bcs)
+    rt.trace(tg, backend="native")
+    for k in case["tracks"]:
+        u = k["uid"] - 1
+        assert tg.bc_fwd[u] == BC[k["bc_fwd"]] and tg.bc_bwd[u] == BC[k["bc_bwd"]]
+        assert tg.next_fwd_uid[u] == k["next_fwd_uid"] and tg.next_bwd_uid[u] == k["next_bwd_uid"]
+        assert tg.dir_next_fwd[u] == DIR[k["dir_fwd"]] and tg.dir_next_bwd[u] == DIR[k["dir_bwd"]]
+
+
+@pytest.mark.parametrize("bcs_kw", [dict(top="Periodic", bottom="Periodic", left="Periodic", right="Periodic"),
+                                    dict(top="Vacuum", bottom="Reflective", left="Periodic", right="Periodic")])
+def test_periodic_linking_matches_numpy(rt, pincell, bcs_kw):
+    bcs = rt.BoundaryConditions(**{k: getattr(rt, v) for k, v in bcs_kw.items()})
+    a = rt.TrackGenerator(pincell, 8, 0.1, bcs=bcs)
+    b = rt.TrackGenerator(pincell, 8, 0.1, bcs=bcs)
+    rt.trace(a, backend="native")
+    rt.trace(b, backend="numpy")
+    for name in ("next_fwd_uid", "next_bwd_uid", "dir_next_fwd", "dir_next_bwd", "bc_fwd", "bc_bwd"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("name", ["pincell.msh", "bwr_like.msh"])
+def test_native_msh_ingest_matches_python_loader(rt, name):
+    path = rt.data_path(name)
+    py = rt.Mesh(rt.GmshDiscreteModel(path))
+    nat = rt.Mesh.from_msh(path)
+    assert np.array_equal(py.x, nat.x) and np.array_equal(py.y, nat.y)
+    assert np.array_equal(py.cell_nodes, nat.cell_nodes)
+    assert np.array_equal(py.node_cells_ptrs, nat.node_cells_ptrs)
+    assert np.array_equal(py.node_cells_data, nat.node_cells_data)
+    assert py.bb_min == nat.bb_min and py.bb_max == nat.bb_max
+
+
+def test_native_msh_errors(capi, tmp_path):
+    with pytest.raises(capi.RtError, match="cannot open"):
+        capi.native_load_msh(str(tmp_path / "missing.msh"))
+    bad = tmp_path / "bad.msh"
+    bad.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n")
+    with pytest.raises(capi.RtError, match="4.1"):
+        capi.native_load_msh(str(bad))
