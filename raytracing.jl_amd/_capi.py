@@ -45,6 +45,27 @@ def build(force: bool = False, extra: str = "") -> str:
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch's ROCm wheels bundle their own ``libamdhip64.so`` (same SONAME as ROCm's).  Two
+    copies of the HIP runtime in one process cannot both see the GPU: whichever initialises second
+    reports "No HIP GPUs are available".  If torch is installed, load its copy first — this
+    library then binds to it by SONAME, and a later ``import torch`` finds it already loaded."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 _lib = None
 _vp = C.c_void_p
 _dp = C.POINTER(C.c_double)
@@ -60,6 +81,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback for segmentize)")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     L.rt_abi_version.restype = C.c_int32
     L.rt_last_error.restype = C.c_char_p

@@ -87,3 +87,33 @@ def test_idempotent(rt, traced):
     rt.segmentize(tg)
     for k, v in a.items():
         assert np.array_equal(v, getattr(tg.segments, k))
+
+
+def test_device_resident_results_as_torch_tensors(rt, traced, oracle_run):
+    """Consumers that stay on the GPU (and the RCCL path of bench.py) read the results through
+    rt_device_pointers; torch wraps them zero-copy via __cuda_array_interface__."""
+    import torch
+
+    from raytracing_jl_amd import distributed as rtd
+
+    tg = traced(8, 2e-2)
+    rt.segmentize(tg, fetch=False)
+    dt = tg.device_tracks
+    ref = oracle_run(tg)
+    p = dt.device_pointers()
+    dev = torch.device("cuda", 0)
+    n = dt.total
+    off = torch.as_tensor(rtd.DevArray(p["offsets"], dt.n + 1, "<i8", dt), device=dev)
+    el = torch.as_tensor(rtd.DevArray(p["element"], n, "<i4", dt), device=dev)
+    ell = torch.as_tensor(rtd.DevArray(p["ell"], n, "<f8", dt), device=dev)
+    vol = torch.as_tensor(rtd.DevArray(p["volumes"], dt.dmesh.n_cells, "<f8", dt), device=dev)
+    assert np.array_equal(off.cpu().numpy(), ref["offsets"])
+    assert np.array_equal(el.cpu().numpy(), ref["element"])
+    assert np.array_equal(ell.cpu().numpy(), ref["ell"])
+    assert np.allclose(vol.cpu().numpy(), ref["volumes"], rtol=1e-10, atol=0)
+    local = {"counts": off[1:] - off[:-1], "element": el, "ell": ell}
+    for name in ("px", "py", "qx", "qy"):
+        local[name] = torch.as_tensor(rtd.DevArray(p[name], n, "<f8", dt), device=dev)
+    g = rtd.allgather_segments(local)  # world size 1: identity + offsets
+    assert np.array_equal(g["offsets"].cpu().numpy(), ref["offsets"])
+    rtd.allreduce_volumes(vol)  # no-op without a process group
