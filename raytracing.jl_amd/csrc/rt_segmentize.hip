@@ -107,23 +107,33 @@ struct DStage {
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
 
-// One lane marches one track (_segmentize_track!, src/track.jl:106-178); one wave per
-// workgroup.  kStage: single pass, records go to the wave-interleaved staging pool (then
-// k_compact).  kCount / kFill: the two-pass variant (count, scan, re-march writing at the CSR
-// offsets).  All modes set counts[] / status[] identically.
-template <int MODE>
-__global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
-                                              int32_t *__restrict__ status,
-                                              const int64_t *__restrict__ offsets, DOut out, DStage stg,
-                                              unsigned long long *__restrict__ fail_info) {
-    __shared__ volatile int32_t chunk_lds[MODE == kStage ? kMaxChunks : 1];
-    const int lane = threadIdx.x;
+// One lane marches one track (_segmentize_track!, src/track.jl:106-178).  kStage: single pass,
+// records go to the wave-interleaved staging pool (then k_compact).  kCount / kFill: the
+// two-pass variant (count, scan, re-march writing at the CSR offsets).  All modes set counts[] /
+// status[] identically.  WAVES = 1: one wave per workgroup.  WAVES = 4 (kStage only): four
+// consecutive waves share one workgroup and an LDS-private copy of `volumes`, so fill_volumes
+// (src/trackgenerator.jl:371-386) is fused into the march as ds_add_f64 + one coalesced flush.
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
+                                                      int32_t *__restrict__ status,
+                                                      const int64_t *__restrict__ offsets, DOut out, DStage stg,
+                                                      unsigned long long *__restrict__ fail_info) {
+    constexpr bool FUSE = WAVES > 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
+    double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    volatile int32_t *chunk_lds = reinterpret_cast<volatile int32_t *>(march_smem + (FUSE ? (size_t)m.n_cells * sizeof(double) : 0)) +
+                                  wib * kMaxChunks;
     if (MODE == kStage) {
         for (int c = lane; c < kMaxChunks; c += 64) chunk_lds[c] = -1;
+        if (FUSE)
+            for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) hist[c] = 0.0;
         __syncthreads();
     }
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= t.n) return;
+    const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wib;
+    const int64_t slot = wave_id * 64 + lane;
+    if (slot < t.n) {
     const int32_t u = t.perm[slot];
     const double tA = t.A[u], tB = t.B[u], tC = t.C[u];
     const double phi = t.phi[u];
@@ -133,10 +143,8 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
     double xpx = t.px[u] + sx, xpy = t.py[u] + sy;  // src/track.jl:114
     int64_t base = 0;
     double w = 0.0;
-    if (MODE == kFill) {
-        base = offsets[u];
-        w = out.delta_s[t.azim[u] - 1];
-    }
+    if (MODE == kFill) base = offsets[u];
+    if (MODE == kFill || FUSE) w = out.delta_s[t.azim[u] - 1];
     int32_t my_chunk = -1;
     int i = 0;
     int32_t it = 0;
@@ -252,8 +260,8 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
                             c = atomicAdd((int32_t *)&stg.cursor[0], 1);
                             if (c >= stg.pool_chunks) { c = -2; stg.cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
                             else {
-                                stg.ctab[(int64_t)blockIdx.x * kMaxChunks + jL] = c;
-                                stg.cowner[c] = (int32_t)(blockIdx.x * kMaxChunks + jL);
+                                stg.ctab[wave_id * kMaxChunks + jL] = c;
+                                stg.cowner[c] = (int32_t)(wave_id * kMaxChunks + jL);
                             }
                             chunk_lds[jL] = c;
                         }
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
                 stg.ell[o] = ell;
                 stg.element[o] = element + 1;
             }
+            if (FUSE) atomicAdd(&hist[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
         }
         if (MODE != kFill) sum_ell += ell;
         lqx = qx; lqy = qy;
@@ -293,6 +302,14 @@ __global__ __launch_bounds__(64) void k_march(DMesh m, DTracks t, DParams prm, i
         if (st != RT_TRACK_OK) {
             atomicAdd(&fail_info[0], 1ull);
             atomicMin(&fail_info[1], (unsigned long long)(u + 1));
+        }
+    }
+    }  // slot < t.n
+    if (FUSE) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) {
+            const double v = hist[c];
+            if (v != 0.0) unsafeAtomicAdd((double *)&out.volumes[c], v);
         }
     }
 }
@@ -520,6 +537,7 @@ struct rt_mesh {
     bool walk_available = false;
     int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
+    int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
@@ -735,6 +753,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "iter_cap")) { mesh->iter_cap = value > 0 ? value : 4000000; return RT_SUCCESS; }
     if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
@@ -874,8 +893,9 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         return RT_SUCCESS;
     };
     // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
+    bool fused_volumes_this_call = false;
     auto launch_volumes = [&]() -> int {
-        if (m->volumes_mode == 2 && n > 0) {
+        if (m->volumes_mode == 2 && n > 0 && !fused_volumes_this_call) {
             const int64_t want_blocks = 512;
             int32_t tpb = (int32_t)std::max<int64_t>(1, (n + want_blocks - 1) / want_blocks);
             tpb = std::min(tpb, 4096);
@@ -906,6 +926,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
                            : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * n_waves + 64;
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
+        // fill_volumes fused into the march when an LDS copy of `volumes` (+ 4 chunk tables) leaves room
+        // for two workgroups per CU; larger meshes use the separate k_volumes pass
+        const size_t fuse_smem = (size_t)m->n_cells * sizeof(double) + 4 * rt::kMaxChunks * sizeof(int32_t);
+        const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && fuse_smem <= 78 * 1024;
+        fused_volumes_this_call = fuse;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
                 const size_t slots = (size_t)want * rt::kChunkRows * 64;
@@ -924,9 +949,18 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
             RT_HIP(hipEventRecord(t->ev[1], s));
-            if (n > 0)
-                hipLaunchKernelGGL(rt::k_march<rt::kStage>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
-                                   t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
+            if (n > 0) {
+                if (fuse) {
+                    if (fuse_smem > 48 * 1024)
+                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 4>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), fuse_smem, s,
+                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
+                } else {
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 1>), dim3(grid), dim3(64), rt::kMaxChunks * sizeof(int32_t), s,
+                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
+                }
+            }
             RT_HIP(hipEventRecord(t->ev[2], s));
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
@@ -952,7 +986,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         RT_HIP(hipEventRecord(t->ev[1], s));
         if (n > 0)
-            hipLaunchKernelGGL(rt::k_march<rt::kCount>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
+            hipLaunchKernelGGL((rt::k_march<rt::kCount, 1>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
                                t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
         RT_HIP(hipEventRecord(t->ev[2], s));
         if (int rc = scan_counts()) return rc;
@@ -964,7 +998,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         if (int rc = reserve_out(total)) return rc;
         RT_HIP(hipEventRecord(t->ev[4], s));
         if (n > 0)
-            hipLaunchKernelGGL(rt::k_march<rt::kFill>, dim3(grid), dim3(64), 0, s, m->d, t->d, prm, t->counts.p,
+            hipLaunchKernelGGL((rt::k_march<rt::kFill, 1>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
                                t->status.p, (const int64_t *)t->offsets.p, out, stg, d_fail);
         RT_HIP(hipEventRecord(t->ev[5], s));
         if (int rc = launch_volumes()) return rc;
