@@ -358,6 +358,29 @@ __device__ __forceinline__ bool intersections(const DMesh &m, int32_t cell, doub
     return true;
 }
 
+// The generic step as ONE out-of-line function: its register demand (ring search, k-best list,
+// three edge intersections) then lives in the callee's frame instead of inflating the march
+// loop, which runs the walk step >98 % of the time.  Returns 0: segment (px..ell, element, eq)
+// produced; 1: the reference takes a `continue` branch (advance by tiny_step); 2: locate failed
+// (src/track.jl:140-143); 3: undefined intersection (src/intersection.jl:82-94).
+struct GenericOut {
+    double px, py, qx, qy, ell;
+    int32_t element, eq;
+};
+__device__ __noinline__ int generic_step(const DMesh &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
+                                         double tA, double tB, double tC, GenericOut &o) {
+    const int32_t element = find_element(m, xpx, xpy, k);  // src/track.jl:122 and :138-139
+    o.element = element;
+    if (element < 0) return 2;
+    if (element == prev_element) return 1;  // :147-150
+    int eq;
+    if (!intersections(m, element, phi, tA, tB, tC, o.px, o.py, o.qx, o.qy, eq)) return 3;  // :153
+    o.eq = eq;
+    if (isapprox_v2(o.px, o.py, o.qx, o.qy)) return 1;  // :156-159
+    o.ell = norm2(o.px - o.qx, o.py - o.qy);            // Segment ctor, src/segment.jl:31-33
+    return 0;
+}
+
 // ======================================================================= walk step ========
 // After a segment has been emitted in cell T with its exit point q on edge `ko`, the reference
 // re-seeds at xp = q + tiny_step·(cos ϕ, sin ϕ) and locates from scratch (src/track.jl:165,
@@ -426,9 +449,15 @@ __device__ __forceinline__ void load_next(const DMesh &m, int32_t pred, NextRec 
 // Written straight-line (all certificates are folded into one predicate; a lane without a
 // prediction reads record 0 and is masked out) except for the rare exact shallow-crossing test:
 // on a 64-wide wave, selects are cheaper than divergent early exits.
+#ifdef RT_SPECULATE
+__device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, NextRec &nr, int kk, double tA, double tB,
+                                         double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
+                                         double &qy, double &ell) {
+#else
 __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, double tA, double tB,
                                          double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
                                          double &qy, double &ell) {
+#endif
     const bool has = m.walk_ok && w.pred >= 0;
     const int32_t n1 = nr.n1, n2 = nr.n2, Tn = nr.cell, meta = nr.meta;
     const double dTn = nr.dT;
@@ -441,6 +470,12 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     const bool p0 = s0 > 0, p1 = s1 > 0, p2 = s2 > 0;
     ok = ok && (p0 != p1);
     const bool exit1 = p1 != p2;  // the line leaves through rotated edge 1 = (v1,v2), else edge 2 = (v2,v0)
+#ifdef RT_SPECULATE
+    // The successor record is known as soon as the exit edge is: fetch it now, under the divisions
+    // and the square root below, instead of at the top of the next iteration.
+    NextRec spec;
+    load_next(m, exit1 ? n1 : n2, spec);
+#endif
     // --- certificate 2: xp is inside T', at least eps_iso (barycentric) from edges 1 and 2
     const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     const double sg = area2 > 0 ? 1.0 : -1.0;
@@ -487,6 +522,9 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     w.bx = em ? (exit1 ? x2 : x0) : w.bx; w.by = em ? (exit1 ? y2 : y0) : w.by;
     w.cx = em ? (exit1 ? x0 : x1) : w.cx; w.cy = em ? (exit1 ? y0 : y1) : w.cy;
     w.pred = em ? (exit1 ? n1 : n2) : w.pred;
+#ifdef RT_SPECULATE
+    if (em) nr = spec;
+#endif
     return res;
 }
 

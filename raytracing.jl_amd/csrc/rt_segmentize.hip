@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         }
         double px, py, qx, qy, ell;
         int32_t element = -1;
-#ifndef RT_PREFETCH
+#if !defined(RT_PREFETCH) && !defined(RT_SPECULATE)
         load_next(m, wk.pred, nr);
 #endif
         const int res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         }
 #endif
         if (res == kWalkGeneric) {
+#ifndef RT_GENERIC_OUTOFLINE  // out-of-line generic step + RT_SPECULATE: -4 % (pincell) / +4 % (BWR-like); off
             element = find_element(m, xpx, xpy, prm.k);               // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
             if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
@@ -225,9 +226,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :156-159
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
+#else
+            GenericOut go;
+            const int rc = generic_step(m, xpx, xpy, prm.k, prev_element, phi, tA, tB, tC, go);
+            if (rc == 2) { st = RT_TRACK_LOCATE_FAILED; break; }
+            if (rc == 3) { st = RT_TRACK_UNDEF_INTERSECTION; break; }
+            if (rc == 1) { xpx = xpx + sx; xpy = xpy + sy; continue; }
+            element = go.element; px = go.px; py = go.py; qx = go.qx; qy = go.qy; ell = go.ell;
+            const int eq = go.eq;
+#endif
             if (m.walk_ok && eq >= 0) walk_enter(m, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
-#ifdef RT_PREFETCH
+#if defined(RT_PREFETCH) || defined(RT_SPECULATE)
             load_next(m, wk.pred, nr);
 #endif
         }
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
         RT_G double *dst = a == 0 ? out.px : a == 1 ? out.py : a == 2 ? out.qx : a == 3 ? out.qy : out.ell;
         double v[kChunkRows];
 #pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? src[s0 + r * 64] : 0.0;
+        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? __builtin_nontemporal_load(&src[s0 + r * 64]) : 0.0;
 #pragma unroll
         for (int r = 0; r < kChunkRows; ++r) tile[r * kTilePitch + lane] = v[r];
         __syncthreads();
@@ -367,13 +377,13 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
             const int tt = g * kTracksPerStore + tsub;
             const int32_t ct = __shfl(cnt, tt, 64);
             const int64_t ot = __shfl(off, tt, 64);
-            if (row < ct) dst[ot + row] = tile[r16 * kTilePitch + tt];
+            if (row < ct) __builtin_nontemporal_store(tile[r16 * kTilePitch + tt], &dst[ot + row]);  // streamed once
         }
     } else {
         int32_t *itile = reinterpret_cast<int32_t *>(tile);
         int32_t v[kChunkRows];
 #pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? stg.element[s0 + r * 64] : 0;
+        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? __builtin_nontemporal_load(&stg.element[s0 + r * 64]) : 0;
 #pragma unroll
         for (int r = 0; r < kChunkRows; ++r) itile[r * kTilePitch + lane] = v[r];
         __syncthreads();
