@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 # reads each 44-B record from the staging pool and writes it to its CSR position.
 KERNELS = {
     "march": ("rt::k_march<2, 4>", 45.0),   # single-pass staged march, fill_volumes fused (LDS-private)
-    "compact": ("rt::k_compact", 88.0),
+    "compact": ("rt::k_compact2", 88.0),
     "volumes": ("rt::k_scale_volumes", 0.0),  # volumes ./= n_azim_2 (the accumulation is fused into the march)
 }
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")

@@ -397,6 +397,87 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
     }
 }
 
+// Compaction by (wave of tracks, array) instead of (chunk, array): a 4-wave workgroup owns the 64
+// consecutive tracks of one march wave for one array; each of its waves takes 16 tracks, gathers
+// their columns of 64 staging rows at a time, transposes them in a private LDS tile and writes
+// every track's rows as ONE run of up to 64 consecutive records (512 B, whole lines).  Measured
+// against k_compact (32-record runs from many different waves): the store side of k_compact ran
+// at 1.8 TB/s because most runs end in partial lines shared with a run written by another wave.
+constexpr int kC2Pitch = 68;
+__global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__restrict__ counts,
+                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out) {
+    __shared__ double tiles[4][16 * kC2Pitch];
+    if (stg.cursor[1] != 0) return;  // pool overflow: this attempt is void
+    const int64_t w = blockIdx.x;
+    const int a = blockIdx.y;
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tl = lane & 15, rr = lane >> 4;
+    volatile double *tile = tiles[q];
+    volatile int32_t *itile = reinterpret_cast<volatile int32_t *>(tiles[q]);
+    // counts / offsets of this wave's 16 tracks live in lanes 0..15
+    const int64_t slot = w * 64 + 16 * q + tl;
+    int32_t cnt = 0;
+    int64_t off = 0;
+    if (slot < t.n) {
+        const int32_t u = t.perm[slot];
+        cnt = counts[u];
+        off = offsets[u];
+    }
+    int32_t gmax = cnt;
+    for (int o = 8; o > 0; o >>= 1) {
+        const int32_t v = __shfl_xor(gmax, o, 64);
+        gmax = v > gmax ? v : gmax;
+    }
+    gmax = __shfl(gmax, 0, 64);
+    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
+    const int64_t col = 16 * q + tl;
+    for (int r0 = 0; r0 < gmax; r0 += 64) {
+        // the 64 rows of this block live in (at most) 64 / kChunkRows chunks of the wave's list
+        int32_t cid[64 / kChunkRows];
+#pragma unroll
+        for (int k = 0; k < 64 / kChunkRows; ++k) cid[k] = (r0 + k * kChunkRows < gmax) ? ctab[(r0 >> kChunkLog2) + k] : 0;
+        if (a < 5) {
+            const RT_G double *src = a == 0 ? stg.px : a == 1 ? stg.py : a == 2 ? stg.qx : a == 3 ? stg.qy : stg.ell;
+            RT_G double *dst = a == 0 ? out.px : a == 1 ? out.py : a == 2 ? out.qx : a == 3 ? out.qy : out.ell;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = i * 4 + rr;  // row within the block
+                const int64_t sidx = ((int64_t)cid[rl >> kChunkLog2] * kChunkRows + (rl & (kChunkRows - 1))) * 64 + col;
+                v[i] = (r0 + rl < gmax) ? __builtin_nontemporal_load(&src[sidx]) : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tile[tl * kC2Pitch + i * 4 + rr] = v[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const int32_t ct = __shfl(cnt, tt, 64);
+                const int64_t ot = __shfl(off, tt, 64);
+                if (r0 + lane < ct) __builtin_nontemporal_store(tile[tt * kC2Pitch + lane], &dst[ot + r0 + lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            int32_t v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = i * 4 + rr;
+                const int64_t sidx = ((int64_t)cid[rl >> kChunkLog2] * kChunkRows + (rl & (kChunkRows - 1))) * 64 + col;
+                v[i] = (r0 + rl < gmax) ? __builtin_nontemporal_load(&stg.element[sidx]) : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) itile[tl * kC2Pitch + i * 4 + rr] = v[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const int32_t ct = __shfl(cnt, tt, 64);
+                const int64_t ot = __shfl(off, tt, 64);
+                if (r0 + lane < ct) __builtin_nontemporal_store(itile[tt * kC2Pitch + lane], &out.element[ot + r0 + lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ---- exclusive scan of per-track counts (int32) into CSR offsets (int64) ----------------
 constexpr int kScanBlock = 256;
 constexpr int kScanPer = 4;
@@ -547,6 +628,7 @@ struct rt_mesh {
     bool walk_available = false;
     int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
+    int compact_mode = 2;  // 1: k_compact by (chunk, array), 2: k_compact2 by (wave of tracks, array): 64-record runs
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
@@ -763,6 +845,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "iter_cap")) { mesh->iter_cap = value > 0 ? value : 4000000; return RT_SUCCESS; }
     if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "compact_mode")) { mesh->compact_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
@@ -975,7 +1058,10 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
             RT_HIP(hipEventRecord(t->ev[4], s));
-            if (n > 0)
+            if (n > 0 && m->compact_mode == 2)
+                hipLaunchKernelGGL(rt::k_compact2, dim3((unsigned)n_waves, 6), dim3(256), 0, s, t->d,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out);
+            else if (n > 0)
                 hipLaunchKernelGGL(rt::k_compact, dim3((unsigned)stg.pool_chunks, 6), dim3(64), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out);
             RT_HIP(hipEventRecord(t->ev[5], s));
