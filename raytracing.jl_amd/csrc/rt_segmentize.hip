@@ -107,17 +107,119 @@ struct DStage {
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
 
+// ---- track splitting ("pieces") ------------------------------------------------------------
+// The march of a track is a serial dependent chain; a batch lasts as long as its longest track.
+// In split mode a track is cut into P pieces by arclength.  Piece k >= 1 starts from a SEED: the
+// segment (cell, p, q) of the cell that contains the point M_k of the track, computed with the
+// generic locate + intersections (k_seed).  Every piece marches like a track, but stops — before
+// emitting — at the segment that equals the next live seed bit for bit (cell id, p and q): from
+// there on the reference's state (xp = q + tiny·d, prev_element = cell) is exactly the state the
+// next piece started from, so the concatenation of the pieces IS the reference's segment list.
+// A piece that never meets the next seed simply marches on to the end of the track, and
+// k_resolve drops the pieces it overran: a miss costs time, never correctness.
+struct DSplit {
+    const RT_G int32_t *vorder;   // [n_vwaves] dispatch order (longest pieces first) -> canonical virtual wave
+    const RT_G int32_t *vw_wave;  // [n_vwaves] canonical virtual wave -> wave of 64 consecutive uids
+    const RT_G int32_t *vw_k;     // [n_vwaves] piece index within the wave
+    const RT_G int32_t *w_base;   // [n_waves] first canonical virtual wave of a wave
+    const RT_G int32_t *w_P;      // [n_waves] pieces per track of the wave
+    RT_G int32_t *s_el, *s_eq;    // seeds, per piece (canonical virtual wave * 64 + lane); s_el < 0: no seed
+    RT_G double *s_px, *s_py, *s_qx, *s_qy, *s_ell;
+    RT_G int32_t *p_count, *p_flags;  // per piece: segments emitted; bit0 matched the next seed, bits 8..15 status, bits 16.. target piece
+    RT_G double *p_sum;               // per piece: sum of its segment lengths, in march order
+    RT_G int32_t *p_valid, *p_rel;    // after k_resolve: records kept from the piece / their offset inside the track's run
+    int32_t n_vwaves;
+};
+
+__global__ __launch_bounds__(64) void k_seed(DMesh m, DTracks t, DParams prm, DSplit sp) {
+    const int32_t cv = blockIdx.x;
+    const int32_t k = sp.vw_k[cv];
+    if (k == 0) return;
+    const int32_t w = sp.vw_wave[cv];
+    const int lane = threadIdx.x;
+    const int64_t u = (int64_t)w * 64 + lane;
+    if (u >= t.n) return;
+    const int64_t pi = (int64_t)cv * 64 + lane;
+    const double frac = (double)k / (double)sp.w_P[w];
+    const double cs = t.cs[u], sn = t.sn[u];
+    const double mx = t.px[u] + (frac * t.ell[u]) * cs, my = t.py[u] + (frac * t.ell[u]) * sn;
+    int32_t el = -1;
+    GenericOut go;
+    go.eq = -1;
+    if (!inboundary(m, mx, my, prm.tiny_step)) {
+        const int rc = generic_step(m, mx, my, prm.k, -1, t.phi[u], t.A[u], t.B[u], t.C[u], go);
+        // Any genuine segment of the track near M will do: whether the march really produces it is
+        // checked bit for bit by the piece that arrives there (k_march), not assumed here.
+        if (rc == 0 && go.eq >= 0 && go.ell >= m.l_min) el = go.element;
+    }
+    sp.s_el[pi] = el;
+    if (el >= 0) {
+        sp.s_eq[pi] = go.eq;
+        sp.s_px[pi] = go.px; sp.s_py[pi] = go.py; sp.s_qx[pi] = go.qx; sp.s_qy[pi] = go.qy;
+        sp.s_ell[pi] = go.ell;
+    }
+}
+
+// One lane per track: follow the chain of matched pieces, keep exactly those, and finish the
+// per-track results (count, status, the Σℓ check of src/track.jl:171, failure summary).
+__global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit sp, int32_t *__restrict__ counts,
+                                                 int32_t *__restrict__ status,
+                                                 unsigned long long *__restrict__ fail_info) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= t.n) return;
+    const int32_t w = (int32_t)(u >> 6), lane = (int32_t)(u & 63);
+    const int32_t P = sp.w_P[w], base = sp.w_base[w];
+    for (int k = 0; k < P; ++k) sp.p_valid[(int64_t)(base + k) * 64 + lane] = 0;
+    int32_t total = 0, st = RT_TRACK_OK;
+    double sum = 0.0;
+    int k = 0;
+#ifdef RT_STATS
+    {
+        unsigned long long alive = 1, cnt_all = 0;
+        for (int kk2 = 0; kk2 < P; ++kk2) {
+            if (kk2 > 0 && sp.s_el[(int64_t)(base + kk2) * 64 + lane] >= 0) ++alive;
+            cnt_all += (unsigned long long)sp.p_count[(int64_t)(base + kk2) * 64 + lane];
+        }
+        atomicAdd(&fail_info[3], alive);
+        atomicAdd(&fail_info[4], (unsigned long long)P);
+        atomicAdd(&fail_info[5], cnt_all);
+    }
+#endif
+    for (int guard = 0; guard < P; ++guard) {
+#ifdef RT_STATS
+        atomicAdd(&fail_info[2], 1ull);
+#endif
+        const int64_t pi = (int64_t)(base + k) * 64 + lane;
+        const int32_t c = sp.p_count[pi], fl = sp.p_flags[pi];
+        sp.p_rel[pi] = total;
+        sp.p_valid[pi] = c;
+        total += c;
+        sum += sp.p_sum[pi];
+        if (st == RT_TRACK_OK) st = (fl >> 8) & 255;
+        if (!(fl & 1) || st != RT_TRACK_OK) break;
+        k = fl >> 16;  // the piece whose seed this one met
+    }
+    if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
+    counts[u] = total;
+    status[u] = st;
+    if (st != RT_TRACK_OK) {
+        atomicAdd(&fail_info[0], 1ull);
+        atomicMin(&fail_info[1], (unsigned long long)(u + 1));
+    }
+}
+
 // One lane marches one track (_segmentize_track!, src/track.jl:106-178).  kStage: single pass,
 // records go to the wave-interleaved staging pool (then k_compact).  kCount / kFill: the
 // two-pass variant (count, scan, re-march writing at the CSR offsets).  All modes set counts[] /
 // status[] identically.  WAVES = 1: one wave per workgroup.  WAVES = 4 (kStage only): four
 // consecutive waves share one workgroup and an LDS-private copy of `volumes`, so fill_volumes
 // (src/trackgenerator.jl:371-386) is fused into the march as ds_add_f64 + one coalesced flush.
-template <int MODE, int WAVES>
+// SPLIT (kStage, WAVES = 1): the lanes march pieces of tracks (see DSplit above).
+template <int MODE, int WAVES, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
-                                                      unsigned long long *__restrict__ fail_info) {
+                                                      unsigned long long *__restrict__ fail_info, DSplit sp) {
     constexpr bool FUSE = WAVES > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
@@ -131,10 +233,38 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) hist[c] = 0.0;
         __syncthreads();
     }
-    const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wib;
-    const int64_t slot = wave_id * 64 + lane;
+    int64_t wave_id = (int64_t)blockIdx.x * WAVES + wib;  // indexes the wave's chunk table (ctab)
+    int64_t slot = wave_id * 64 + lane;
+    int32_t pk = 0, pP = 1, pw = 0;  // SPLIT: piece index, pieces per track, wave of tracks
+    if (SPLIT) {
+        wave_id = sp.vorder[blockIdx.x];
+        pw = sp.vw_wave[wave_id];
+        pk = sp.vw_k[wave_id];
+        pP = sp.w_P[pw];
+        slot = (int64_t)pw * 64 + lane;
+    }
     if (slot < t.n) {
-    const int32_t u = t.perm[slot];
+    const int32_t u = SPLIT ? (int32_t)slot : t.perm[slot];
+    const int64_t pi = wave_id * 64 + lane;  // SPLIT: this lane's piece
+    // SPLIT: the seed this piece starts from (k >= 1) and the next live seed, at which it stops
+    bool seed_pending = false, piece_dead = false, matched = false;
+    int32_t tgt_el = -1, tgt_k = 0;
+    double tgt_px = 0, tgt_py = 0, tgt_qx = 0, tgt_qy = 0;
+    if (SPLIT) {
+        if (pk > 0) {
+            if (sp.s_el[pi] < 0) piece_dead = true;
+            else seed_pending = true;
+        }
+        for (int kk2 = pk + 1; kk2 < pP; ++kk2) {
+            const int64_t pj = (int64_t)(sp.w_base[pw] + kk2) * 64 + lane;
+            const int32_t e = sp.s_el[pj];
+            if (e >= 0) {
+                tgt_el = e; tgt_k = kk2;
+                tgt_px = sp.s_px[pj]; tgt_py = sp.s_py[pj]; tgt_qx = sp.s_qx[pj]; tgt_qy = sp.s_qy[pj];
+                break;
+            }
+        }
+    }
     const double tA = t.A[u], tB = t.B[u], tC = t.C[u];
     const double phi = t.phi[u];
     // advance_step (src/point.jl:43): x + step * Point2D(cos ϕ, sin ϕ)
@@ -162,51 +292,46 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
     // band.  Run as its own loop so that the 64 lanes of the wave, whose bands differ in length
     // (≈1/sin ϕ or 1/|cos ϕ| steps), reach their first locate together.
-    while (st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
+    while (!(SPLIT && (seed_pending || piece_dead)) && st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
         xpx = xpx + sx; xpy = xpy + sy;
     }
-#ifdef RT_STATS
-    unsigned long long tk_walk = 0, tk_gen = 0, tk_emit = 0, tk_band = 0, n_gen = 0;
-    const unsigned long long tk_begin = __builtin_amdgcn_s_memtime();
-#endif
-    while (st == RT_TRACK_OK && i < kMaxIter) {  // :119
-#ifdef RT_STATS
-        const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
-#endif
+    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter) {  // :119
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
+        double px, py, qx, qy, ell;
+        int32_t element = -1;
+        const bool from_seed = SPLIT && seed_pending;
+        int res = kWalkEmit;
+        if (from_seed) {
+            // first segment of a seeded piece: the seed itself (k_seed), then march on from its exit point
+            element = sp.s_el[pi];
+            px = sp.s_px[pi]; py = sp.s_py[pi]; qx = sp.s_qx[pi]; qy = sp.s_qy[pi]; ell = sp.s_ell[pi];
+            walk_enter(m, wk, element, sp.s_eq[pi]);
+            seed_pending = false;
+        } else {
         // The reference locates first and tests the boundary second (:122-125); the locate
         // result is unused on both boundary branches, so the order is swapped here.
         if (inboundary(m, xpx, xpy, prm.tiny_step)) {  // :125
             if (i == 0) {
                 xpx = xpx + sx; xpy = xpy + sy;
-#ifdef RT_STATS
-                tk_band += __builtin_amdgcn_s_memtime() - tk0;
-#endif
                 continue;  // :126-129
             }
             break;  // :130-132
         }
-        double px, py, qx, qy, ell;
-        int32_t element = -1;
 #if !defined(RT_PREFETCH) && !defined(RT_SPECULATE)
         load_next(m, wk.pred, nr);
 #endif
-        const int res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+        res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
 #ifdef RT_PREFETCH  // loading the next record one iteration ahead measured 2-3 % slower (253 VGPRs)
         if (res == kWalkEmit) load_next(m, wk.pred, nr);
 #endif
 #ifdef RT_STATS
-        if (MODE != kFill) atomicAdd(&fail_info[2 + res], 1ull);
+        if (MODE != kFill && !SPLIT) atomicAdd(&fail_info[2 + res], 1ull);
 #endif
         if (res == kWalkSkip) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
         px = lqx; py = lqy; element = wk.T;  // valid when res == kWalkEmit
 #ifdef RT_STATS
-        const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
-        tk_walk += tk1 - tk0;
-#endif
-#ifdef RT_STATS
-        if (MODE != kFill) {
+        if (MODE != kFill && !SPLIT) {
             const unsigned long long any_gen = __ballot(res == kWalkGeneric);
             if (lane == __ffsll((long long)__ballot(1)) - 1) {
                 atomicAdd(&fail_info[5], 1ull);                       // wave iterations reaching here
@@ -241,10 +366,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             load_next(m, wk.pred, nr);
 #endif
         }
-#ifdef RT_STATS
-        const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
-        if (__ballot(res == kWalkGeneric)) { tk_gen += tk2 - tk1; n_gen++; }
-#endif
+        }
+        if (SPLIT && !from_seed && tgt_el >= 0 && element == tgt_el && qx == tgt_qx && qy == tgt_qy && px == tgt_px &&
+            py == tgt_py) {
+            matched = true;  // the next piece starts with exactly this segment: stop here
+            break;
+        }
         if (MODE == kFill) {
             const int64_t o = base + i;
             out.px[o] = px; out.py[o] = py; out.qx[o] = qx; out.qy[o] = qy;
@@ -293,18 +420,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         xpx = qx + sx; xpy = qy + sy;  // :165
         prev_element = element;        // :166
         ++i;                           // :168
-#ifdef RT_STATS
-        tk_emit += __builtin_amdgcn_s_memtime() - tk2;
-#endif
     }
-#ifdef RT_STATS
-    if (MODE != kFill && lane == __ffsll((long long)__ballot(1)) - 1) {
-        atomicAdd(&fail_info[8], tk_walk); atomicAdd(&fail_info[9], tk_gen); atomicAdd(&fail_info[10], tk_emit);
-        atomicAdd(&fail_info[11], tk_band); atomicAdd(&fail_info[12], __builtin_amdgcn_s_memtime() - tk_begin);
-        atomicAdd(&fail_info[13], n_gen);
-    }
-#endif
-    if (MODE != kFill) {
+    if (SPLIT) {
+        sp.p_count[pi] = i;
+        sp.p_flags[pi] = (matched ? 1 : 0) | (st << 8) | (tgt_k << 16);
+        sp.p_sum[pi] = sum_ell;
+    } else if (MODE != kFill) {
         // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol)
         if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
         counts[u] = i;
@@ -404,24 +525,31 @@ __global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__rest
 // against k_compact (32-record runs from many different waves): the store side of k_compact ran
 // at 1.8 TB/s because most runs end in partial lines shared with a run written by another wave.
 constexpr int kC2Pitch = 68;
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__restrict__ counts,
-                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out) {
+                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out, DSplit sp) {
     __shared__ double tiles[4][16 * kC2Pitch];
     if (stg.cursor[1] != 0) return;  // pool overflow: this attempt is void
-    const int64_t w = blockIdx.x;
+    const int64_t w = blockIdx.x;  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
     const int a = blockIdx.y;
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = lane & 15, rr = lane >> 4;
     volatile double *tile = tiles[q];
     volatile int32_t *itile = reinterpret_cast<volatile int32_t *>(tiles[q]);
     // counts / offsets of this wave's 16 tracks live in lanes 0..15
-    const int64_t slot = w * 64 + 16 * q + tl;
+    const int64_t slot = (SPLIT ? (int64_t)sp.vw_wave[w] : w) * 64 + 16 * q + tl;
     int32_t cnt = 0;
     int64_t off = 0;
     if (slot < t.n) {
-        const int32_t u = t.perm[slot];
-        cnt = counts[u];
-        off = offsets[u];
+        if (SPLIT) {
+            const int64_t pi = w * 64 + 16 * q + tl;
+            cnt = sp.p_valid[pi];               // 0 for a piece that was overrun
+            off = offsets[slot] + sp.p_rel[pi];
+        } else {
+            const int32_t u = t.perm[slot];
+            cnt = counts[u];
+            off = offsets[u];
+        }
     }
     int32_t gmax = cnt;
     for (int o = 8; o > 0; o >>= 1) {
@@ -628,6 +756,8 @@ struct rt_mesh {
     bool walk_available = false;
     int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
+    int split = -1;         // track splitting (see DSplit), read by rt_tracks_create: -1 auto (only batches that leave the chip
+                            // underfilled), 0 off, > 0 pieces of about `split` expected segments
     int compact_mode = 2;  // 1: k_compact by (chunk, array), 2: k_compact2 by (wave of tracks, array): 64-record runs
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
@@ -655,6 +785,10 @@ struct rt_tracks {
     DevBuf<double> gpx, gpy, gqx, gqy, gell;
     DevBuf<int32_t> gelement, ctab, cowner;
     int64_t pool_chunks = 0, chunks_needed_last = 0;
+    // split mode (pieces of tracks)
+    int32_t n_vwaves = 0;
+    DevBuf<int32_t> vorder, vw_wave, vw_k, w_base, w_P, s_el, s_eq, p_count, p_flags, p_valid, p_rel;
+    DevBuf<double> s_px, s_py, s_qx, s_qy, s_ell, p_sum;
     double sum_ell = 0.0;
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     hipEvent_t ev[8] = {};
@@ -748,6 +882,9 @@ void free_tracks(rt_tracks *t) {
     t->volumes.release(); t->delta_s.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release(); t->gell.release();
     t->gelement.release(); t->ctab.release(); t->cowner.release();
+    t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
+    t->s_el.release(); t->s_eq.release(); t->p_count.release(); t->p_flags.release(); t->p_valid.release(); t->p_rel.release();
+    t->s_px.release(); t->s_py.release(); t->s_qx.release(); t->s_qy.release(); t->s_ell.release(); t->p_sum.release();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     delete t;
@@ -845,6 +982,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "iter_cap")) { mesh->iter_cap = value > 0 ? value : 4000000; return RT_SUCCESS; }
     if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_mode")) { mesh->compact_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
@@ -891,10 +1029,50 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
             for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
     }
     for (size_t i = 0; i < n; ++i) t->sum_ell += ell[i];
+    // split plan: pieces per wave of 64 consecutive uids, canonical numbering, dispatch order
+    std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P;
+    // Splitting pays when the batch has too few waves to fill the chip (the march is then bound by its
+    // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420); on full batches the march is
+    // throughput-bound at 2 waves/SIMD and the pieces' fixed costs make it slower (+20 % at 130 k tracks).
+    const size_t nw_all = (n + 63) / 64;
+    const bool auto_split = mesh->split < 0 && nw_all < 1536;
+    const int p_auto = auto_split ? (int)std::min<size_t>(16, (2048 + nw_all - 1) / std::max<size_t>(1, nw_all)) : 1;
+    if ((mesh->split > 0 || (auto_split && p_auto > 1)) && n > 0) {
+        const size_t nw = (n + 63) / 64;
+        h_w_base.resize(nw); h_w_P.resize(nw);
+        std::vector<double> piece_len;
+        int32_t nv = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            double lmax = 0.0;
+            for (size_t l = 0; l < 64 && w * 64 + l < n; ++l) lmax = std::max(lmax, ell[w * 64 + l]);
+            const double est = lmax * mesh->kappa;  // expected segments of the longest track of the wave
+            int32_t P = mesh->split > 0 ? std::min(8, (int32_t)std::ceil(est / (double)mesh->split))
+                                        : std::min(p_auto, (int32_t)(est / 12.0));  // auto: pieces of >= ~12 segments
+            P = std::max(1, P);
+            if (est > 0.5 * rt::kMaxIter) P = 1;  // MAX_ITER (src/track.jl:104) counts whole tracks
+            h_w_base[w] = nv; h_w_P[w] = P;
+            for (int32_t k = 0; k < P; ++k) { h_vw_wave.push_back((int32_t)w); h_vw_k.push_back(k); piece_len.push_back(lmax / P); }
+            nv += P;
+        }
+        h_vorder.resize(nv);
+        std::iota(h_vorder.begin(), h_vorder.end(), 0);
+        std::stable_sort(h_vorder.begin(), h_vorder.end(), [&](int32_t a, int32_t b) { return piece_len[a] > piece_len[b]; });
+        t->n_vwaves = nv;
+    }
     bool ok = upload(t->px, px, n, s) == 0 && upload(t->py, py, n, s) == 0 && upload(t->phi, phi, n, s) == 0 &&
               upload(t->cs, cos_phi, n, s) == 0 && upload(t->sn, sin_phi, n, s) == 0 && upload(t->A, A, n, s) == 0 &&
               upload(t->B, B, n, s) == 0 && upload(t->C, C, n, s) == 0 && upload(t->ell, ell, n, s) == 0 &&
               upload(t->azim, azim_idx, n, s) == 0 && upload(t->perm, perm.data(), n, s) == 0;
+    if (ok && t->n_vwaves > 0) {
+        const size_t np = (size_t)t->n_vwaves * 64;
+        ok = upload(t->vorder, h_vorder.data(), h_vorder.size(), s) == 0 && upload(t->vw_wave, h_vw_wave.data(), h_vw_wave.size(), s) == 0 &&
+             upload(t->vw_k, h_vw_k.data(), h_vw_k.size(), s) == 0 && upload(t->w_base, h_w_base.data(), h_w_base.size(), s) == 0 &&
+             upload(t->w_P, h_w_P.data(), h_w_P.size(), s) == 0 && t->s_el.reserve(np) == hipSuccess && t->s_eq.reserve(np) == hipSuccess &&
+             t->p_count.reserve(np) == hipSuccess && t->p_flags.reserve(np) == hipSuccess && t->p_valid.reserve(np) == hipSuccess &&
+             t->p_rel.reserve(np) == hipSuccess && t->s_px.reserve(np) == hipSuccess && t->s_py.reserve(np) == hipSuccess &&
+             t->s_qx.reserve(np) == hipSuccess && t->s_qy.reserve(np) == hipSuccess && t->s_ell.reserve(np) == hipSuccess &&
+             t->p_sum.reserve(np) == hipSuccess;
+    }
     for (auto &e : t->ev)
         if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
     if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
@@ -959,6 +1137,18 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     out.delta_s = as_global(t->delta_s.p);
     out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
     rt::DStage stg{};
+    rt::DSplit sp{};
+    const bool split = m->single_pass && t->n_vwaves > 0;
+    if (split) {
+        sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
+        sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
+        sp.s_el = as_global(t->s_el.p); sp.s_eq = as_global(t->s_eq.p);
+        sp.s_px = as_global(t->s_px.p); sp.s_py = as_global(t->s_py.p); sp.s_qx = as_global(t->s_qx.p);
+        sp.s_qy = as_global(t->s_qy.p); sp.s_ell = as_global(t->s_ell.p);
+        sp.p_count = as_global(t->p_count.p); sp.p_flags = as_global(t->p_flags.p); sp.p_sum = as_global(t->p_sum.p);
+        sp.p_valid = as_global(t->p_valid.p); sp.p_rel = as_global(t->p_rel.p);
+        sp.n_vwaves = t->n_vwaves;
+    }
     const unsigned grid = (unsigned)n_waves;
     int64_t total = 0;
     unsigned long long fi[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1014,15 +1204,15 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     if (m->single_pass) {
         // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
         //      (or from what the previous call needed) and grown + re-run on overflow
-        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, n_waves) * rt::kMaxChunks));
+        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, split ? t->n_vwaves : n_waves) * rt::kMaxChunks));
         int64_t want = t->chunks_needed_last > 0
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
-                           : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * n_waves + 64;
+                           : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * (split ? t->n_vwaves : n_waves) + 64;
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
         // fill_volumes fused into the march when an LDS copy of `volumes` (+ 4 chunk tables) leaves room
         // for two workgroups per CU; larger meshes use the separate k_volumes pass
         const size_t fuse_smem = (size_t)m->n_cells * sizeof(double) + 4 * rt::kMaxChunks * sizeof(int32_t);
-        const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && fuse_smem <= 78 * 1024;
+        const bool fuse = !split && m->volumes_mode == 2 && m->fuse_volumes && fuse_smem <= 78 * 1024;
         fused_volumes_this_call = fuse;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
@@ -1042,25 +1232,35 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
             RT_HIP(hipEventRecord(t->ev[1], s));
-            if (n > 0) {
+            if (n > 0 && split) {
+                hipLaunchKernelGGL(rt::k_seed, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
+                hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, true>), dim3((unsigned)t->n_vwaves), dim3(64),
+                                   rt::kMaxChunks * sizeof(int32_t), s, m->d, t->d, prm, t->counts.p, t->status.p,
+                                   (const int64_t *)nullptr, out, stg, d_fail, sp);
+                hipLaunchKernelGGL(rt::k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t->d, prm, sp, t->counts.p,
+                                   t->status.p, d_fail);
+            } else if (n > 0) {
                 if (fuse) {
                     if (fuse_smem > 48 * 1024)
-                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4>,
+                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4, false>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 4>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), fuse_smem, s,
-                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 4, false>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), fuse_smem, s,
+                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
                 } else {
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 1>), dim3(grid), dim3(64), rt::kMaxChunks * sizeof(int32_t), s,
-                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, false>), dim3(grid), dim3(64), rt::kMaxChunks * sizeof(int32_t), s,
+                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
                 }
             }
             RT_HIP(hipEventRecord(t->ev[2], s));
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
             RT_HIP(hipEventRecord(t->ev[4], s));
-            if (n > 0 && m->compact_mode == 2)
-                hipLaunchKernelGGL(rt::k_compact2, dim3((unsigned)n_waves, 6), dim3(256), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out);
+            if (n > 0 && split)
+                hipLaunchKernelGGL(rt::k_compact2<true>, dim3((unsigned)t->n_vwaves, 6), dim3(256), 0, s, t->d,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
+            else if (n > 0 && m->compact_mode == 2)
+                hipLaunchKernelGGL(rt::k_compact2<false>, dim3((unsigned)n_waves, 6), dim3(256), 0, s, t->d,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
             else if (n > 0)
                 hipLaunchKernelGGL(rt::k_compact, dim3((unsigned)stg.pool_chunks, 6), dim3(64), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out);
@@ -1082,8 +1282,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         RT_HIP(hipEventRecord(t->ev[1], s));
         if (n > 0)
-            hipLaunchKernelGGL((rt::k_march<rt::kCount, 1>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
-                               t->status.p, (const int64_t *)nullptr, out, stg, d_fail);
+            hipLaunchKernelGGL((rt::k_march<rt::kCount, 1, false>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
+                               t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
         RT_HIP(hipEventRecord(t->ev[2], s));
         if (int rc = scan_counts()) return rc;
         RT_HIP(hipEventRecord(t->ev[3], s));
@@ -1094,8 +1294,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         if (int rc = reserve_out(total)) return rc;
         RT_HIP(hipEventRecord(t->ev[4], s));
         if (n > 0)
-            hipLaunchKernelGGL((rt::k_march<rt::kFill, 1>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
-                               t->status.p, (const int64_t *)t->offsets.p, out, stg, d_fail);
+            hipLaunchKernelGGL((rt::k_march<rt::kFill, 1, false>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
+                               t->status.p, (const int64_t *)t->offsets.p, out, stg, d_fail, sp);
         RT_HIP(hipEventRecord(t->ev[5], s));
         if (int rc = launch_volumes()) return rc;
         RT_HIP(hipEventRecord(t->ev[6], s));
@@ -1110,8 +1310,6 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
 #ifdef RT_STATS
     fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
             fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
-    fprintf(stderr, "[rt stats] memtime ticks (last lane alive per wave): walk=%llu generic=%llu (n=%llu) emit=%llu band=%llu lifetime=%llu\n",
-            fi[8], fi[9], fi[13], fi[10], fi[11], fi[12]);
 #endif
     t->total = total;
     t->n_failed = (int64_t)fi[0];
