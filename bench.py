@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 # SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input.  The compaction
 # reads each 44-B record from the staging pool and writes it to its CSR position.
 KERNELS = {
-    "march": ("rt::k_march<2, 4>", 45.0),   # single-pass staged march, fill_volumes fused (LDS-private)
-    "compact": ("rt::k_compact2", 88.0),
+    "march": ("rt::k_march<2, 4, false>", 45.0),   # single-pass staged march, fill_volumes fused (LDS-private)
+    "compact": ("rt::k_compact2<false>", 88.0),
     "volumes": ("rt::k_scale_volumes", 0.0),  # volumes ./= n_azim_2 (the accumulation is fused into the march)
 }
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
