@@ -97,14 +97,17 @@ __device__ __forceinline__ bool isapprox_v2(double px, double py, double qx, dou
     return isapprox_s(px, qx, kRtolDefault) && isapprox_s(py, qy, kRtolDefault);
 }
 
-// inboundary(mesh, x, atol) with atol = tiny_step > 0 (=> rtol = 0) — src/mesh.jl:91-95
+// inboundary(mesh, x, atol) — src/mesh.jl:91-95: four scalar isapprox(x[i], bb[i]; atol), i.e.
+// x == b || (isfinite(x) && isfinite(b) && |x - b| <= max(atol, rtol·max(|x|,|b|))) with rtol = 0 when
+// atol > 0 and √eps otherwise.  Evaluated without branches (it runs once per march iteration and a
+// short-circuit form costs ~25 divergent branches there); the bounding box is finite.
+__device__ __forceinline__ bool near_bb(double x, double b, double atol) {
+    const double ax = fabs(x), ab = fabs(b);
+    const double tol = atol > 0.0 ? atol : kRtolDefault * (ax > ab ? ax : ab);
+    return (x == b) | (isfin(x) & (fabs(x - b) <= tol));
+}
 __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
-    if (atol > 0.0) {
-        return (x == m.bx1 || fabs(x - m.bx1) <= atol) || (x == m.bx0 || fabs(x - m.bx0) <= atol) ||
-               (y == m.by1 || fabs(y - m.by1) <= atol) || (y == m.by0 || fabs(y - m.by0) <= atol);
-    }
-    return isapprox_s(x, m.bx1, kRtolDefault) || isapprox_s(x, m.bx0, kRtolDefault) ||
-           isapprox_s(y, m.by1, kRtolDefault) || isapprox_s(y, m.by0, kRtolDefault);
+    return near_bb(x, m.bx1, atol) | near_bb(x, m.bx0, atol) | near_bb(y, m.by1, atol) | near_bb(y, m.by0, atol);
 }
 
 // ------------------------------------------------------- point_in_triangle ---------------
@@ -527,5 +530,6 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
 #endif
     return res;
 }
+
 
 }  // namespace rt

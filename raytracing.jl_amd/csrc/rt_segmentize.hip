@@ -215,6 +215,19 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
 // consecutive waves share one workgroup and an LDS-private copy of `volumes`, so fill_volumes
 // (src/trackgenerator.jl:371-386) is fused into the march as ds_add_f64 + one coalesced flush.
 // SPLIT (kStage, WAVES = 1): the lanes march pieces of tracks (see DSplit above).
+#ifdef RT_TIMING
+// development only: in-kernel cycle stamps (s_memtime), tied to a value so the compiler keeps the order;
+// RT_TIMING=2 also drains the memory queue before every stamp
+__device__ __forceinline__ unsigned long long rt_tick(double dep) {
+    unsigned long long t;
+#if RT_TIMING == 2
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+#else
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+#endif
+    return t;
+}
+#endif
 template <int MODE, int WAVES, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
@@ -296,8 +309,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
         xpx = xpx + sx; xpy = xpy + sy;
     }
+#ifdef RT_TIMING
+    unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tn = 0, tD = 0;
+    const unsigned long long tstart = rt_tick(xpx);
+#endif
     while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter) {  // :119
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
+#ifdef RT_TIMING
+        const unsigned long long tA_ = rt_tick(xpx);
+        unsigned long long tC_ = 0;
+        if (tD) tacc3 += tA_ - tD;
+#endif
         double px, py, qx, qy, ell;
         int32_t element = -1;
         const bool from_seed = SPLIT && seed_pending;
@@ -321,7 +343,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
 #if !defined(RT_PREFETCH) && !defined(RT_SPECULATE)
         load_next(m, wk.pred, nr);
 #endif
+#ifdef RT_TIMING
+        const unsigned long long tB_ = rt_tick(RT_TIMING == 2 ? nr.e2C : xpx);
+        tacc0 += tB_ - tA_;
+#endif
         res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+#ifdef RT_TIMING
+        tC_ = rt_tick(ell + (double)res);
+        tacc1 += tC_ - tB_;
+#endif
 #ifdef RT_PREFETCH  // loading the next record one iteration ahead measured 2-3 % slower (253 VGPRs)
         if (res == kWalkEmit) load_next(m, wk.pred, nr);
 #endif
@@ -415,12 +445,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             if (FUSE) atomicAdd(&hist[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
         }
+#ifdef RT_TIMING
+        tD = rt_tick(ell);
+        if (!from_seed && res == kWalkEmit) { tacc2 += tD - tC_; ++tn; }
+#endif
         if (MODE != kFill) sum_ell += ell;
         lqx = qx; lqy = qy;
         xpx = qx + sx; xpy = qy + sy;  // :165
         prev_element = element;        // :166
         ++i;                           // :168
     }
+#ifdef RT_TIMING
+    if (!SPLIT && MODE == kStage && lane == __ffsll((long long)__ballot(1)) - 1) {
+        atomicAdd(&fail_info[8], tacc0); atomicAdd(&fail_info[9], tacc1); atomicAdd(&fail_info[10], tacc2);
+        atomicAdd(&fail_info[11], tacc3); atomicAdd(&fail_info[12], tn); atomicAdd(&fail_info[13], rt_tick(xpx) - tstart);
+        atomicAdd(&fail_info[14], 1ull);
+    }
+#endif
     if (SPLIT) {
         sp.p_count[pi] = i;
         sp.p_flags[pi] = (matched ? 1 : 0) | (st << 8) | (tgt_k << 16);
@@ -1307,6 +1348,10 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan
     RT_HIP(hipEventElapsedTime(&f, t->ev[4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
     RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f;   // volumes
+#ifdef RT_TIMING
+    fprintf(stderr, "[rt timing] per wave-iteration (lane-0 view, cycles): top+load %.0f | walk_step %.0f | emit %.0f | loop-back %.0f | iters/wave %.1f | loop cycles/wave %.0f\n",
+            (double)fi[8] / fi[12], (double)fi[9] / fi[12], (double)fi[10] / fi[12], (double)fi[11] / fi[12], (double)fi[12] / fi[14], (double)fi[13] / fi[14]);
+#endif
 #ifdef RT_STATS
     fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
             fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
