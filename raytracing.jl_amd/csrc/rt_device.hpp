@@ -104,10 +104,11 @@ __device__ __forceinline__ bool isapprox_v2(double px, double py, double qx, dou
 __device__ __forceinline__ bool near_bb(double x, double b, double atol) {
     const double ax = fabs(x), ab = fabs(b);
     const double tol = atol > 0.0 ? atol : kRtolDefault * (ax > ab ? ax : ab);
-    return (x == b) | (isfin(x) & (fabs(x - b) <= tol));
+    return ((int)(x == b) | ((int)isfin(x) & (int)(fabs(x - b) <= tol))) != 0;
 }
 __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
-    return near_bb(x, m.bx1, atol) | near_bb(x, m.bx0, atol) | near_bb(y, m.by1, atol) | near_bb(y, m.by0, atol);
+    return ((int)near_bb(x, m.bx1, atol) | (int)near_bb(x, m.bx0, atol) | (int)near_bb(y, m.by1, atol) |
+            (int)near_bb(y, m.by0, atol)) != 0;
 }
 
 // ------------------------------------------------------- point_in_triangle ---------------
@@ -531,5 +532,35 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     return res;
 }
 
+
+// After walk_step returned kWalkSkip at the previous xp: would it return kWalkSkip again at this xp
+// (same T, same predicted T')?  Only what depends on xp is re-evaluated — certificate 2, the exact
+// shallow-crossing λ and the scan-order rule, with the expressions of walk_step; the track line,
+// the exit point and ℓ do not change while the lane creeps by tiny_step.  A track that crosses an
+// edge at a very small angle takes hundreds of such steps (src/track.jl:147-150); this keeps each
+// of them to a few dozen instructions instead of a full march iteration.
+__device__ __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const NextRec &nr, double xpx, double xpy) {
+    const double x0 = nr.x0, y0 = nr.y0, x1 = nr.x1, y1 = nr.y1, x2 = nr.x2, y2 = nr.y2;
+    const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    const double sg = area2 > 0 ? 1.0 : -1.0;
+    const double aa = fabs(area2);
+    const double c0 = sg * ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0));
+    const double c1 = sg * ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1));
+    const double c2 = sg * ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2));
+    if (!(c0 >= -0.25 * kRtolDefault * aa && c1 >= m.eps_iso * aa && c2 >= m.eps_iso * aa)) return false;
+    const double numT = (w.ay - w.by) * xpx + (w.bx - w.ax) * xpy + (w.ax * w.by - w.bx * w.ay);
+    const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
+    if (clearly_out) return false;
+    const double lamT = numT / w.dT;
+    if (!(lamT >= 0.0 - kRtolDefault)) return false;
+    const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
+    const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
+    const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
+    const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
+    const double dab = da < db ? da : db;
+    const bool tie = dc == dab || dcp == dab || dc == dcp;
+    const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < nr.cell);
+    return !tie && t_first;
+}
 
 }  // namespace rt

@@ -103,6 +103,9 @@ struct DStage {
     RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
+#ifdef RT_TIMING
+    unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
+#endif
 };
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         xpx = xpx + sx; xpy = xpy + sy;
     }
 #ifdef RT_TIMING
-    unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tn = 0, tD = 0;
+    unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tn = 0, tD = 0, wits = 0, wgen = 0;
     const unsigned long long tstart = rt_tick(xpx);
 #endif
     while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter) {  // :119
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
 #ifdef RT_TIMING
         const unsigned long long tA_ = rt_tick(xpx);
         unsigned long long tC_ = 0;
+        ++wits;
         if (tD) tacc3 += tA_ - tD;
 #endif
         double px, py, qx, qy, ell;
@@ -358,7 +362,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
 #ifdef RT_STATS
         if (MODE != kFill && !SPLIT) atomicAdd(&fail_info[2 + res], 1ull);
 #endif
-        if (res == kWalkSkip) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
+        if (res == kWalkSkip) {  // :147-150
+            xpx = xpx + sx; xpy = xpy + sy;
+#if !defined(RT_SPECULATE) && !defined(RT_NO_SKIPRUN)
+            // creep on while the reference would keep locating T: each pass stands for one more march
+            // iteration that ends in the same `continue`
+            while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && walk_still_skip(m, wk, nr, xpx, xpy)) {
+                ++it;
+                xpx = xpx + sx; xpy = xpy + sy;
+            }
+#endif
+            continue;
+        }
         px = lqx; py = lqy; element = wk.T;  // valid when res == kWalkEmit
 #ifdef RT_STATS
         if (MODE != kFill && !SPLIT) {
@@ -369,11 +384,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
         }
 #endif
+#ifdef RT_TIMING
+        if (__ballot(res == kWalkGeneric)) ++wgen;
+#endif
         if (res == kWalkGeneric) {
 #ifndef RT_GENERIC_OUTOFLINE  // out-of-line generic step + RT_SPECULATE: -4 % (pincell) / +4 % (BWR-like); off
             element = find_element(m, xpx, xpy, prm.k);               // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
-            if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :147-150
+            if (element == prev_element) {  // :147-150
+                xpx = xpx + sx; xpy = xpy + sy;
+#ifndef RT_NO_SKIPRUN
+                // Creep: a track that leaves a cell at a very small angle next to a vertex is located
+                // in the same cell again for hundreds of tiny steps (BWR-like config 4: 229 in a row).
+                // Each pass stands for one march iteration ending in this `continue`; only the
+                // reference's own locate is repeated, not the walk step that cannot certify here.
+                while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && find_element(m, xpx, xpy, prm.k) == prev_element) {
+                    ++it;
+                    xpx = xpx + sx; xpy = xpy + sy;
+                }
+#endif
+                continue;
+            }
             int eq;
             if (!intersections(m, element, phi, tA, tB, tC, px, py, qx, qy, eq)) {  // :153
                 st = RT_TRACK_UNDEF_INTERSECTION;
@@ -460,6 +491,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         atomicAdd(&fail_info[8], tacc0); atomicAdd(&fail_info[9], tacc1); atomicAdd(&fail_info[10], tacc2);
         atomicAdd(&fail_info[11], tacc3); atomicAdd(&fail_info[12], tn); atomicAdd(&fail_info[13], rt_tick(xpx) - tstart);
         atomicAdd(&fail_info[14], 1ull);
+        if (stg.dbg) {
+            stg.dbg[4 * wave_id + 0] = rt_tick(xpx) - tstart; stg.dbg[4 * wave_id + 1] = wits;
+            stg.dbg[4 * wave_id + 2] = wgen; stg.dbg[4 * wave_id + 3] = tn;
+        }
     }
 #endif
     if (SPLIT) {
@@ -820,6 +855,9 @@ struct rt_tracks {
     DevBuf<int64_t> offsets, tile_sums;
     // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag
     DevBuf<unsigned long long> ctl;
+#ifdef RT_TIMING
+    DevBuf<unsigned long long> dbg;
+#endif
     unsigned long long *h_ctl = nullptr;  // pinned: [0..31] init image, [32..63] read-back
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
     // staging pool of the single-pass march
@@ -918,6 +956,9 @@ void free_tracks(rt_tracks *t) {
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
     t->tile_sums.release(); t->ctl.release();
+#ifdef RT_TIMING
+    t->dbg.release();
+#endif
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->delta_s.release();
@@ -1270,6 +1311,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             stg.qy = as_global(t->gqy.p); stg.ell = as_global(t->gell.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
+#ifdef RT_TIMING
+            RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
+            RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
+            stg.dbg = t->dbg.p;
+#endif
             RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
             RT_HIP(hipEventRecord(t->ev[1], s));
@@ -1349,6 +1395,13 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     RT_HIP(hipEventElapsedTime(&f, t->ev[4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
     RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f;   // volumes
 #ifdef RT_TIMING
+    if (const char *path = getenv("RT_TIMING_DUMP")) {
+        if (t->dbg.p) {
+            std::vector<unsigned long long> h((size_t)((n + 63) / 64) * 4);
+            RT_HIP(hipMemcpy(h.data(), t->dbg.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+        }
+    }
     fprintf(stderr, "[rt timing] per wave-iteration (lane-0 view, cycles): top+load %.0f | walk_step %.0f | emit %.0f | loop-back %.0f | iters/wave %.1f | loop cycles/wave %.0f\n",
             (double)fi[8] / fi[12], (double)fi[9] / fi[12], (double)fi[10] / fi[12], (double)fi[11] / fi[12], (double)fi[12] / fi[14], (double)fi[13] / fi[14]);
 #endif
