@@ -34,11 +34,12 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 # Algorithmic bytes per segment of each kernel of a step.  The march's figure is
-# SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input.  The compaction
-# reads each 44-B record from the staging pool and writes it to its CSR position.
+# SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input (the march itself stages
+# only 20 B of it: q and the cell).  The compaction reads those 20 B from the staging pool, rebuilds p
+# and ℓ, and writes the 44-B record to its CSR position.
 KERNELS = {
     "march": ("rt::k_march<2, 4, false>", 45.0),   # single-pass staged march, fill_volumes fused (LDS-private)
-    "compact": ("rt::k_compact2<false>", 88.0),
+    "compact": ("rt::k_compact3<false>", 64.0),
     "volumes": ("rt::k_scale_volumes", 0.0),  # volumes ./= n_azim_2 (the accumulation is fused into the march)
 }
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")

@@ -88,7 +88,7 @@ struct DOut {
 // output array.  Lane l of a wave writes its i-th segment to row i of the wave's chunk list,
 // column l — lanes of a wave emit in near lockstep, so each store instruction writes whole
 // 512-B rows instead of 64 scattered 8-B pieces.  Chunks are handed out from one atomic
-// cursor, once per wave and chunk (wave-aggregated), and recorded in `ctab` for k_compact.
+// cursor, once per wave and chunk (wave-aggregated), and recorded in `ctab` / `cowner` for the compaction.
 #ifndef RT_CHUNK_LOG2
 #define RT_CHUNK_LOG2 5  // 32 rows per chunk measured best (8: -18 %, 16: -6 % vs 32 at C3)
 #endif
@@ -103,6 +103,8 @@ struct DStage {
     RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
+    int32_t chunk0;         // k_compact3: first chunk of this launch
+    int32_t lean;           // 1: rows hold (qx, qy, ±element) only; p is staged just for rows it cannot be derived for
 #ifdef RT_TIMING
     unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
 #endif
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
 }
 
 // One lane marches one track (_segmentize_track!, src/track.jl:106-178).  kStage: single pass,
-// records go to the wave-interleaved staging pool (then k_compact).  kCount / kFill: the
+// records go to the wave-interleaved staging pool (then k_compact3).  kCount / kFill: the
 // two-pass variant (count, scan, re-march writing at the CSR offsets).  All modes set counts[] /
 // status[] identically.  WAVES = 1: one wave per workgroup.  WAVES = 4 (kStage only): four
 // consecutive waves share one workgroup and an LDS-private copy of `volumes`, so fill_volumes
@@ -470,9 +472,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             if (my_chunk >= 0) {
                 const int64_t o = ((int64_t)my_chunk * kChunkRows + r) * 64 + lane;
-                stg.px[o] = px; stg.py[o] = py; stg.qx[o] = qx; stg.qy[o] = qy;
-                stg.ell[o] = ell;
-                stg.element[o] = element + 1;
+                if (stg.lean) {
+                    // A walk-step record starts where the lane's previous record ended (p = previous q, bit for
+                    // bit) and ℓ = ‖p − q‖ is a function of the two: only q and the cell are staged (20 B instead
+                    // of 44) and k_compact3 rebuilds p and ℓ.  Records of the generic step / a seed keep their
+                    // own p and are marked by a negative element.
+                    const bool derived = res == kWalkEmit && !from_seed;
+                    stg.qx[o] = qx; stg.qy[o] = qy;
+                    stg.element[o] = derived ? element + 1 : -(element + 1);
+                    if (!derived) { stg.px[o] = px; stg.py[o] = py; }
+                } else {
+                    stg.px[o] = px; stg.py[o] = py; stg.qx[o] = qx; stg.qy[o] = qy;
+                    stg.ell[o] = ell;
+                    stg.element[o] = element + 1;
+                }
             }
             if (FUSE) atomicAdd(&hist[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
         }
@@ -521,85 +534,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     }
 }
 
-// Staging pool -> compact CSR records.  One wave per CHUNK (16 rows x 64 tracks x 6 arrays):
-// rows are read coalesced (512 B per row and array), transposed through an LDS tile (row
-// pitch 66 doubles: conflict-free for both the row-wise writes and the column-wise reads),
-// and written as runs of up to 16 consecutive records per track (4 tracks x 16 rows per
-// store instruction).  The grid covers the whole pool; workgroups past the cursor exit.
-constexpr int kTilePitch = kChunkRows == 16 ? 66 : 65;  // conflict-free column reads for 4 (resp. 2) tracks per instruction
-constexpr int kTracksPerStore = 64 / kChunkRows;
-// grid = (pool chunks, 6 arrays): one wave moves one array of one chunk, so no wave ever queues
-// a load behind its own stores (gfx950 retires loads and stores through one in-order vmcnt
-// queue) and the chip sees ~6x more independent waves.
-__global__ __launch_bounds__(64) void k_compact(DTracks t, const int32_t *__restrict__ counts,
-                                                const int64_t *__restrict__ offsets, DStage stg, DOut out) {
-    __shared__ double tile[kChunkRows * kTilePitch];
-    const int32_t c = blockIdx.x;
-    // cursor[1] != 0: the pool overflowed, the records are incomplete and the CSR offsets exceed
-    // the output buffers — the host grows the pool and re-runs the whole call
-    if (stg.cursor[1] != 0 || c >= stg.cursor[0]) return;
-    const int a = blockIdx.y;
-    const int lane = threadIdx.x;
-    const int32_t owner = stg.cowner[c];
-    const int64_t wv = owner / kMaxChunks;
-    const int j = owner % kMaxChunks;
-    const int64_t slot = wv * 64 + lane;
-    int32_t cnt = 0;
-    int64_t off = 0;
-    if (slot < t.n) {
-        const int32_t u = t.perm[slot];
-        cnt = counts[u];
-        off = offsets[u];
-    }
-    int32_t maxcnt = cnt;
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t v = __shfl_xor(maxcnt, o, 64);
-        maxcnt = v > maxcnt ? v : maxcnt;
-    }
-    const int nrows = min(kChunkRows, maxcnt - j * kChunkRows);  // rows of this chunk any lane used (wave-uniform)
-    const int tsub = lane >> kChunkLog2, r16 = lane & (kChunkRows - 1);
-    const int64_t s0 = ((int64_t)c * kChunkRows) * 64 + lane;
-    const int row = j * kChunkRows + r16;
-    if (a < 5) {
-        const RT_G double *src = a == 0 ? stg.px : a == 1 ? stg.py : a == 2 ? stg.qx : a == 3 ? stg.qy : stg.ell;
-        RT_G double *dst = a == 0 ? out.px : a == 1 ? out.py : a == 2 ? out.qx : a == 3 ? out.qy : out.ell;
-        double v[kChunkRows];
-#pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? __builtin_nontemporal_load(&src[s0 + r * 64]) : 0.0;
-#pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) tile[r * kTilePitch + lane] = v[r];
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 64 / kTracksPerStore; ++g) {  // this lane writes row `row` of track tt
-            const int tt = g * kTracksPerStore + tsub;
-            const int32_t ct = __shfl(cnt, tt, 64);
-            const int64_t ot = __shfl(off, tt, 64);
-            if (row < ct) __builtin_nontemporal_store(tile[r16 * kTilePitch + tt], &dst[ot + row]);  // streamed once
-        }
-    } else {
-        int32_t *itile = reinterpret_cast<int32_t *>(tile);
-        int32_t v[kChunkRows];
-#pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) v[r] = r < nrows ? __builtin_nontemporal_load(&stg.element[s0 + r * 64]) : 0;
-#pragma unroll
-        for (int r = 0; r < kChunkRows; ++r) itile[r * kTilePitch + lane] = v[r];
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 64 / kTracksPerStore; ++g) {
-            const int tt = g * kTracksPerStore + tsub;
-            const int32_t ct = __shfl(cnt, tt, 64);
-            const int64_t ot = __shfl(off, tt, 64);
-            if (row < ct) out.element[ot + row] = itile[r16 * kTilePitch + tt];
-        }
-    }
-}
-
-// Compaction by (wave of tracks, array) instead of (chunk, array): a 4-wave workgroup owns the 64
-// consecutive tracks of one march wave for one array; each of its waves takes 16 tracks, gathers
-// their columns of 64 staging rows at a time, transposes them in a private LDS tile and writes
-// every track's rows as ONE run of up to 64 consecutive records (512 B, whole lines).  Measured
-// against k_compact (32-record runs from many different waves): the store side of k_compact ran
-// at 1.8 TB/s because most runs end in partial lines shared with a run written by another wave.
+// Fully staged rows (compact_mode 2, kept as the cross-check of the lean path): compaction by (wave of
+// tracks, array).  A 4-wave workgroup owns the 64 consecutive tracks of one march wave for one array;
+// each of its waves takes 16 tracks, gathers their columns of 64 staging rows at a time, transposes
+// them in a private LDS tile and writes every track's rows as one run of up to 64 consecutive records.
 constexpr int kC2Pitch = 68;
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__restrict__ counts,
@@ -678,6 +616,125 @@ __global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__re
                 if (r0 + lane < ct) __builtin_nontemporal_store(itile[tt * kC2Pitch + lane], &out.element[ot + r0 + lane]);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Lean staging -> compact CSR records, all six arrays in one pass.  One 4-wave workgroup per CHUNK
+// (32 rows x the 64 consecutive tracks of one march wave); each wave takes 16 tracks: (qx, qy,
+// ±element) are read once, coalesced, transposed in wave-private LDS tiles, and every track's 32 rows
+// leave as one run per output array.  p of a row is the q of the row before it (tile column shifted by
+// one; slot 0 holds the last row of the wave's previous chunk) unless the row is marked (element < 0:
+// first record of a track / piece, generic step), in which case the staged p is fetched; ℓ = ‖p − q‖
+// is recomputed with the march's own expression (Segment ctor, src/segment.jl:31-33), so the records
+// are bit-identical to fully staged ones.  20 B read + 44 B written per segment instead of 44 + 44.
+// Every wave issues all its loads, then all its stores: no load is ever queued behind a store of the
+// same wave (gfx950 retires both through one in-order vmcnt queue), and the grid (whole pool;
+// workgroups past the cursor exit) gives the chip tens of thousands of independent waves.
+constexpr int kC3Pitch = kChunkRows + 4;  // doubles per track in a tile: slot 0 = carry, slots 1..32 = rows
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__restrict__ counts,
+                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out, DSplit sp) {
+    static_assert(kChunkRows == 32, "k_compact3 moves one 32-row chunk per workgroup");
+    __shared__ double tiles_x[4][16 * kC3Pitch];  // 36.9 KB per workgroup: four workgroups per CU
+    __shared__ double tiles_y[4][16 * kC3Pitch];
+    const int32_t c = blockIdx.x + stg.chunk0;
+    if (stg.cursor[1] != 0 || c >= stg.cursor[0]) return;  // pool overflow (this attempt is void) / unused chunk
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr+4, ...
+    const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub+2, ...
+    // The chunk's rows are requested at once, before anything is known about their tracks: the chain
+    // cowner -> perm -> counts / offsets (three dependent loads) then runs under the same latency.
+    // Rows nobody wrote are fetched too (in bounds: the pool), and ignored.
+    const int64_t col = 16 * q + tl;
+    double vx[8], vy[8];
+    int32_t ve[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t sidx = ((int64_t)c * kChunkRows + i * 4 + rr) * 64 + col;
+        vx[i] = __builtin_nontemporal_load(&stg.qx[sidx]);
+        vy[i] = __builtin_nontemporal_load(&stg.qy[sidx]);
+        ve[i] = __builtin_nontemporal_load(&stg.element[sidx]);
+    }
+    const int32_t owner = stg.cowner[c];
+    const int64_t w = owner / kMaxChunks;  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
+    const int j = owner % kMaxChunks;      // the wave's j-th chunk: rows 32 j .. 32 j + 31 of its tracks
+    volatile double *tx = tiles_x[q], *ty = tiles_y[q];
+    volatile int32_t *te = reinterpret_cast<volatile int32_t *>(tiles_x[q]);  // the x tile is reused for the cell ids
+    const int64_t slot = (SPLIT ? (int64_t)sp.vw_wave[w] : w) * 64 + 16 * q + tl;  // lanes 0..15: their track's count / offset
+    int32_t cnt = 0;
+    int64_t off = 0;
+    if (slot < t.n) {
+        if (SPLIT) {
+            const int64_t pi = w * 64 + 16 * q + tl;
+            cnt = sp.p_valid[pi];  // 0 for a piece that was overrun
+            off = offsets[slot] + sp.p_rel[pi];
+        } else {
+            const int32_t u = t.perm[slot];
+            cnt = counts[u];
+            off = offsets[u];
+        }
+    }
+    int32_t gmax = cnt;
+    for (int o = 8; o > 0; o >>= 1) {
+        const int32_t v = __shfl_xor(gmax, o, 64);
+        gmax = v > gmax ? v : gmax;
+    }
+    gmax = __shfl(gmax, 0, 64);
+    const int r0 = j << kChunkLog2;
+    if (r0 >= gmax) return;  // none of this wave's 16 tracks reaches the chunk
+    double hx = 0.0, hy = 0.0;  // lanes 0..15: q of the row before this chunk's first
+    if (j > 0 && lane < 16) {
+        const int32_t cp = stg.ctab[w * kMaxChunks + j - 1];
+        const int64_t sidx = ((int64_t)cp * kChunkRows + (kChunkRows - 1)) * 64 + col;
+        hx = stg.qx[sidx]; hy = stg.qy[sidx];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = i * 4 + rr;
+        tx[tl * kC3Pitch + 1 + rl] = vx[i];
+        ty[tl * kC3Pitch + 1 + rl] = vy[i];
+    }
+    if (lane < 16) { tx[tl * kC3Pitch] = hx; ty[tl * kC3Pitch] = hy; }
+    __builtin_amdgcn_wave_barrier();
+    // Pass 1 gathers the records (and fetches the staged p of marked rows) into registers, pass 2 only
+    // stores: a load between the stores would have to wait for every store queued before it.
+    double rpx[8], rpy[8], rqx[8], rqy[8];
+    int32_t re[8];
+    int64_t ro[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int tt = 2 * g + sub;
+        const int32_t ct = __shfl(cnt, tt, 64);
+        const int64_t ot = __shfl(off, tt, 64);
+        const int row = r0 + rowL;
+        ro[g] = row < ct ? ot + row : -1;
+        rqx[g] = tx[tt * kC3Pitch + 1 + rowL]; rqy[g] = ty[tt * kC3Pitch + 1 + rowL];
+        rpx[g] = tx[tt * kC3Pitch + rowL]; rpy[g] = ty[tt * kC3Pitch + rowL];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) te[tl * kC3Pitch + 1 + i * 4 + rr] = ve[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int tt = 2 * g + sub;
+        re[g] = te[tt * kC3Pitch + 1 + rowL];
+        if (ro[g] >= 0 && re[g] < 0) {  // this record keeps its own entry point
+            const int64_t sidx = ((int64_t)c * kChunkRows + rowL) * 64 + 16 * q + tt;
+            rpx[g] = stg.px[sidx]; rpy[g] = stg.py[sidx];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (ro[g] >= 0) {
+            const int64_t o = ro[g];
+            __builtin_nontemporal_store(rpx[g], &out.px[o]);
+            __builtin_nontemporal_store(rpy[g], &out.py[o]);
+            __builtin_nontemporal_store(rqx[g], &out.qx[o]);
+            __builtin_nontemporal_store(rqy[g], &out.qy[o]);
+            __builtin_nontemporal_store(norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]), &out.ell[o]);
+            __builtin_nontemporal_store(re[g] < 0 ? -re[g] : re[g], &out.element[o]);
         }
     }
 }
@@ -834,7 +891,7 @@ struct rt_mesh {
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
     int split = -1;         // track splitting (see DSplit), read by rt_tracks_create: -1 auto (only batches that leave the chip
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
-    int compact_mode = 2;  // 1: k_compact by (chunk, array), 2: k_compact2 by (wave of tracks, array): 64-record runs
+    int compact_mode = 3;  // 3: lean staging (q and cell only) + k_compact3; 2: fully staged rows + k_compact2 (cross-check)
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
@@ -1300,10 +1357,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (want > t->pool_chunks) {
                 const size_t slots = (size_t)want * rt::kChunkRows * 64;
                 RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots));
-                RT_HIP(t->gqy.reserve(slots)); RT_HIP(t->gell.reserve(slots)); RT_HIP(t->gelement.reserve(slots));
+                RT_HIP(t->gqy.reserve(slots)); RT_HIP(t->gelement.reserve(slots));
                 RT_HIP(t->cowner.reserve((size_t)want));
                 t->pool_chunks = want;
             }
+            if (m->compact_mode == 2) RT_HIP(t->gell.reserve((size_t)t->pool_chunks * rt::kChunkRows * 64));  // fully staged rows carry ℓ too
             // the compact records can never outnumber the pool's slots: sizing the outputs by the
             // pool lets march -> scan -> compaction -> volumes run back to back without a host sync
             if (int rc = reserve_out(t->pool_chunks * rt::kChunkRows * 64)) return rc;
@@ -1311,6 +1369,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             stg.qy = as_global(t->gqy.p); stg.ell = as_global(t->gell.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
+            stg.lean = m->compact_mode != 2 ? 1 : 0;
 #ifdef RT_TIMING
             RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
             RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
@@ -1342,15 +1401,27 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
             RT_HIP(hipEventRecord(t->ev[4], s));
-            if (n > 0 && split)
+            // k_compact3 runs one workgroup per chunk; the number of chunks in use is only known on the device, so
+            // the grid covers what the previous call needed (the whole pool the first time) and the few chunks
+            // beyond that, if any, get a second launch once the cursor has been read back
+            const int32_t c3_grid = (int32_t)std::min<int64_t>(stg.pool_chunks, t->chunks_needed_last > 0 ? t->chunks_needed_last + 64 : stg.pool_chunks);
+            auto launch_compact3 = [&](int32_t first, int32_t count) {
+                rt::DStage sg = stg;
+                sg.chunk0 = first;
+                if (split)
+                    hipLaunchKernelGGL(rt::k_compact3<true>, dim3((unsigned)count), dim3(256), 0, s, t->d,
+                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, sg, out, sp);
+                else
+                    hipLaunchKernelGGL(rt::k_compact3<false>, dim3((unsigned)count), dim3(256), 0, s, t->d,
+                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, sg, out, sp);
+            };
+            if (n > 0 && stg.lean) launch_compact3(0, c3_grid);
+            else if (n > 0 && split)
                 hipLaunchKernelGGL(rt::k_compact2<true>, dim3((unsigned)t->n_vwaves, 6), dim3(256), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
-            else if (n > 0 && m->compact_mode == 2)
+            else if (n > 0)
                 hipLaunchKernelGGL(rt::k_compact2<false>, dim3((unsigned)n_waves, 6), dim3(256), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
-            else if (n > 0)
-                hipLaunchKernelGGL(rt::k_compact, dim3((unsigned)stg.pool_chunks, 6), dim3(64), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out);
             RT_HIP(hipEventRecord(t->ev[5], s));
             if (int rc = launch_volumes()) return rc;
             RT_HIP(hipEventRecord(t->ev[6], s));
@@ -1361,6 +1432,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
+            if (!cur[1] && n > 0 && stg.lean && cur[0] > c3_grid) continue;  // more chunks than the compaction grid covered: run again, now sized right
             if (!cur[1]) break;
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
