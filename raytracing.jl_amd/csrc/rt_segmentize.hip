@@ -103,12 +103,18 @@ struct DStage {
     RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
-    int32_t chunk0;         // k_compact3: first chunk of this launch
     int32_t lean;           // 1: rows hold (qx, qy, ±element) only; p is staged just for rows it cannot be derived for
 #ifdef RT_TIMING
     unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
 #endif
 };
+
+// Slot of (row, lane) inside a chunk: quarter-major — the 16 lanes of a quarter-wave keep their 32 rows in
+// one contiguous 4-KB block, so the compaction workgroup of that quarter reads whole lines that nobody
+// else needs; a march store (64 lanes, one row) still writes four full 128-B lines.
+__device__ __forceinline__ int64_t stage_slot(int32_t chunk, int row, int lane) {
+    return (((int64_t)chunk * 4 + (lane >> 4)) * kChunkRows + row) * 16 + (lane & 15);
+}
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
 
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 }
             }
             if (my_chunk >= 0) {
-                const int64_t o = ((int64_t)my_chunk * kChunkRows + r) * 64 + lane;
+                const int64_t o = stage_slot(my_chunk, r, lane);
                 if (stg.lean) {
                     // A walk-step record starts where the lane's previous record ended (p = previous q, bit for
                     // bit) and ℓ = ‖p − q‖ is a function of the two: only q and the cell are staged (20 B instead
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__re
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rl = i * 4 + rr;  // row within the block
-                const int64_t sidx = ((int64_t)cid[rl >> kChunkLog2] * kChunkRows + (rl & (kChunkRows - 1))) * 64 + col;
+                const int64_t sidx = stage_slot(cid[rl >> kChunkLog2], rl & (kChunkRows - 1), (int)col);
                 v[i] = (r0 + rl < gmax) ? __builtin_nontemporal_load(&src[sidx]) : 0.0;
             }
 #pragma unroll
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__re
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rl = i * 4 + rr;
-                const int64_t sidx = ((int64_t)cid[rl >> kChunkLog2] * kChunkRows + (rl & (kChunkRows - 1))) * 64 + col;
+                const int64_t sidx = stage_slot(cid[rl >> kChunkLog2], rl & (kChunkRows - 1), (int)col);
                 v[i] = (r0 + rl < gmax) ? __builtin_nontemporal_load(&stg.element[sidx]) : 0;
             }
 #pragma unroll
@@ -620,47 +626,33 @@ __global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__re
     }
 }
 
-// Lean staging -> compact CSR records, all six arrays in one pass.  One 4-wave workgroup per CHUNK
-// (32 rows x the 64 consecutive tracks of one march wave); each wave takes 16 tracks: (qx, qy,
-// ±element) are read once, coalesced, transposed in wave-private LDS tiles, and every track's 32 rows
-// leave as one run per output array.  p of a row is the q of the row before it (tile column shifted by
-// one; slot 0 holds the last row of the wave's previous chunk) unless the row is marked (element < 0:
-// first record of a track / piece, generic step), in which case the staged p is fetched; ℓ = ‖p − q‖
-// is recomputed with the march's own expression (Segment ctor, src/segment.jl:31-33), so the records
-// are bit-identical to fully staged ones.  20 B read + 44 B written per segment instead of 44 + 44.
-// Every wave issues all its loads, then all its stores: no load is ever queued behind a store of the
-// same wave (gfx950 retires both through one in-order vmcnt queue), and the grid (whole pool;
-// workgroups past the cursor exit) gives the chip tens of thousands of independent waves.
+// Lean staging -> compact CSR records, all six arrays in one pass.  One 4-wave workgroup per
+// (march wave, quarter of its 64 consecutive tracks): wave k moves chunk 4 s + k of the quarter's 16
+// tracks (rows 32 (4 s + k) ..), s = 0, 1, ... — almost always s = 0 only, so the workgroup writes the
+// 16 tracks' whole contiguous span of every output array and the partial cache lines at the ends of a
+// 32-row run are completed by a sibling wave a moment later (run ends shared between workgroups on
+// different XCDs, hence different L2s, cost 30 % of the store rate).  Each wave reads its quarter's
+// 4-KB blocks of (qx, qy, ±cell) once, transposes them in private LDS tiles, derives p (tile column
+// shifted by one row; slot 0 = last row of the previous chunk; staged p for marked rows, element < 0:
+// first record of a track / piece, generic step) and ℓ = ‖p − q‖ with the march's own expression (Segment
+// ctor, src/segment.jl:31-33), so the records are bit-identical to fully staged ones, and writes every
+// track's 32 rows as one run per output array.  20 B read + 44 B written per segment instead of 44 + 44.
+// All loads are issued before the first store: gfx950 retires both through one in-order vmcnt queue.
 constexpr int kC3Pitch = kChunkRows + 4;  // doubles per track in a tile: slot 0 = carry, slots 1..32 = rows
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__restrict__ counts,
                                                   const int64_t *__restrict__ offsets, DStage stg, DOut out, DSplit sp) {
-    static_assert(kChunkRows == 32, "k_compact3 moves one 32-row chunk per workgroup");
+    static_assert(kChunkRows == 32, "k_compact3 moves 32-row chunks");
     __shared__ double tiles_x[4][16 * kC3Pitch];  // 36.9 KB per workgroup: four workgroups per CU
     __shared__ double tiles_y[4][16 * kC3Pitch];
-    const int32_t c = blockIdx.x + stg.chunk0;
-    if (stg.cursor[1] != 0 || c >= stg.cursor[0]) return;  // pool overflow (this attempt is void) / unused chunk
-    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (stg.cursor[1] != 0) return;  // pool overflow: this attempt is void
+    const int64_t w = blockIdx.x >> 2;  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
+    const int q = blockIdx.x & 3;       // quarter: tracks 16 q .. 16 q + 15 of the wave
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr+4, ...
     const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub+2, ...
-    // The chunk's rows are requested at once, before anything is known about their tracks: the chain
-    // cowner -> perm -> counts / offsets (three dependent loads) then runs under the same latency.
-    // Rows nobody wrote are fetched too (in bounds: the pool), and ignored.
-    const int64_t col = 16 * q + tl;
-    double vx[8], vy[8];
-    int32_t ve[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t sidx = ((int64_t)c * kChunkRows + i * 4 + rr) * 64 + col;
-        vx[i] = __builtin_nontemporal_load(&stg.qx[sidx]);
-        vy[i] = __builtin_nontemporal_load(&stg.qy[sidx]);
-        ve[i] = __builtin_nontemporal_load(&stg.element[sidx]);
-    }
-    const int32_t owner = stg.cowner[c];
-    const int64_t w = owner / kMaxChunks;  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
-    const int j = owner % kMaxChunks;      // the wave's j-th chunk: rows 32 j .. 32 j + 31 of its tracks
-    volatile double *tx = tiles_x[q], *ty = tiles_y[q];
-    volatile int32_t *te = reinterpret_cast<volatile int32_t *>(tiles_x[q]);  // the x tile is reused for the cell ids
+    volatile double *tx = tiles_x[k], *ty = tiles_y[k];
+    volatile int32_t *te = reinterpret_cast<volatile int32_t *>(tiles_x[k]);  // the x tile is reused for the cell ids
     const int64_t slot = (SPLIT ? (int64_t)sp.vw_wave[w] : w) * 64 + 16 * q + tl;  // lanes 0..15: their track's count / offset
     int32_t cnt = 0;
     int64_t off = 0;
@@ -681,61 +673,74 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
         gmax = v > gmax ? v : gmax;
     }
     gmax = __shfl(gmax, 0, 64);
-    const int r0 = j << kChunkLog2;
-    if (r0 >= gmax) return;  // none of this wave's 16 tracks reaches the chunk
-    double hx = 0.0, hy = 0.0;  // lanes 0..15: q of the row before this chunk's first
-    if (j > 0 && lane < 16) {
-        const int32_t cp = stg.ctab[w * kMaxChunks + j - 1];
-        const int64_t sidx = ((int64_t)cp * kChunkRows + (kChunkRows - 1)) * 64 + col;
-        hx = stg.qx[sidx]; hy = stg.qy[sidx];
-    }
+    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
+    const int lane_q = 16 * q + tl;  // this lane's column of the march wave (load mapping)
+    for (int j = k; (j << kChunkLog2) < gmax; j += 4) {
+        const int r0 = j << kChunkLog2;
+        const int32_t c = ctab[j];
+        double vx[8], vy[8];
+        int32_t ve[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int rl = i * 4 + rr;
-        tx[tl * kC3Pitch + 1 + rl] = vx[i];
-        ty[tl * kC3Pitch + 1 + rl] = vy[i];
-    }
-    if (lane < 16) { tx[tl * kC3Pitch] = hx; ty[tl * kC3Pitch] = hy; }
-    __builtin_amdgcn_wave_barrier();
-    // Pass 1 gathers the records (and fetches the staged p of marked rows) into registers, pass 2 only
-    // stores: a load between the stores would have to wait for every store queued before it.
-    double rpx[8], rpy[8], rqx[8], rqy[8];
-    int32_t re[8];
-    int64_t ro[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const int tt = 2 * g + sub;
-        const int32_t ct = __shfl(cnt, tt, 64);
-        const int64_t ot = __shfl(off, tt, 64);
-        const int row = r0 + rowL;
-        ro[g] = row < ct ? ot + row : -1;
-        rqx[g] = tx[tt * kC3Pitch + 1 + rowL]; rqy[g] = ty[tt * kC3Pitch + 1 + rowL];
-        rpx[g] = tx[tt * kC3Pitch + rowL]; rpy[g] = ty[tt * kC3Pitch + rowL];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) te[tl * kC3Pitch + 1 + i * 4 + rr] = ve[i];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const int tt = 2 * g + sub;
-        re[g] = te[tt * kC3Pitch + 1 + rowL];
-        if (ro[g] >= 0 && re[g] < 0) {  // this record keeps its own entry point
-            const int64_t sidx = ((int64_t)c * kChunkRows + rowL) * 64 + 16 * q + tt;
-            rpx[g] = stg.px[sidx]; rpy[g] = stg.py[sidx];
+        for (int i = 0; i < 8; ++i) {
+            const int64_t sidx = stage_slot(c, i * 4 + rr, lane_q);
+            vx[i] = __builtin_nontemporal_load(&stg.qx[sidx]);
+            vy[i] = __builtin_nontemporal_load(&stg.qy[sidx]);
+            ve[i] = __builtin_nontemporal_load(&stg.element[sidx]);
         }
-    }
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        if (ro[g] >= 0) {
-            const int64_t o = ro[g];
-            __builtin_nontemporal_store(rpx[g], &out.px[o]);
-            __builtin_nontemporal_store(rpy[g], &out.py[o]);
-            __builtin_nontemporal_store(rqx[g], &out.qx[o]);
-            __builtin_nontemporal_store(rqy[g], &out.qy[o]);
-            __builtin_nontemporal_store(norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]), &out.ell[o]);
-            __builtin_nontemporal_store(re[g] < 0 ? -re[g] : re[g], &out.element[o]);
+        double hx = 0.0, hy = 0.0;  // lanes 0..15: q of the row before this chunk's first
+        if (j > 0 && lane < 16) {
+            const int64_t sidx = stage_slot(ctab[j - 1], kChunkRows - 1, lane_q);
+            hx = stg.qx[sidx]; hy = stg.qy[sidx];
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = i * 4 + rr;
+            tx[tl * kC3Pitch + 1 + rl] = vx[i];
+            ty[tl * kC3Pitch + 1 + rl] = vy[i];
+        }
+        if (lane < 16) { tx[tl * kC3Pitch] = hx; ty[tl * kC3Pitch] = hy; }
+        __builtin_amdgcn_wave_barrier();
+        // Pass 1 gathers the records (and fetches the staged p of marked rows) into registers, pass 2 only
+        // stores: a load between the stores would have to wait for every store queued before it.
+        double rpx[8], rpy[8], rqx[8], rqy[8];
+        int32_t re[8];
+        int64_t ro[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int tt = 2 * g + sub;
+            const int32_t ct = __shfl(cnt, tt, 64);
+            const int64_t ot = __shfl(off, tt, 64);
+            const int row = r0 + rowL;
+            ro[g] = row < ct ? ot + row : -1;
+            rqx[g] = tx[tt * kC3Pitch + 1 + rowL]; rqy[g] = ty[tt * kC3Pitch + 1 + rowL];
+            rpx[g] = tx[tt * kC3Pitch + rowL]; rpy[g] = ty[tt * kC3Pitch + rowL];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) te[tl * kC3Pitch + 1 + i * 4 + rr] = ve[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int tt = 2 * g + sub;
+            re[g] = te[tt * kC3Pitch + 1 + rowL];
+            if (ro[g] >= 0 && re[g] < 0) {  // this record keeps its own entry point
+                const int64_t sidx = stage_slot(c, rowL, 16 * q + tt);
+                rpx[g] = stg.px[sidx]; rpy[g] = stg.py[sidx];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (ro[g] >= 0) {
+                const int64_t o = ro[g];
+                __builtin_nontemporal_store(rpx[g], &out.px[o]);
+                __builtin_nontemporal_store(rpy[g], &out.py[o]);
+                __builtin_nontemporal_store(rqx[g], &out.qx[o]);
+                __builtin_nontemporal_store(rqy[g], &out.qy[o]);
+                __builtin_nontemporal_store(norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]), &out.ell[o]);
+                __builtin_nontemporal_store(re[g] < 0 ? -re[g] : re[g], &out.element[o]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
     }
 }
 
@@ -1401,21 +1406,12 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
             RT_HIP(hipEventRecord(t->ev[4], s));
-            // k_compact3 runs one workgroup per chunk; the number of chunks in use is only known on the device, so
-            // the grid covers what the previous call needed (the whole pool the first time) and the few chunks
-            // beyond that, if any, get a second launch once the cursor has been read back
-            const int32_t c3_grid = (int32_t)std::min<int64_t>(stg.pool_chunks, t->chunks_needed_last > 0 ? t->chunks_needed_last + 64 : stg.pool_chunks);
-            auto launch_compact3 = [&](int32_t first, int32_t count) {
-                rt::DStage sg = stg;
-                sg.chunk0 = first;
-                if (split)
-                    hipLaunchKernelGGL(rt::k_compact3<true>, dim3((unsigned)count), dim3(256), 0, s, t->d,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, sg, out, sp);
-                else
-                    hipLaunchKernelGGL(rt::k_compact3<false>, dim3((unsigned)count), dim3(256), 0, s, t->d,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, sg, out, sp);
-            };
-            if (n > 0 && stg.lean) launch_compact3(0, c3_grid);
+            if (n > 0 && stg.lean && split)
+                hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
+            else if (n > 0 && stg.lean)
+                hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_waves), dim3(256), 0, s, t->d,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
             else if (n > 0 && split)
                 hipLaunchKernelGGL(rt::k_compact2<true>, dim3((unsigned)t->n_vwaves, 6), dim3(256), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
@@ -1432,7 +1428,6 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
-            if (!cur[1] && n > 0 && stg.lean && cur[0] > c3_grid) continue;  // more chunks than the compaction grid covered: run again, now sized right
             if (!cur[1]) break;
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
