@@ -732,12 +732,14 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
         for (int g = 0; g < 8; ++g) {
             if (ro[g] >= 0) {
                 const int64_t o = ro[g];
-                __builtin_nontemporal_store(rpx[g], &out.px[o]);
-                __builtin_nontemporal_store(rpy[g], &out.py[o]);
-                __builtin_nontemporal_store(rqx[g], &out.qx[o]);
-                __builtin_nontemporal_store(rqy[g], &out.qy[o]);
-                __builtin_nontemporal_store(norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]), &out.ell[o]);
-                __builtin_nontemporal_store(re[g] < 0 ? -re[g] : re[g], &out.element[o]);
+                // plain stores: the partial lines at the ends of a run wait in L2 for the sibling wave's half
+                // (nontemporal stores push them out half-written: +30 % compaction time)
+                out.px[o] = rpx[g];
+                out.py[o] = rpy[g];
+                out.qx[o] = rqx[g];
+                out.qy[o] = rqy[g];
+                out.ell[o] = norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]);
+                out.element[o] = re[g] < 0 ? -re[g] : re[g];
             }
         }
         __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
