@@ -1178,8 +1178,9 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     // split plan: pieces per wave of 64 consecutive uids, canonical numbering, dispatch order
     std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P;
     // Splitting pays when the batch has too few waves to fill the chip (the march is then bound by its
-    // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420); on full batches the march is
-    // throughput-bound at 2 waves/SIMD and the pieces' fixed costs make it slower (+20 % at 130 k tracks).
+    // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420); a batch that already occupies the
+    // 2,048 wave slots of the 180-VGPR kernel only gets more waves that must queue, and the pieces'
+    // fixed costs make the step slower (+20 % at 130 k tracks).
     const size_t nw_all = (n + 63) / 64;
     const bool auto_split = mesh->split < 0 && nw_all < 1536;
     const int p_auto = auto_split ? (int)std::min<size_t>(16, (2048 + nw_all - 1) / std::max<size_t>(1, nw_all)) : 1;
