@@ -146,9 +146,13 @@ class OracleMesh:
             out[name] = np.zeros(total, np.float64)
         out["element"] = np.zeros(total, np.int32)
         self._lib.orc_fetch(self._h, out["px"], out["py"], out["qx"], out["qy"], out["ell"], out["element"])
+        self._last_total = int(total)
         return out
 
     def fill_volumes(self, offsets, azim_idx, delta_s, n_azim_2):
+        """fill_volumes over the segments of this handle's LAST segmentize (they live inside the C handle)."""
+        if getattr(self, "_last_total", None) is None or int(offsets[-1]) != self._last_total:
+            raise RuntimeError("fill_volumes: call segmentize on this OracleMesh first (offsets must be that run's)")
         vol = np.zeros(self.n_cells)
         self._lib.orc_fill_volumes(self._h, len(azim_idx), np.ascontiguousarray(offsets, np.int64),
                                    np.ascontiguousarray(azim_idx, np.int32),
