@@ -97,13 +97,13 @@ constexpr int kChunkRows = 1 << kChunkLog2;
 constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
 
 struct DStage {
-    RT_G double *px, *py, *qx, *qy, *ell;
+    RT_G double *qx, *qy;   // exit point of every record
+    RT_G double *px, *py;   // entry point, only for records whose element is staged negative (see k_march)
     RT_G int32_t *element;
     RT_G int32_t *ctab;     // [n_waves][kMaxChunks] chunk ids
     RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
-    int32_t lean;           // 1: rows hold (qx, qy, ±element) only; p is staged just for rows it cannot be derived for
 #ifdef RT_TIMING
     unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
 #endif
@@ -478,20 +478,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             if (my_chunk >= 0) {
                 const int64_t o = stage_slot(my_chunk, r, lane);
-                if (stg.lean) {
-                    // A walk-step record starts where the lane's previous record ended (p = previous q, bit for
-                    // bit) and ℓ = ‖p − q‖ is a function of the two: only q and the cell are staged (20 B instead
-                    // of 44) and k_compact3 rebuilds p and ℓ.  Records of the generic step / a seed keep their
-                    // own p and are marked by a negative element.
-                    const bool derived = res == kWalkEmit && !from_seed;
-                    stg.qx[o] = qx; stg.qy[o] = qy;
-                    stg.element[o] = derived ? element + 1 : -(element + 1);
-                    if (!derived) { stg.px[o] = px; stg.py[o] = py; }
-                } else {
-                    stg.px[o] = px; stg.py[o] = py; stg.qx[o] = qx; stg.qy[o] = qy;
-                    stg.ell[o] = ell;
-                    stg.element[o] = element + 1;
-                }
+                // A walk-step record starts where the lane's previous record ended (p = previous q, bit for
+                // bit) and ℓ = ‖p − q‖ is a function of the two: only q and the cell are staged (20 B instead
+                // of 44) and k_compact3 rebuilds p and ℓ.  Records of the generic step / a seed keep their
+                // own p and are marked by a negative element.
+                const bool derived = res == kWalkEmit && !from_seed;
+                stg.qx[o] = qx; stg.qy[o] = qy;
+                stg.element[o] = derived ? element + 1 : -(element + 1);
+                if (!derived) { stg.px[o] = px; stg.py[o] = py; }
             }
             if (FUSE) atomicAdd(&hist[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
         }
@@ -536,92 +530,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) {
             const double v = hist[c];
             if (v != 0.0) unsafeAtomicAdd((double *)&out.volumes[c], v);
-        }
-    }
-}
-
-// Fully staged rows (compact_mode 2, kept as the cross-check of the lean path): compaction by (wave of
-// tracks, array).  A 4-wave workgroup owns the 64 consecutive tracks of one march wave for one array;
-// each of its waves takes 16 tracks, gathers their columns of 64 staging rows at a time, transposes
-// them in a private LDS tile and writes every track's rows as one run of up to 64 consecutive records.
-constexpr int kC2Pitch = 68;
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_compact2(DTracks t, const int32_t *__restrict__ counts,
-                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out, DSplit sp) {
-    __shared__ double tiles[4][16 * kC2Pitch];
-    if (stg.cursor[1] != 0) return;  // pool overflow: this attempt is void
-    const int64_t w = blockIdx.x;  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
-    const int a = blockIdx.y;
-    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tl = lane & 15, rr = lane >> 4;
-    volatile double *tile = tiles[q];
-    volatile int32_t *itile = reinterpret_cast<volatile int32_t *>(tiles[q]);
-    // counts / offsets of this wave's 16 tracks live in lanes 0..15
-    const int64_t slot = (SPLIT ? (int64_t)sp.vw_wave[w] : w) * 64 + 16 * q + tl;
-    int32_t cnt = 0;
-    int64_t off = 0;
-    if (slot < t.n) {
-        if (SPLIT) {
-            const int64_t pi = w * 64 + 16 * q + tl;
-            cnt = sp.p_valid[pi];               // 0 for a piece that was overrun
-            off = offsets[slot] + sp.p_rel[pi];
-        } else {
-            const int32_t u = t.perm[slot];
-            cnt = counts[u];
-            off = offsets[u];
-        }
-    }
-    int32_t gmax = cnt;
-    for (int o = 8; o > 0; o >>= 1) {
-        const int32_t v = __shfl_xor(gmax, o, 64);
-        gmax = v > gmax ? v : gmax;
-    }
-    gmax = __shfl(gmax, 0, 64);
-    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
-    const int64_t col = 16 * q + tl;
-    for (int r0 = 0; r0 < gmax; r0 += 64) {
-        // the 64 rows of this block live in (at most) 64 / kChunkRows chunks of the wave's list
-        int32_t cid[64 / kChunkRows];
-#pragma unroll
-        for (int k = 0; k < 64 / kChunkRows; ++k) cid[k] = (r0 + k * kChunkRows < gmax) ? ctab[(r0 >> kChunkLog2) + k] : 0;
-        if (a < 5) {
-            const RT_G double *src = a == 0 ? stg.px : a == 1 ? stg.py : a == 2 ? stg.qx : a == 3 ? stg.qy : stg.ell;
-            RT_G double *dst = a == 0 ? out.px : a == 1 ? out.py : a == 2 ? out.qx : a == 3 ? out.qy : out.ell;
-            double v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rl = i * 4 + rr;  // row within the block
-                const int64_t sidx = stage_slot(cid[rl >> kChunkLog2], rl & (kChunkRows - 1), (int)col);
-                v[i] = (r0 + rl < gmax) ? __builtin_nontemporal_load(&src[sidx]) : 0.0;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tile[tl * kC2Pitch + i * 4 + rr] = v[i];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int tt = 0; tt < 16; ++tt) {
-                const int32_t ct = __shfl(cnt, tt, 64);
-                const int64_t ot = __shfl(off, tt, 64);
-                if (r0 + lane < ct) __builtin_nontemporal_store(tile[tt * kC2Pitch + lane], &dst[ot + r0 + lane]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            int32_t v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rl = i * 4 + rr;
-                const int64_t sidx = stage_slot(cid[rl >> kChunkLog2], rl & (kChunkRows - 1), (int)col);
-                v[i] = (r0 + rl < gmax) ? __builtin_nontemporal_load(&stg.element[sidx]) : 0;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) itile[tl * kC2Pitch + i * 4 + rr] = v[i];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int tt = 0; tt < 16; ++tt) {
-                const int32_t ct = __shfl(cnt, tt, 64);
-                const int64_t ot = __shfl(off, tt, 64);
-                if (r0 + lane < ct) __builtin_nontemporal_store(itile[tt * kC2Pitch + lane], &out.element[ot + r0 + lane]);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -898,7 +806,6 @@ struct rt_mesh {
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
     int split = -1;         // track splitting (see DSplit), read by rt_tracks_create: -1 auto (only batches that leave the chip
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
-    int compact_mode = 3;  // 3: lean staging (q and cell only) + k_compact3; 2: fully staged rows + k_compact2 (cross-check)
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
@@ -925,7 +832,7 @@ struct rt_tracks {
     unsigned long long *h_ctl = nullptr;  // pinned: [0..31] init image, [32..63] read-back
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
     // staging pool of the single-pass march
-    DevBuf<double> gpx, gpy, gqx, gqy, gell;
+    DevBuf<double> gpx, gpy, gqx, gqy;
     DevBuf<int32_t> gelement, ctab, cowner;
     int64_t pool_chunks = 0, chunks_needed_last = 0;
     // split mode (pieces of tracks)
@@ -1026,7 +933,7 @@ void free_tracks(rt_tracks *t) {
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->delta_s.release();
-    t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release(); t->gell.release();
+    t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
     t->gelement.release(); t->ctab.release(); t->cowner.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
     t->s_el.release(); t->s_eq.release(); t->p_count.release(); t->p_flags.release(); t->p_valid.release(); t->p_rel.release();
@@ -1129,7 +1036,6 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "volumes_mode")) { mesh->volumes_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
-    if (!strcmp(name, "compact_mode")) { mesh->compact_mode = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
@@ -1369,15 +1275,13 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                 RT_HIP(t->cowner.reserve((size_t)want));
                 t->pool_chunks = want;
             }
-            if (m->compact_mode == 2) RT_HIP(t->gell.reserve((size_t)t->pool_chunks * rt::kChunkRows * 64));  // fully staged rows carry ℓ too
             // the compact records can never outnumber the pool's slots: sizing the outputs by the
             // pool lets march -> scan -> compaction -> volumes run back to back without a host sync
             if (int rc = reserve_out(t->pool_chunks * rt::kChunkRows * 64)) return rc;
             stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
-            stg.qy = as_global(t->gqy.p); stg.ell = as_global(t->gell.p); stg.element = as_global(t->gelement.p);
+            stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
-            stg.lean = m->compact_mode != 2 ? 1 : 0;
 #ifdef RT_TIMING
             RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
             RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
@@ -1409,17 +1313,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (int rc = scan_counts()) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));
             RT_HIP(hipEventRecord(t->ev[4], s));
-            if (n > 0 && stg.lean && split)
+            if (n > 0 && split)
                 hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
-            else if (n > 0 && stg.lean)
-                hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_waves), dim3(256), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
-            else if (n > 0 && split)
-                hipLaunchKernelGGL(rt::k_compact2<true>, dim3((unsigned)t->n_vwaves, 6), dim3(256), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
             else if (n > 0)
-                hipLaunchKernelGGL(rt::k_compact2<false>, dim3((unsigned)n_waves, 6), dim3(256), 0, s, t->d,
+                hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_waves), dim3(256), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
             RT_HIP(hipEventRecord(t->ev[5], s));
             if (int rc = launch_volumes()) return rc;
