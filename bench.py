@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 KERNELS = {
     "march": ("rt::k_march<2, 4, false>", 45.0),   # single-pass staged march, fill_volumes fused (LDS-private)
     "compact": ("rt::k_compact3<false>", 64.0),
-    "volumes": ("rt::k_scale_volumes", 0.0),  # volumes ./= n_azim_2 (the accumulation is fused into the march)
+    "scan": ("rt::k_scan_write", 0.0),  # three small kernels: CSR offsets of the counts; volumes ./= n_azim_2 rides along
 }
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
 

@@ -677,8 +677,21 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
     }
 }
 
+// Start of a call: the control block (failure summary, total, pool cursor) and `volumes` are reset by one
+// small kernel instead of a host-to-device copy and a memset.
+__global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 32) ctl[i] = i == 1 ? ~0ull : 0ull;  // [1]: first failing uid, an atomicMin target
+    if (i < n_cells) volumes[i] = 0.0;
+}
+
+// host_copy (optional): pinned host memory that receives the 32-word control block — the march (and
+// k_resolve) are done when this single workgroup runs, so `total`, the failure summary and the pool cursor
+// are final and the call needs no device-to-host copy after its last kernel.
 __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t *__restrict__ tile_sums, int64_t n_tiles,
-                                                     int64_t *__restrict__ total) {
+                                                     int64_t *__restrict__ total,
+                                                     const unsigned long long *__restrict__ ctl,
+                                                     unsigned long long *__restrict__ host_copy) {
     __shared__ int64_t buf[1024];
     __shared__ int64_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -700,12 +713,23 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t *__restrict__ tile_
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
+    if (host_copy) {
+        __syncthreads();
+        __threadfence();
+        if (threadIdx.x < 32) host_copy[threadIdx.x] = __builtin_nontemporal_load(&ctl[threadIdx.x]);
+    }
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__restrict__ counts, int64_t n,
                                                            const int64_t *__restrict__ tile_offsets,
                                                            const int64_t *__restrict__ total,
-                                                           int64_t *__restrict__ offsets) {
+                                                           int64_t *__restrict__ offsets,
+                                                           double *__restrict__ volumes, int32_t n_cells,
+                                                           double n_azim_2) {
+    // volumes ./= n_azim_2 (src/trackgenerator.jl:386) rides along when fill_volumes was fused into the march
+    if (volumes)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += gridDim.x * blockDim.x)
+            volumes[c] = volumes[c] / n_azim_2;
     __shared__ int64_t wsum[kScanBlock / 64];
     const int64_t i0 = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
     int64_t c[kScanPer];
@@ -1178,6 +1202,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     int64_t *const d_total = reinterpret_cast<int64_t *>(t->ctl.p + 16);
     int32_t *const d_cursor = reinterpret_cast<int32_t *>(t->ctl.p + 18);
     unsigned long long *const h_res = t->h_ctl + 32;
+    unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tiles writes it)
+    RT_HIP(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
     RT_HIP(t->volumes.reserve(m->n_cells));
     if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
         t->h_delta_s.assign(delta_s, delta_s + n_azim_2);
@@ -1207,13 +1233,17 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     unsigned long long fi[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float f = 0;
 
-    auto scan_counts = [&]() -> int {
+    // copy_out: k_scan_tiles also writes the control block to the pinned host copy; scale: k_scan_write also
+    // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
+    auto scan_counts = [&](bool copy_out, bool scale) -> int {
         if (n > 0) {
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p);
-            hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, d_total);
+            hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, d_total,
+                               (const unsigned long long *)t->ctl.p, copy_out ? h_res_dev : (unsigned long long *)nullptr);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
-                               t->tile_sums.p, d_total, t->offsets.p);
+                               t->tile_sums.p, d_total, t->offsets.p, scale ? t->volumes.p : (double *)nullptr, m->n_cells,
+                               (double)n_azim_2);
         } else {
             RT_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
             RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
@@ -1230,6 +1260,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     };
     // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
     bool fused_volumes_this_call = false;
+    bool volumes_pass = true;  // false: fill_volumes rode along with the march and the scan, no ev[6]
     auto launch_volumes = [&]() -> int {
         if (m->volumes_mode == 2 && n > 0 && !fused_volumes_this_call) {
             const int64_t want_blocks = 512;
@@ -1247,13 +1278,14 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                                (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds,
                                m->single_pass ? (const int32_t *)(d_cursor + 1) : (const int32_t *)nullptr);
         }
-        hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
-                           m->n_cells, (double)n_azim_2);
+        if (!(fused_volumes_this_call && n > 0))  // the fused path scales inside k_scan_write
+            hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
+                               m->n_cells, (double)n_azim_2);
         return RT_SUCCESS;
     };
 
     RT_HIP(hipEventRecord(t->ev[0], s));
-    RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+    if (!m->single_pass) RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
     if (m->single_pass) {
         // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
         //      (or from what the previous call needed) and grown + re-run on overflow
@@ -1287,8 +1319,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
             stg.dbg = t->dbg.p;
 #endif
-            RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-            RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+            hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, 32) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
+                               t->volumes.p, m->n_cells);
             RT_HIP(hipEventRecord(t->ev[1], s));
             if (n > 0 && split) {
                 hipLaunchKernelGGL(rt::k_seed, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
@@ -1310,9 +1342,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                 }
             }
             RT_HIP(hipEventRecord(t->ev[2], s));
-            if (int rc = scan_counts()) return rc;
-            RT_HIP(hipEventRecord(t->ev[3], s));
-            RT_HIP(hipEventRecord(t->ev[4], s));
+            if (int rc = scan_counts(true, fuse)) return rc;
+            RT_HIP(hipEventRecord(t->ev[3], s));  // every event record costs ≈4 µs of stream time: none is recorded twice
             if (n > 0 && split)
                 hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
@@ -1321,9 +1352,10 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                                    (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
             RT_HIP(hipEventRecord(t->ev[5], s));
             if (int rc = launch_volumes()) return rc;
-            RT_HIP(hipEventRecord(t->ev[6], s));
+            volumes_pass = !(fuse && n > 0);
+            if (volumes_pass) RT_HIP(hipEventRecord(t->ev[6], s));
             int32_t cur[4] = {0, 0, 0, 0};
-            RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             RT_HIP(hipStreamSynchronize(s));
             memcpy(fi, h_res, sizeof(fi));
             memcpy(&total, h_res + 16, sizeof(total));
@@ -1340,7 +1372,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             hipLaunchKernelGGL((rt::k_march<rt::kCount, 1, false>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
                                t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
         RT_HIP(hipEventRecord(t->ev[2], s));
-        if (int rc = scan_counts()) return rc;
+        if (int rc = scan_counts(false, false)) return rc;
         RT_HIP(hipEventRecord(t->ev[3], s));
         RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RT_HIP(hipStreamSynchronize(s));
@@ -1357,11 +1389,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         RT_HIP(hipStreamSynchronize(s));
     }
     RT_HIP(hipGetLastError());
-    RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[6])); t->ms[0] = f;   // whole call, device side
+    RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
     RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
-    RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan
-    RT_HIP(hipEventElapsedTime(&f, t->ev[4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
-    RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f;   // volumes
+    RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan (+ volumes ./= n_azim_2 when fused)
+    RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 3 : 4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
+    if (volumes_pass) { RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f; }   // volumes as its own pass
 #ifdef RT_TIMING
     if (const char *path = getenv("RT_TIMING_DUMP")) {
         if (t->dbg.p) {
