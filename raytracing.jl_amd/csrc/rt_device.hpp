@@ -40,11 +40,10 @@ struct __attribute__((aligned(128))) WalkRec {
 static_assert(sizeof(WalkRec) == 128, "WalkRec layout");
 
 // Flattened mesh in HBM (SoA; all ids 0-based on the device, converted at upload).
-struct DMesh {
-    const RT_G WalkRec *wrec;    // [3*n_cells] rotated walk records
-    const RT_G int32_t *adjr;    // [3*n_cells] record index reached across edge k of cell c; -1 on the boundary
-    double eps_iso, d_vertex, l_min;     // certificate margins of the walk step
-    int32_t walk_ok;
+// What only the generic step reads (locate + intersections): kept behind a pointer in constant address space,
+// so that the march loop, which runs the walk step >99.9 % of the time, does not hold ~30 SGPRs of pointers
+// and grid parameters it never uses there (the kernel was spilling SGPRs to VGPR lanes in its hot path).
+struct DGeo {
     const RT_G double *x;        // [n_nodes]
     const RT_G double *y;        // [n_nodes]
     const RT_G int32_t *cn;      // [3*n_cells] cell -> nodes, reference order
@@ -54,9 +53,28 @@ struct DMesh {
     const RT_G int32_t *gnode;   // node ids grouped by bucket
     double gx0, gy0, gh, ginv;   // grid origin, bucket size and its inverse
     int32_t gnx, gny;
-    double bx0, by0, bx1, by1;   // bounding box (bb_min, bb_max)
-    int32_t n_nodes, n_cells;
+    int32_t n_nodes, pad_;
 };
+#define RT_K __attribute__((address_space(4)))
+
+struct DMesh {
+    const RT_G WalkRec *wrec;    // [3*n_cells] rotated walk records
+    const RT_G int32_t *adjr;    // [3*n_cells] record index reached across edge k of cell c; -1 on the boundary
+    double eps_iso, d_vertex, l_min;     // certificate margins of the walk step
+    int32_t walk_ok;
+    int32_t n_cells;
+    double bx0, by0, bx1, by1;   // bounding box (bb_min, bb_max)
+    const RT_K DGeo *geo;        // device copy of the generic step's data
+};
+
+// The generic step's data, fetched with scalar loads where it is needed.
+__device__ __forceinline__ DGeo load_geo(const RT_K DGeo *p) {
+    DGeo g;
+    g.x = p->x; g.y = p->y; g.cn = p->cn; g.ncp = p->ncp; g.ncd = p->ncd; g.gstart = p->gstart; g.gnode = p->gnode;
+    g.gx0 = p->gx0; g.gy0 = p->gy0; g.gh = p->gh; g.ginv = p->ginv;
+    g.gnx = p->gnx; g.gny = p->gny; g.n_nodes = p->n_nodes; g.pad_ = 0;
+    return g;
+}
 
 // Per-track inputs in HBM (SoA, uid order) + the march order.
 struct DTracks {
@@ -115,7 +133,7 @@ __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, d
 // src/mesh.jl:158-176: λ = [x1 x2 x3; y1 y2 y3; 1 1 1] \ [x, y, 1] by the closed form
 // StaticArrays uses for 3x3 (cofactors / det, det = col1 · (col2 × col3)); inside iff every
 // λ ∈ [0 - tol, 1 + tol], tol = sqrt(eps).
-__device__ __forceinline__ bool point_in_triangle(const DMesh &m, int32_t cell, double x, double y) {
+__device__ __forceinline__ bool point_in_triangle(const DGeo &m, int32_t cell, double x, double y) {
     const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
     const double x1 = m.x[n1], y1 = m.y[n1];
     const double x2 = m.x[n2], y2 = m.y[n2];
@@ -151,7 +169,7 @@ __device__ __forceinline__ void kbest_push(KBest &b, double d2, int32_t id) {
 
 // Lower bound on the distance from (qx,qy) to any node outside the visited block of buckets
 // [ix-r, ix+r] x [iy-r, iy+r]; +inf once the block covers the whole grid.
-__device__ __forceinline__ double ring_bound(const DMesh &m, double qx, double qy, int ix, int iy, int r) {
+__device__ __forceinline__ double ring_bound(const DGeo &m, double qx, double qy, int ix, int iy, int r) {
     const double inf = __builtin_huge_val();
     double lb = inf;
     if (ix - r > 0) lb = fmin(lb, qx - (m.gx0 + (double)(ix - r) * m.gh));
@@ -161,7 +179,7 @@ __device__ __forceinline__ double ring_bound(const DMesh &m, double qx, double q
     return lb;
 }
 
-__device__ __forceinline__ void bucket_of(const DMesh &m, double qx, double qy, int &ix, int &iy) {
+__device__ __forceinline__ void bucket_of(const DGeo &m, double qx, double qy, int &ix, int &iy) {
     double fx = floor((qx - m.gx0) * m.ginv), fy = floor((qy - m.gy0) * m.ginv);
     fx = fx < 0.0 ? 0.0 : fx;
     fy = fy < 0.0 ? 0.0 : fy;
@@ -170,7 +188,7 @@ __device__ __forceinline__ void bucket_of(const DMesh &m, double qx, double qy, 
 }
 
 // nn(kdtree, x): the nearest node (0-based id).
-__device__ __forceinline__ int32_t nearest_node(const DMesh &m, double qx, double qy) {
+__device__ __forceinline__ int32_t nearest_node(const DGeo &m, double qx, double qy) {
     int ix, iy;
     bucket_of(m, qx, qy, ix, iy);
     double best = __builtin_huge_val();
@@ -206,7 +224,7 @@ __device__ __forceinline__ int32_t nearest_node(const DMesh &m, double qx, doubl
 }
 
 // knn(kdtree, x, k, true, i -> i == skip): the k nearest nodes other than `skip`, ascending.
-__device__ __noinline__ void knearest_nodes(const DMesh &m, double qx, double qy, int k, int32_t skip, KBest &kb) {
+__device__ __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int k, int32_t skip, KBest &kb) {
     kb.n = 0;
     kb.k = k > kMaxK ? kMaxK : k;
     if (kb.k <= 0) return;
@@ -240,7 +258,7 @@ __device__ __noinline__ void knearest_nodes(const DMesh &m, double qx, double qy
     }
 }
 
-__device__ __forceinline__ int32_t first_cell_containing(const DMesh &m, int32_t node, double x, double y) {
+__device__ __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node, double x, double y) {
     for (int32_t s = m.ncp[node]; s < m.ncp[node + 1]; ++s) {
         const int32_t c = m.ncd[s];
         if (point_in_triangle(m, c, x, y)) return c;
@@ -252,7 +270,7 @@ __device__ __forceinline__ int32_t first_cell_containing(const DMesh &m, int32_t
 // followed, on failure, by find_element(mesh, xp, k) (src/track.jl:122,139).  The second
 // call repeats the first one's tests and then looks at nodes 3..k of the same sorted list,
 // so one sorted list of max(2,k) nodes serves both.
-__device__ __noinline__ int32_t find_element_fallback(const DMesh &m, double x, double y, int k, int32_t nn_id) {
+__device__ __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double y, int k, int32_t nn_id) {
     KBest kb;
     const int kk = k > 2 ? k : 2;
     knearest_nodes(m, x, y, kk, nn_id, kb);
@@ -270,7 +288,7 @@ __device__ __noinline__ int32_t find_element_fallback(const DMesh &m, double x, 
 }
 
 // find_element (src/mesh.jl:103-146), 0-based cell id or -1.
-__device__ __forceinline__ int32_t find_element(const DMesh &m, double x, double y, int k) {
+__device__ __forceinline__ int32_t find_element(const DGeo &m, double x, double y, int k) {
     const int32_t nn_id = nearest_node(m, x, y);
     if (nn_id < 0) return -1;
     const int32_t c = first_cell_containing(m, nn_id, x, y);
@@ -318,7 +336,7 @@ __device__ __forceinline__ bool order_points(double phi, double x1, double y1, d
 // branch in which the reference reads an unassigned variable (n_int == 3, all coincident).
 // `eq` receives the index (0..2) of the cell edge the exit point q lies on (-1 if q was not
 // produced): the walk step uses it to predict the next cell through the adjacency table.
-__device__ __forceinline__ bool intersections(const DMesh &m, int32_t cell, double phi, double tA, double tB,
+__device__ __forceinline__ bool intersections(const DGeo &m, int32_t cell, double phi, double tA, double tB,
                                               double tC, double &px, double &py, double &qx, double &qy, int &eq) {
     eq = -1;
     const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
@@ -371,7 +389,7 @@ struct GenericOut {
     double px, py, qx, qy, ell;
     int32_t element, eq;
 };
-__device__ __noinline__ int generic_step(const DMesh &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
+__device__ __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
                                          double tA, double tB, double tC, GenericOut &o) {
     const int32_t element = find_element(m, xpx, xpy, k);  // src/track.jl:122 and :138-139
     o.element = element;

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64) void k_seed(DMesh m, DTracks t, DParams prm, DS
     GenericOut go;
     go.eq = -1;
     if (!inboundary(m, mx, my, prm.tiny_step)) {
-        const int rc = generic_step(m, mx, my, prm.k, -1, t.phi[u], t.A[u], t.B[u], t.C[u], go);
+        const DGeo g = load_geo(m.geo);
+        const int rc = generic_step(g, mx, my, prm.k, -1, t.phi[u], t.A[u], t.B[u], t.C[u], go);
         // Any genuine segment of the track near M will do: whether the march really produces it is
         // checked bit for bit by the piece that arrives there (k_march), not assumed here.
         if (rc == 0 && go.eq >= 0 && go.ell >= m.l_min) el = go.element;
@@ -396,8 +397,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         if (__ballot(res == kWalkGeneric)) ++wgen;
 #endif
         if (res == kWalkGeneric) {
+            const DGeo g = load_geo(m.geo);  // scalar loads, here only: the generic step's pointers and grid parameters
 #ifndef RT_GENERIC_OUTOFLINE  // out-of-line generic step + RT_SPECULATE: -4 % (pincell) / +4 % (BWR-like); off
-            element = find_element(m, xpx, xpy, prm.k);               // :122 and :138-139
+            element = find_element(g, xpx, xpy, prm.k);               // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
             if (element == prev_element) {  // :147-150
                 xpx = xpx + sx; xpy = xpy + sy;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 // in the same cell again for hundreds of tiny steps (BWR-like config 4: 229 in a row).
                 // Each pass stands for one march iteration ending in this `continue`; only the
                 // reference's own locate is repeated, not the walk step that cannot certify here.
-                while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && find_element(m, xpx, xpy, prm.k) == prev_element) {
+                while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && find_element(g, xpx, xpy, prm.k) == prev_element) {
                     ++it;
                     xpx = xpx + sx; xpy = xpy + sy;
                 }
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 continue;
             }
             int eq;
-            if (!intersections(m, element, phi, tA, tB, tC, px, py, qx, qy, eq)) {  // :153
+            if (!intersections(g, element, phi, tA, tB, tC, px, py, qx, qy, eq)) {  // :153
                 st = RT_TRACK_UNDEF_INTERSECTION;
                 break;
             }
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
 #else
             GenericOut go;
-            const int rc = generic_step(m, xpx, xpy, prm.k, prev_element, phi, tA, tB, tC, go);
+            const int rc = generic_step(g, xpx, xpy, prm.k, prev_element, phi, tA, tB, tC, go);
             if (rc == 2) { st = RT_TRACK_LOCATE_FAILED; break; }
             if (rc == 3) { st = RT_TRACK_UNDEF_INTERSECTION; break; }
             if (rc == 1) { xpx = xpx + sx; xpy = xpy + sy; continue; }
@@ -823,6 +825,7 @@ struct rt_mesh {
     DevBuf<int32_t> cn, ncp, ncd, gstart, gnode;
     DevBuf<rt::WalkRec> wrec;
     DevBuf<int32_t> adjr;
+    DevBuf<rt::DGeo> geo;
     rt::DMesh d{};
     int64_t iter_cap = 4000000;
     bool walk_available = false;
@@ -926,11 +929,16 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     m->n_cells = n_cells;
     rt::DMesh &d = m->d;
     using rt::as_global;
-    d.x = as_global(m->x.p); d.y = as_global(m->y.p); d.cn = as_global(m->cn.p); d.ncp = as_global(m->ncp.p);
-    d.ncd = as_global(m->ncd.p); d.gstart = as_global(m->gstart.p); d.gnode = as_global(m->gnode.p);
-    d.gx0 = bb[0]; d.gy0 = bb[1]; d.gh = gh; d.ginv = ginv; d.gnx = gnx; d.gny = gny;
+    rt::DGeo g{};
+    g.x = as_global(m->x.p); g.y = as_global(m->y.p); g.cn = as_global(m->cn.p); g.ncp = as_global(m->ncp.p);
+    g.ncd = as_global(m->ncd.p); g.gstart = as_global(m->gstart.p); g.gnode = as_global(m->gnode.p);
+    g.gx0 = bb[0]; g.gy0 = bb[1]; g.gh = gh; g.ginv = ginv; g.gnx = gnx; g.gny = gny;
+    g.n_nodes = n_nodes;
+    if ((rc = upload(m->geo, &g, 1, s))) return rc;
+    RT_HIP(hipStreamSynchronize(s));
+    d.geo = (const RT_K rt::DGeo *)m->geo.p;
     d.bx0 = bb[0]; d.by0 = bb[1]; d.bx1 = bb[2]; d.by1 = bb[3];
-    d.n_nodes = n_nodes; d.n_cells = n_cells;
+    d.n_cells = n_cells;
     d.wrec = as_global(m->wrec.p); d.adjr = as_global(m->adjr.p); d.eps_iso = P.eps_iso; d.d_vertex = P.d_vertex; d.l_min = P.l_min;
     d.walk_ok = P.walk_ok ? 1 : 0;
     m->walk_available = P.walk_ok;
@@ -941,7 +949,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
 
 void free_mesh(rt_mesh *m) {
     m->x.release(); m->y.release(); m->cn.release(); m->ncp.release(); m->ncd.release();
-    m->gstart.release(); m->gnode.release(); m->wrec.release(); m->adjr.release();
+    m->gstart.release(); m->gnode.release(); m->wrec.release(); m->adjr.release(); m->geo.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
