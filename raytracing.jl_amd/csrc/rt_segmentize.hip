@@ -1304,8 +1304,12 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
         // fill_volumes fused into the march when an LDS copy of `volumes` (+ 4 chunk tables) leaves room
         // for two workgroups per CU; larger meshes use the separate k_volumes pass
-        const size_t fuse_smem = (size_t)m->n_cells * sizeof(double) + 4 * rt::kMaxChunks * sizeof(int32_t);
-        const bool fuse = !split && m->volumes_mode == 2 && m->fuse_volumes && fuse_smem <= 78 * 1024;
+        // The 132-VGPR march fits three waves per SIMD (12 per CU): four-wave workgroups when three copies of the
+        // LDS histogram fit in the CU's 160 KB, six-wave workgroups (two copies) for larger meshes.
+        const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
+        const int fuse_waves = 3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 ? 4 : 6;
+        const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
+        const bool fuse = !split && m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024;
         fused_volumes_this_call = fuse;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
@@ -1339,11 +1343,19 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                                    t->status.p, d_fail);
             } else if (n > 0) {
                 if (fuse) {
-                    if (fuse_smem > 48 * 1024)
-                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4, false>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 4, false>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), fuse_smem, s,
-                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
+                    if (fuse_waves == 4) {
+                        if (fuse_smem > 48 * 1024)
+                            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4, false>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
+                        hipLaunchKernelGGL((rt::k_march<rt::kStage, 4, false>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), fuse_smem, s,
+                                           m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
+                    } else {
+                        if (fuse_smem > 48 * 1024)
+                            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 6, false>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
+                        hipLaunchKernelGGL((rt::k_march<rt::kStage, 6, false>), dim3((unsigned)((n_waves + 5) / 6)), dim3(384), fuse_smem, s,
+                                           m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
+                    }
                 } else {
                     hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, false>), dim3(grid), dim3(64), rt::kMaxChunks * sizeof(int32_t), s,
                                        m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
