@@ -212,6 +212,11 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
         k = fl >> 16;  // the piece whose seed this one met
     }
     if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
+    {   // records of overrun pieces were marched (and, with fused volumes, accumulated) but are not kept
+        int32_t all = 0;
+        for (int kk2 = 0; kk2 < P; ++kk2) all += sp.p_count[(int64_t)(base + kk2) * 64 + lane];
+        if (all != total) atomicAdd(&fail_info[7], (unsigned long long)(all - total));
+    }
     counts[u] = total;
     status[u] = st;
     if (st != RT_TRACK_OK) {
@@ -226,7 +231,8 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
 // status[] identically.  WAVES = 1: one wave per workgroup.  WAVES = 4 (kStage only): four
 // consecutive waves share one workgroup and an LDS-private copy of `volumes`, so fill_volumes
 // (src/trackgenerator.jl:371-386) is fused into the march as ds_add_f64 + one coalesced flush.
-// SPLIT (kStage, WAVES = 1): the lanes march pieces of tracks (see DSplit above).
+// SPLIT (kStage): the lanes march pieces of tracks (see DSplit above); with fused volumes the records of a
+// piece that overran its stop seed are counted by k_resolve and the host recomputes the volumes (rare).
 #ifdef RT_TIMING
 // development only: in-kernel cycle stamps (s_memtime), tied to a value so the compiler keeps the order;
 // RT_TIMING=2 also drains the memory queue before every stamp
@@ -262,11 +268,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     int64_t slot = wave_id * 64 + lane;
     int32_t pk = 0, pP = 1, pw = 0;  // SPLIT: piece index, pieces per track, wave of tracks
     if (SPLIT) {
-        wave_id = sp.vorder[blockIdx.x];
-        pw = sp.vw_wave[wave_id];
-        pk = sp.vw_k[wave_id];
-        pP = sp.w_P[pw];
-        slot = (int64_t)pw * 64 + lane;
+        const int64_t vidx = (int64_t)blockIdx.x * WAVES + wib;  // position in the dispatch order
+        if (vidx < sp.n_vwaves) {
+            wave_id = sp.vorder[vidx];
+            pw = sp.vw_wave[wave_id];
+            pk = sp.vw_k[wave_id];
+            pP = sp.w_P[pw];
+            slot = (int64_t)pw * 64 + lane;
+        } else {
+            slot = t.n;  // padding wave of the last workgroup
+        }
     }
     if (slot < t.n) {
     const int32_t u = SPLIT ? (int32_t)slot : t.perm[slot];
@@ -1309,7 +1320,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
         const int fuse_waves = 3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 ? 4 : 6;
         const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
-        const bool fuse = !split && m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024;
+        const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024;
         fused_volumes_this_call = fuse;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
@@ -1336,9 +1347,23 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             RT_HIP(hipEventRecord(t->ev[1], s));
             if (n > 0 && split) {
                 hipLaunchKernelGGL(rt::k_seed, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
-                hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, true>), dim3((unsigned)t->n_vwaves), dim3(64),
-                                   rt::kMaxChunks * sizeof(int32_t), s, m->d, t->d, prm, t->counts.p, t->status.p,
-                                   (const int64_t *)nullptr, out, stg, d_fail, sp);
+                if (fuse && fuse_waves == 4) {
+                    if (fuse_smem > 48 * 1024)
+                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 4, true>), dim3((unsigned)((t->n_vwaves + 3) / 4)), dim3(256), fuse_smem, s,
+                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
+                } else if (fuse) {
+                    if (fuse_smem > 48 * 1024)
+                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 6, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 6, true>), dim3((unsigned)((t->n_vwaves + 5) / 6)), dim3(384), fuse_smem, s,
+                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
+                } else {
+                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, true>), dim3((unsigned)t->n_vwaves), dim3(64),
+                                       rt::kMaxChunks * sizeof(int32_t), s, m->d, t->d, prm, t->counts.p, t->status.p,
+                                       (const int64_t *)nullptr, out, stg, d_fail, sp);
+                }
                 hipLaunchKernelGGL(rt::k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t->d, prm, sp, t->counts.p,
                                    t->status.p, d_fail);
             } else if (n > 0) {
@@ -1381,6 +1406,14 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
+            if (!cur[1] && split && fuse && fi[7] != 0) {
+                // some piece marched past the seed it should have stopped at: its surplus records were dropped by
+                // k_resolve but had already been added to the fused volumes — recompute them from the kept records
+                fused_volumes_this_call = false;
+                RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+                if (int rc = launch_volumes()) return rc;
+                RT_HIP(hipStreamSynchronize(s));
+            }
             if (!cur[1]) break;
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
