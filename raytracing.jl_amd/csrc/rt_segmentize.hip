@@ -846,6 +846,7 @@ struct rt_mesh {
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
+    int test_volumes_fallback = 0;  // tests only: take the split mode's volumes recomputation path unconditionally
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
@@ -1081,6 +1082,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
+    if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
         mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
@@ -1406,7 +1408,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
-            if (!cur[1] && split && fuse && fi[7] != 0) {
+            if (!cur[1] && split && fuse && (fi[7] != 0 || m->test_volumes_fallback)) {
                 // some piece marched past the seed it should have stopped at: its surplus records were dropped by
                 // k_resolve but had already been added to the fused volumes — recompute them from the kept records
                 fused_volumes_this_call = false;

@@ -104,7 +104,8 @@ def test_single_track_and_empty_batch(rt, orc, traced):
 
 
 @pytest.mark.parametrize("opts", [dict(single_pass=0), dict(single_pass=0, volumes_mode=1), dict(walk=0),
-                                  dict(sort_mode=0), dict(sort_mode=1), dict(fuse_volumes=0), dict(split=48), dict(split=8), dict(split=20, walk=0)])
+                                  dict(sort_mode=0), dict(sort_mode=1), dict(fuse_volumes=0), dict(split=48), dict(split=8), dict(split=20, walk=0),
+                                  dict(split=24, test_volumes_fallback=1), dict(split=24, fuse_volumes=0)])
 def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
     from raytracing_jl_amd import _capi
 
