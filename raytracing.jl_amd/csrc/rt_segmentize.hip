@@ -1320,7 +1320,9 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         // The 132-VGPR march fits three waves per SIMD (12 per CU): four-wave workgroups when three copies of the
         // LDS histogram fit in the CU's 160 KB, six-wave workgroups (two copies) for larger meshes.
         const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
-        const int fuse_waves = 3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 ? 4 : 6;
+        // (six-wave workgroups measured -10 % march time on a batch that is resident at once, BWR-like C4, and
+        //  +5 % on one that takes many rounds, C5 on one GPU)
+        const int fuse_waves = (3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || n_waves > 3072) ? 4 : 6;
         const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
         const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024;
         fused_volumes_this_call = fuse;
