@@ -1129,9 +1129,9 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     // split plan: pieces per wave of 64 consecutive uids, canonical numbering, dispatch order
     std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P;
     // Splitting pays when the batch has too few waves to fill the chip (the march is then bound by its
-    // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420); a batch that already occupies the
-    // 2,048 wave slots of the 180-VGPR kernel only gets more waves that must queue, and the pieces'
-    // fixed costs make the step slower (+20 % at 130 k tracks).
+    // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420).  On a batch whose waves are all resident
+    // anyway the split variant of the march plus its seed and resolve kernels costs more than shorter
+    // chains win back (+17 % march time at 130 k tracks even with one piece per track).
     const size_t nw_all = (n + 63) / 64;
     const bool auto_split = mesh->split < 0 && nw_all < 1536;
     const int p_auto = auto_split ? (int)std::min<size_t>(16, (2048 + nw_all - 1) / std::max<size_t>(1, nw_all)) : 1;
