@@ -471,15 +471,9 @@ __device__ __forceinline__ void load_next(const DMesh &m, int32_t pred, NextRec 
 // Written straight-line (all certificates are folded into one predicate; a lane without a
 // prediction reads record 0 and is masked out) except for the rare exact shallow-crossing test:
 // on a 64-wide wave, selects are cheaper than divergent early exits.
-#ifdef RT_SPECULATE
-__device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, NextRec &nr, int kk, double tA, double tB,
-                                         double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
-                                         double &qy, double &ell) {
-#else
 __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, double tA, double tB,
                                          double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
                                          double &qy, double &ell) {
-#endif
     const bool has = m.walk_ok && w.pred >= 0;
     const int32_t n1 = nr.n1, n2 = nr.n2, Tn = nr.cell, meta = nr.meta;
     const double dTn = nr.dT;
@@ -492,12 +486,6 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     const bool p0 = s0 > 0, p1 = s1 > 0, p2 = s2 > 0;
     ok = ok && (p0 != p1);
     const bool exit1 = p1 != p2;  // the line leaves through rotated edge 1 = (v1,v2), else edge 2 = (v2,v0)
-#ifdef RT_SPECULATE
-    // The successor record is known as soon as the exit edge is: fetch it now, under the divisions
-    // and the square root below, instead of at the top of the next iteration.
-    NextRec spec;
-    load_next(m, exit1 ? n1 : n2, spec);
-#endif
     // --- certificate 2: xp is inside T', at least eps_iso (barycentric) from edges 1 and 2
     const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     const double sg = area2 > 0 ? 1.0 : -1.0;
@@ -544,9 +532,6 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     w.bx = em ? (exit1 ? x2 : x0) : w.bx; w.by = em ? (exit1 ? y2 : y0) : w.by;
     w.cx = em ? (exit1 ? x0 : x1) : w.cx; w.cy = em ? (exit1 ? y0 : y1) : w.cy;
     w.pred = em ? (exit1 ? n1 : n2) : w.pred;
-#ifdef RT_SPECULATE
-    if (em) nr = spec;
-#endif
     return res;
 }
 

@@ -364,9 +364,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             break;  // :130-132
         }
-#if !defined(RT_PREFETCH) && !defined(RT_SPECULATE)
         load_next(m, wk.pred, nr);
-#endif
 #ifdef RT_TIMING
         const unsigned long long tB_ = rt_tick(RT_TIMING == 2 ? nr.e2C : xpx);
         tacc0 += tB_ - tA_;
@@ -376,22 +374,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         tC_ = rt_tick(ell + (double)res);
         tacc1 += tC_ - tB_;
 #endif
-#ifdef RT_PREFETCH  // loading the next record one iteration ahead measured 2-3 % slower (253 VGPRs)
-        if (res == kWalkEmit) load_next(m, wk.pred, nr);
-#endif
 #ifdef RT_STATS
         if (MODE != kFill && !SPLIT) atomicAdd(&fail_info[2 + res], 1ull);
 #endif
         if (res == kWalkSkip) {  // :147-150
             xpx = xpx + sx; xpy = xpy + sy;
-#if !defined(RT_SPECULATE) && !defined(RT_NO_SKIPRUN)
             // creep on while the reference would keep locating T: each pass stands for one more march
             // iteration that ends in the same `continue`
             while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && walk_still_skip(m, wk, nr, xpx, xpy)) {
                 ++it;
                 xpx = xpx + sx; xpy = xpy + sy;
             }
-#endif
             continue;
         }
         px = lqx; py = lqy; element = wk.T;  // valid when res == kWalkEmit
@@ -409,12 +402,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
 #endif
         if (res == kWalkGeneric) {
             const DGeo g = load_geo(m.geo);  // scalar loads, here only: the generic step's pointers and grid parameters
-#ifndef RT_GENERIC_OUTOFLINE  // out-of-line generic step + RT_SPECULATE: -4 % (pincell) / +4 % (BWR-like); off
             element = find_element(g, xpx, xpy, prm.k);               // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
             if (element == prev_element) {  // :147-150
                 xpx = xpx + sx; xpy = xpy + sy;
-#ifndef RT_NO_SKIPRUN
                 // Creep: a track that leaves a cell at a very small angle next to a vertex is located
                 // in the same cell again for hundreds of tiny steps (BWR-like config 4: 229 in a row).
                 // Each pass stands for one march iteration ending in this `continue`; only the
@@ -423,7 +414,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                     ++it;
                     xpx = xpx + sx; xpy = xpy + sy;
                 }
-#endif
                 continue;
             }
             int eq;
@@ -433,20 +423,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :156-159
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
-#else
-            GenericOut go;
-            const int rc = generic_step(g, xpx, xpy, prm.k, prev_element, phi, tA, tB, tC, go);
-            if (rc == 2) { st = RT_TRACK_LOCATE_FAILED; break; }
-            if (rc == 3) { st = RT_TRACK_UNDEF_INTERSECTION; break; }
-            if (rc == 1) { xpx = xpx + sx; xpy = xpy + sy; continue; }
-            element = go.element; px = go.px; py = go.py; qx = go.qx; qy = go.qy; ell = go.ell;
-            const int eq = go.eq;
-#endif
             if (m.walk_ok && eq >= 0) walk_enter(m, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
-#if defined(RT_PREFETCH) || defined(RT_SPECULATE)
-            load_next(m, wk.pred, nr);
-#endif
         }
         }
         if (SPLIT && !from_seed && tgt_el >= 0 && element == tgt_el && qx == tgt_qx && qy == tgt_qy && px == tgt_px &&
