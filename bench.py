@@ -86,6 +86,18 @@ def cpu_baseline(tg, max_seconds=30.0):
 
 
 def main():
+    # RCCL prints a version banner on stdout when a communicator is created: keep the real stdout for the
+    # one JSON line and send everything else that writes to fd 1 to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    try:
+        _main(real_stdout)
+    finally:
+        real_stdout.flush()
+
+
+def _main(real_stdout):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -94,7 +106,10 @@ def main():
     ap.add_argument("--delta", type=float, default=1e-3)
     ap.add_argument("--mesh", default="pincell.msh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--allgather", action="store_true",
+                    help="N>1: also time the RCCL all-gather that reassembles the global segment list on every rank (after the timed region)")
+    ap.add_argument("--no-allgather", action="store_true", help="(default; kept for compatibility)")
+    ap.add_argument("--force-dist", action="store_true", help="development: run the multi-GPU code path with a one-rank RCCL group")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +132,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+    elif args.force_dist:  # development: the multi-GPU code path with a one-rank RCCL group
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     # ---- workload (deterministic, no RNG): host-side trace! then upload the rank's uid range
     mesh_file = rt.data_path(args.mesh)
@@ -130,13 +149,51 @@ def main():
     dmesh.set_stream(stream.cuda_stream)  # kernels run on torch's current stream
     dt, (lo, hi) = rtd.segmentize_shard(tg, rank, world, device=local_rank, dmesh=dmesh)
 
+    # fill_volumes is the one reduction across tracks: every rank's partial `volumes` are summed by an RCCL
+    # all-reduce per step, in place in the library's buffer.  It is pipelined by one step: the library
+    # alternates between two volumes buffers, and the all-reduce of step i's buffer is issued from the enqueue
+    # hook of step i+1 (when step i+1's kernels are already queued) on a side stream — its launch and its
+    # latency sit beside the next march instead of between two steps.  The last one is waited for inside the
+    # timed region (`drain`).
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        side = torch.cuda.Stream(device=dev)
+        state = {"prev": None, "views": {}, "work": {}, "n": 0}
+
+        def issue_allreduce():
+            if state["prev"] is None:
+                return
+            k, vol = state["prev"]
+            state["prev"] = None
+            with torch.cuda.stream(side):  # the buffer's kernels finished with the previous (host-synchronous) call
+                state["work"][k] = dist.all_reduce(vol, op=dist.ReduceOp.SUM, async_op=True)
+
+        dmesh.set_enqueue_hook(issue_allreduce)
+
     def step():
-        total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
-        if world > 1:
-            p = dt.device_pointers()
-            vol = torch.as_tensor(rtd.DevArray(p["volumes"], dmesh.n_cells, "<f8", dt), device=dev)
-            rtd.allreduce_volumes(vol)
+        if dist_on:
+            k = state["n"] & 1  # the library alternates between two volumes buffers: this call writes buffer k
+            w = state["work"].get(k)
+            if w is not None:   # its all-reduce of two steps ago must be over before it is zeroed (stream-level wait)
+                w.wait()
+                state["work"][k] = None
+        total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)  # hook: all-reduce of the previous step
+        if dist_on:
+            if k not in state["views"]:  # first two calls: wrap the buffer once
+                ptr = dt.device_pointers()["volumes"]
+                state["views"][k] = torch.as_tensor(rtd.DevArray(ptr, dmesh.n_cells, "<f8", dt), device=dev)
+            state["prev"] = (k, state["views"][k])
+            state["n"] += 1
         return total
+
+    def drain():
+        """Issue and finish the all-reduce still owed for the last step (inside the timed region)."""
+        if dist_on:
+            issue_allreduce()
+            for k, w in list(state["work"].items()):
+                if w is not None:
+                    w.wait()
+                    state["work"][k] = None
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -146,6 +203,7 @@ def main():
 
     for _ in range(args.warmup):
         local_total = step()
+    drain()
     sync()
     kern = {"march": 0.0, "compact": 0.0, "scan": 0.0, "volumes": 0.0, "plan": 0.0, "total": 0.0}
     t0 = time.perf_counter()
@@ -154,6 +212,7 @@ def main():
         tm = dt.timing()  # HIP events recorded on the launch stream inside rt_segmentize
         for k in kern:
             kern[k] += tm[k]
+    drain()
     sync()
     elapsed = time.perf_counter() - t0
     n_failed, _, _ = dt.failed()  # tracks on which the reference itself would have thrown (never fatal here:
@@ -170,7 +229,7 @@ def main():
 
     # ---- optional: reassemble the global segment list on every rank (RCCL all-gather)
     allgather = None
-    if world > 1 and not args.no_allgather:
+    if world > 1 and args.allgather:
         p = dt.device_pointers()
         off = torch.as_tensor(rtd.DevArray(p["offsets"], dt.n + 1, "<i8", dt), device=dev)
         local = {"counts": off[1:] - off[:-1]}
@@ -239,8 +298,10 @@ def main():
             out["allgather"] = allgather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tg)
-        print(json.dumps(out, ensure_ascii=False))
-    if world > 1:
+        real_stdout.write(json.dumps(out, ensure_ascii=False) + "\n")
+        real_stdout.flush()
+    if dist_on:
+        dmesh.set_enqueue_hook(None)
         dist.destroy_process_group()
 
 

@@ -75,6 +75,12 @@ void rt_mesh_destroy(rt_mesh *mesh);
  * library's own stream). */
 int32_t rt_mesh_set_stream(rt_mesh *mesh, void *hip_stream);
 void *rt_mesh_get_stream(rt_mesh *mesh);
+/* Optional hook: called by rt_segmentize on the calling thread once all kernels of the call have been
+ * enqueued and before it waits for them, so that a host can put other work beside the march — e.g. the
+ * RCCL all-reduce of the previous batch's volumes on another stream (bench.py, multi-GPU).  Not called
+ * again if the call has to re-run (staging pool growth).  NULL removes the hook. */
+typedef void (*rt_enqueue_hook)(void *user);
+int32_t rt_mesh_set_enqueue_hook(rt_mesh *mesh, rt_enqueue_hook hook, void *user);
 
 /*
  * The per-track inputs of _segmentize_track! (src/track.jl:106-108: track.p, ϕ, ℓ, ABC),
@@ -119,7 +125,10 @@ int32_t rt_fetch_volumes(rt_tracks *tracks, double *volumes);
  * Device-resident results for consumers that stay on the GPU (RCCL all-gather of shards,
  * a device-side transport sweep).  ptrs_dev[9] receives, in this order: seg_offsets (i64),
  * status (i32), px, py, qx, qy, ell (f64), element (i32), volumes (f64).  The pointers stay
- * valid until the next rt_segmentize / rt_tracks_destroy on this handle.
+ * valid until the next rt_segmentize / rt_tracks_destroy on this handle — except `volumes`, which
+ * alternates between two buffers from call to call and stays valid (and untouched) during the next
+ * call too, so that a host can still be reducing one batch's volumes across GPUs while the next
+ * batch runs (bench.py).
  */
 int32_t rt_device_pointers(rt_tracks *tracks, void **ptrs_dev);
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RT_SEGMENTIZE_LIB") or os.path.join(_CSRC, "librt_seg
 # every symbol include/rt_segmentize.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_status_message", "rt_device_count",
-    "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_set_stream", "rt_mesh_get_stream",
+    "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option",
@@ -95,6 +95,8 @@ def lib():
     L.rt_mesh_set_stream.argtypes = [_vp, _vp]
     L.rt_mesh_get_stream.restype = _vp
     L.rt_mesh_get_stream.argtypes = [_vp]
+    L.rt_mesh_set_enqueue_hook.restype = C.c_int32
+    L.rt_mesh_set_enqueue_hook.argtypes = [_vp, _vp, _vp]
     L.rt_tracks_create.restype = _vp
     L.rt_tracks_create.argtypes = [_vp, C.c_int64] + [_dp] * 9 + [_ip]
     L.rt_tracks_destroy.argtypes = [_vp]
@@ -173,6 +175,16 @@ class DeviceMesh:
 
     def get_stream(self) -> int:
         return lib().rt_mesh_get_stream(self._h) or 0
+
+    def set_enqueue_hook(self, fn):
+        """``fn()`` is called by every ``segmentize`` of this mesh's track sets once the call's kernels are
+        enqueued and before it waits for them (``rt_mesh_set_enqueue_hook``); ``None`` removes it."""
+        if fn is None:
+            self._hook = None
+            _check(lib().rt_mesh_set_enqueue_hook(self._h, None, None))
+            return
+        self._hook = C.CFUNCTYPE(None, C.c_void_p)(lambda _user: fn())  # keep the thunk alive
+        _check(lib().rt_mesh_set_enqueue_hook(self._h, C.cast(self._hook, C.c_void_p), None))
 
     def set_option(self, name: str, value: int):
         _check(lib().rt_set_option(self._h, name.encode(), int(value)))

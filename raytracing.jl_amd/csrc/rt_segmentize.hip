@@ -816,6 +816,8 @@ struct rt_mesh {
     DevBuf<int32_t> adjr;
     DevBuf<rt::DGeo> geo;
     rt::DMesh d{};
+    rt_enqueue_hook enqueue_hook = nullptr;  // see rt_mesh_set_enqueue_hook
+    void *enqueue_hook_user = nullptr;
     int64_t iter_cap = 4000000;
     bool walk_available = false;
     int volumes_mode = 2;  // 0: skip (measurement only), 1: fused global atomics in the fill march, 2: separate LDS-privatised pass
@@ -848,6 +850,7 @@ struct rt_tracks {
 #endif
     unsigned long long *h_ctl = nullptr;  // pinned: [0..31] init image, [32..63] read-back
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
+    DevBuf<double> volumes_prev;  // the previous call's volumes: the two buffers alternate (see rt_device_pointers)
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy;
     DevBuf<int32_t> gelement, ctab, cowner;
@@ -954,7 +957,7 @@ void free_tracks(rt_tracks *t) {
 #endif
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
-    t->volumes.release(); t->delta_s.release();
+    t->volumes.release(); t->volumes_prev.release(); t->delta_s.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
     t->gelement.release(); t->ctab.release(); t->cowner.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
@@ -1051,6 +1054,13 @@ int32_t rt_mesh_set_stream(rt_mesh *mesh, void *hip_stream) {
     return RT_SUCCESS;
 }
 void *rt_mesh_get_stream(rt_mesh *mesh) { return mesh ? (void *)mesh->stream : nullptr; }
+
+int32_t rt_mesh_set_enqueue_hook(rt_mesh *mesh, rt_enqueue_hook hook, void *user) {
+    if (!mesh) { set_error("rt_mesh_set_enqueue_hook: null mesh"); return RT_ERR_INVALID; }
+    mesh->enqueue_hook = hook;
+    mesh->enqueue_hook_user = user;
+    return RT_SUCCESS;
+}
 
 int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!mesh || !name) { set_error("null argument"); return RT_ERR_INVALID; }
@@ -1203,6 +1213,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     unsigned long long *const h_res = t->h_ctl + 32;
     unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tiles writes it)
     RT_HIP(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
+    std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
     RT_HIP(t->volumes.reserve(m->n_cells));
     if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
         t->h_delta_s.assign(delta_s, delta_s + n_azim_2);
@@ -1383,6 +1394,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             if (volumes_pass) RT_HIP(hipEventRecord(t->ev[6], s));
             int32_t cur[4] = {0, 0, 0, 0};
             if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
             RT_HIP(hipStreamSynchronize(s));
             memcpy(fi, h_res, sizeof(fi));
             memcpy(&total, h_res + 16, sizeof(total));
@@ -1410,6 +1422,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         if (int rc = scan_counts(false, false)) return rc;
         RT_HIP(hipEventRecord(t->ev[3], s));
         RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        if (m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);  // (the count march is the longer half of this mode)
         RT_HIP(hipStreamSynchronize(s));
         memcpy(fi, h_res, sizeof(fi));
         memcpy(&total, h_res + 16, sizeof(total));

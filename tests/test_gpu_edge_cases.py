@@ -138,3 +138,23 @@ def test_staging_pool_overflow_is_recovered(rt, traced, oracle_run):
     aq = tg.azimuthal_quadrature
     assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
     assert np.array_equal(dt.fetch_segments()["element"], ref["element"])
+
+
+def test_enqueue_hook_runs_once_per_call_beside_the_kernels(rt, traced, oracle_run):
+    """rt_mesh_set_enqueue_hook: called after the kernels are enqueued and before the wait; not on removal."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(8, 2e-2)
+    ref = oracle_run(tg)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    calls = []
+    dm.set_enqueue_hook(lambda: calls.append(len(calls)))
+    for _ in range(3):
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    assert calls == [0, 1, 2]
+    dm.set_enqueue_hook(None)
+    assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    assert calls == [0, 1, 2]
+    assert np.array_equal(dt.fetch_segments()["element"], ref["element"])
