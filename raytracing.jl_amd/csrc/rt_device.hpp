@@ -403,6 +403,19 @@ __device__ __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, 
     return 0;
 }
 
+// Does the reference's iteration at xp end in a tiny step (`continue` at src/track.jl:147-150 or :156-159)?
+// False when it emits a segment or fails to locate / intersect.  Used by the cooperative creep of k_march.
+__device__ __noinline__ bool generic_tiny_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element,
+                                               double phi, double tA, double tB, double tC) {
+    const int32_t element = find_element(m, xpx, xpy, k);
+    if (element < 0) return false;
+    if (element == prev_element) return true;
+    double px, py, qx, qy;
+    int eq;
+    if (!intersections(m, element, phi, tA, tB, tC, px, py, qx, qy, eq)) return false;
+    return isapprox_v2(px, py, qx, qy);
+}
+
 // ======================================================================= walk step ========
 // After a segment has been emitted in cell T with its exit point q on edge `ko`, the reference
 // re-seeds at xp = q + tiny_step·(cos ϕ, sin ϕ) and locates from scratch (src/track.jl:165,

@@ -117,6 +117,7 @@ __device__ __forceinline__ int64_t stage_slot(int32_t chunk, int row, int lane) 
 }
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
+constexpr int kCreepLocal = 16;  // tiny steps a creeping lane takes on its own before the wave helps (k_march)
 
 // ---- track splitting ("pieces") ------------------------------------------------------------
 // The march of a track is a serial dependent chain; a batch lasts as long as its longest track.
@@ -336,7 +337,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tn = 0, tD = 0, wits = 0, wgen = 0;
     const unsigned long long tstart = rt_tick(xpx);
 #endif
-    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter) {  // :119
+    // A lane whose track creeps (see below) for more than kCreepLocal tiny steps leaves the march loop and
+    // waits for the wave: once every lane is out, all 64 lanes test 64 consecutive creep positions of that
+    // track at a time (cooperative creep), then the lane marches on.
+    bool creep_escalate = false;
+    int creep_run = 0;  // generic tiny steps in a row
+    for (;;) {
+    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter && !creep_escalate) {  // :119
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
 #ifdef RT_TIMING
         const unsigned long long tA_ = rt_tick(xpx);
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
 #ifdef RT_STATS
         if (MODE != kFill && !SPLIT) atomicAdd(&fail_info[2 + res], 1ull);
 #endif
+        if (res != kWalkGeneric) creep_run = 0;
         if (res == kWalkSkip) {  // :147-150
             xpx = xpx + sx; xpy = xpy + sy;
             // creep on while the reference would keep locating T: each pass stands for one more march
@@ -404,16 +412,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             const DGeo g = load_geo(m.geo);  // scalar loads, here only: the generic step's pointers and grid parameters
             element = find_element(g, xpx, xpy, prm.k);               // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
+            // Creep: a track that leaves a cell at a very small angle next to a vertex takes hundreds of tiny
+            // steps here (BWR-like config 4: 229 in a row through a 7e-8 sliver), each a full locate by one
+            // lane.  After kCreepLocal in a row the lane asks the wave for help (cooperative creep below).
             if (element == prev_element) {  // :147-150
                 xpx = xpx + sx; xpy = xpy + sy;
-                // Creep: a track that leaves a cell at a very small angle next to a vertex is located
-                // in the same cell again for hundreds of tiny steps (BWR-like config 4: 229 in a row).
-                // Each pass stands for one march iteration ending in this `continue`; only the
-                // reference's own locate is repeated, not the walk step that cannot certify here.
-                while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && find_element(g, xpx, xpy, prm.k) == prev_element) {
-                    ++it;
-                    xpx = xpx + sx; xpy = xpy + sy;
-                }
+                creep_escalate = ++creep_run >= kCreepLocal;
                 continue;
             }
             int eq;
@@ -421,7 +425,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 st = RT_TRACK_UNDEF_INTERSECTION;
                 break;
             }
-            if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }  // :156-159
+            if (isapprox_v2(px, py, qx, qy)) {  // :156-159
+                xpx = xpx + sx; xpy = xpy + sy;
+                creep_escalate = ++creep_run >= kCreepLocal;
+                continue;
+            }
+            creep_run = 0;
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
             if (m.walk_ok && eq >= 0) walk_enter(m, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
@@ -490,6 +499,41 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         prev_element = element;        // :166
         ++i;                           // :168
     }
+    // ---- cooperative creep: every lane of the wave is out of the march loop here
+    unsigned long long need = __ballot(creep_escalate);
+    if (!need) break;
+    {
+        const DGeo g = load_geo(m.geo);
+        while (need) {
+            const int L = __ffsll((long long)need) - 1;  // the lane whose track creeps
+            need &= need - 1;
+            const int32_t l_prev = __shfl(prev_element, L, 64);
+            const double l_sx = __shfl(sx, L, 64), l_sy = __shfl(sy, L, 64);
+            const double l_phi = __shfl(phi, L, 64), l_tA = __shfl(tA, L, 64), l_tB = __shfl(tB, L, 64), l_tC = __shfl(tC, L, 64);
+            for (;;) {
+                // lane j tests position j of the creep: xp advanced j times, exactly as the serial loop adds
+                double cx = __shfl(xpx, L, 64), cy = __shfl(xpy, L, 64);
+                const int32_t l_it = __shfl(it, L, 64);
+                for (int a = 0; a < 63; ++a)
+                    if (a < lane) { cx = cx + l_sx; cy = cy + l_sy; }
+                const bool ok = !inboundary(m, cx, cy, prm.tiny_step) &&
+                                generic_tiny_step(g, cx, cy, prm.k, l_prev, l_phi, l_tA, l_tB, l_tC);
+                const unsigned long long okm = __ballot(ok);
+                int n_ok = okm == ~0ull ? 64 : __ffsll((long long)~okm) - 1;  // leading positions at which the reference steps on
+                const int allowed = cap - l_it;                              // it < cap, one count per step
+                const int n_adv = n_ok < allowed ? n_ok : (allowed > 0 ? allowed : 0);
+                // the lane's new xp is position n_adv (not consumed: the march loop evaluates it), reached by
+                // the same additions
+                if (lane == L) {
+                    for (int a = 0; a < n_adv; ++a) { xpx = xpx + sx; xpy = xpy + sy; }
+                    it = l_it + n_adv;
+                }
+                if (n_adv < 64 || l_it + 64 >= cap) break;  // the creep is over (or the iteration cap is next)
+            }
+            if (lane == L) { creep_escalate = false; creep_run = 0; }
+        }
+    }
+    }  // for (;;)
 #ifdef RT_TIMING
     if (!SPLIT && MODE == kStage && lane == __ffsll((long long)__ballot(1)) - 1) {
         atomicAdd(&fail_info[8], tacc0); atomicAdd(&fail_info[9], tacc1); atomicAdd(&fail_info[10], tacc2);
