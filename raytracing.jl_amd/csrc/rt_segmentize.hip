@@ -117,7 +117,9 @@ __device__ __forceinline__ int64_t stage_slot(int32_t chunk, int row, int lane) 
 }
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
-constexpr int kCreepLocal = 16;  // (2 and 4 measured +30 % at C3: a lane that escalates waits for the rest of its wave; 8..32 equal)  // tiny steps a creeping lane takes on its own before the wave helps (k_march)
+// generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
+// C3 — a lane that escalates waits for the rest of its wave — 8..32 equal)
+constexpr int kCreepLocal = 16;
 
 // ---- track splitting ("pieces") ------------------------------------------------------------
 // The march of a track is a serial dependent chain; a batch lasts as long as its longest track.
