@@ -543,7 +543,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         atomicAdd(&fail_info[14], 1ull);
         if (stg.dbg) {
             stg.dbg[4 * wave_id + 0] = rt_tick(xpx) - tstart; stg.dbg[4 * wave_id + 1] = wits;
-            stg.dbg[4 * wave_id + 2] = wgen; stg.dbg[4 * wave_id + 3] = tn;
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            stg.dbg[4 * wave_id + 2] = wgen | ((unsigned long long)hwid << 16) | ((unsigned long long)(xcc & 15) << 48);
+            stg.dbg[4 * wave_id + 3] = tn | ((unsigned long long)(tstart & 0xffffffffffffull) << 16);
         }
     }
 #endif
