@@ -433,6 +433,7 @@ int64_t orc_segmentize(void *mv, int64_t n_tracks, const double *px, const doubl
     nthr = n_threads > 0 ? n_threads : omp_get_max_threads();
 #else
     (void)n_threads;
+    (void)nthr;
 #endif
     /* contiguous uid chunks (one buffer each) keep per-track order trivially; chunks are
      * handed out dynamically so that long and short angles balance across threads */

@@ -158,3 +158,47 @@ def test_enqueue_hook_runs_once_per_call_beside_the_kernels(rt, traced, oracle_r
     assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
     assert calls == [0, 1, 2]
     assert np.array_equal(dt.fetch_segments()["element"], ref["element"])
+
+
+def test_handles_release_their_device_memory(rt, traced):
+    """Create / segmentize / destroy in a loop: free device memory must come back (no leak in the handles)."""
+    import torch
+
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    aq = tg.azimuthal_quadrature
+
+    def cycle():
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        dt.close()
+        dm.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)  # allocator granularity, not 20 pools (≈ 20 x 100 MB)
+
+
+def test_bad_arguments_are_refused_not_launched(rt, traced):
+    from raytracing_jl_amd import _capi
+
+    tg = traced(8, 2e-2)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    with pytest.raises(_capi.RtError):
+        dm.set_option("no_such_option", 1)
+    L = _capi.lib()
+    assert L.rt_segmentize(None, 1e-8, 5, 1e-8, None, 4) < 0 and b"bad arguments" in L.rt_last_error()
+    cells = np.asarray(tg.mesh.cell_nodes).copy()
+    cells[0, 0] = tg.mesh.num_nodes + 5  # out-of-range node id
+    bad = rt.Mesh.__new__(rt.Mesh)
+    bad.__dict__.update(tg.mesh.__dict__)
+    bad.cell_nodes = cells
+    with pytest.raises(_capi.RtError, match="out of range"):
+        _capi.DeviceMesh(bad, 0)
