@@ -165,9 +165,11 @@ int32_t rt_trace(const double *bb, int32_t n_azim, const int64_t *n_tracks_x, co
                  double *sin_phi, double *ell, double *A, double *B, double *C, int8_t *bc_fwd, int8_t *bc_bwd,
                  int8_t *dir_fwd, int8_t *dir_bwd, int64_t *next_fwd, int64_t *next_bwd);
 
-/* Mesh ingest, replaces GmshDiscreteModel + Mesh(model) (src/mesh.jl:24-69) for gmsh 4.1 ASCII
- * files: node coordinates, cell->nodes (1-based, ascending per cell as Gridap's oriented grid
- * stores them), node->cells CSR (0-based ptrs, 1-based ascending cell ids) and the bounding box —
+/* Mesh ingest, replaces GmshDiscreteModel / DiscreteModelFromFile + Mesh(model) (src/mesh.jl:24-69) for
+ * gmsh 4.1 ASCII files and for Gridap JSON models (a file that starts with '{': "grid" ->
+ * "node_coordinates", "cell_node_ids"; what test/runtests.jl:5-6 and demo/pincell.jl:6-7 load): node
+ * coordinates, cell->nodes (1-based; gmsh: ascending per cell as Gridap's oriented grid stores them,
+ * JSON: as stored), node->cells CSR (0-based ptrs, 1-based ascending cell ids) and the bounding box —
  * exactly the arrays rt_mesh_create takes.  Returns NULL on failure. */
 typedef struct rt_msh rt_msh;
 rt_msh *rt_msh_load(const char *path);

@@ -10,6 +10,7 @@
 // Compiled with -ffp-contract=off like the rest of the library: the per-track inputs must be
 // the values the reference's own arithmetic produces.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -156,6 +157,8 @@ int32_t rt_trace(const double *bb, int32_t n_azim, const int64_t *ntx, const int
 }
 
 // ------------------------------------------------------------------ mesh ingest -----------
+}  // extern "C" (the helpers below are C++)
+
 struct rt_msh {
     std::vector<double> x, y;
     std::vector<int32_t> cells;              // 3 per cell, 1-based, ascending per cell
@@ -166,11 +169,114 @@ struct rt_msh {
 // Loads the 2-D triangles of a gmsh 4.1 ASCII file with Gridap's numbering for such a file
 // (GmshDiscreteModel(msh; renumber=true) + oriented grid): node tags are the ids, triangles keep
 // file order, each cell's node ids are sorted ascending (verified against demo/pincell.json).
+// ---- Gridap JSON (DiscreteModelFromFile, v0.15 dict layout): "grid": {"node_coordinates": [x1, y1, x2, ...],
+//      "cell_node_ids": {"ptrs": [...], "data": [...]}} — a targeted scan, not a general JSON parser
+static const char *json_find(const std::string &s, size_t from, size_t to, const char *key) {
+    const std::string k = std::string("\"") + key + "\"";
+    const size_t p = s.find(k, from);
+    return (p == std::string::npos || p >= to) ? nullptr : s.c_str() + p + k.size();
+}
+static size_t json_match(const std::string &s, size_t open) {  // index of the bracket closing s[open]
+    const char o = s[open], c = o == '{' ? '}' : ']';
+    int depth = 0;
+    bool in_str = false;
+    for (size_t i = open; i < s.size(); ++i) {
+        const char ch = s[i];
+        if (in_str) { if (ch == '\\') ++i; else if (ch == '"') in_str = false; continue; }
+        if (ch == '"') in_str = true;
+        else if (ch == o) ++depth;
+        else if (ch == c && --depth == 0) return i;
+    }
+    return std::string::npos;
+}
+template <typename T, typename Conv>
+static bool json_numbers(const std::string &s, const char *after_key, std::vector<T> &out, Conv conv) {
+    const char *p = after_key;
+    while (*p && *p != '[') { if (*p != ':' && !isspace((unsigned char)*p)) return false; ++p; }
+    if (*p != '[') return false;
+    ++p;
+    for (;;) {
+        while (*p && (isspace((unsigned char)*p) || *p == ',')) ++p;
+        if (*p == ']') return true;
+        char *end = nullptr;
+        out.push_back(conv(p, &end));
+        if (end == p) return false;
+        p = end;
+    }
+}
+static bool load_gridap_json(const std::string &s, rt_msh *M, std::string &why) {
+    const char *g = json_find(s, 0, s.size(), "grid");
+    if (!g) { why = "no \"grid\" object"; return false; }
+    size_t gb = s.find('{', g - s.c_str());
+    const size_t ge = gb == std::string::npos ? gb : json_match(s, gb);
+    if (ge == std::string::npos) { why = "unbalanced \"grid\" object"; return false; }
+    const char *nc = json_find(s, gb, ge, "node_coordinates");
+    std::vector<double> xy;
+    if (!nc || !json_numbers(s, nc, xy, [](const char *p, char **e) { return strtod(p, e); }) || xy.size() % 2) {
+        why = "bad grid.node_coordinates"; return false;
+    }
+    const char *ci = json_find(s, gb, ge, "cell_node_ids");
+    if (!ci) { why = "no grid.cell_node_ids"; return false; }
+    const size_t cb = s.find('{', ci - s.c_str());
+    const size_t ce = cb == std::string::npos ? cb : json_match(s, cb);
+    if (ce == std::string::npos || ce > ge) { why = "unbalanced grid.cell_node_ids"; return false; }
+    std::vector<long> ptrs, data;
+    const char *pp = json_find(s, cb, ce, "ptrs"), *pd = json_find(s, cb, ce, "data");
+    auto tol = [](const char *p, char **e) { return strtol(p, e, 10); };
+    if (!pp || !pd || !json_numbers(s, pp, ptrs, tol) || !json_numbers(s, pd, data, tol) || ptrs.size() < 2) {
+        why = "bad grid.cell_node_ids table"; return false;
+    }
+    for (size_t c = 0; c + 1 < ptrs.size(); ++c)
+        if (ptrs[c + 1] - ptrs[c] != 3) { why = "only triangular cells are supported"; return false; }
+    if ((size_t)(ptrs.back() - ptrs.front()) != data.size()) { why = "cell_node_ids ptrs / data mismatch"; return false; }
+    const size_t nn = xy.size() / 2;
+    M->x.resize(nn); M->y.resize(nn);
+    for (size_t i = 0; i < nn; ++i) { M->x[i] = xy[2 * i]; M->y[i] = xy[2 * i + 1]; }
+    M->cells.assign(data.begin(), data.end());  // 1-based, Gridap's order per cell (no renumbering)
+    return true;
+}
+
+// node -> cells table and bounding box of a filled rt_msh (shared by both file formats)
+static bool finish_msh(rt_msh *M, std::string &why) {
+    if (M->x.empty() || M->cells.empty()) { why = "no 2-D triangles found"; return false; }
+    const int32_t nn = (int32_t)M->x.size(), nc = (int32_t)(M->cells.size() / 3);
+    for (int32_t v : M->cells) if (v < 1 || v > nn) { why = "cell refers to an unknown node"; return false; }
+    // node -> cells (get_faces(topology, 0, 2), src/mesh.jl:27): filled in cell order => ascending
+    M->nc_ptrs.assign(nn + 1, 0);
+    for (int32_t v : M->cells) M->nc_ptrs[v]++;
+    for (int32_t i = 0; i < nn; ++i) M->nc_ptrs[i + 1] += M->nc_ptrs[i];
+    M->nc_data.assign(M->cells.size(), 0);
+    std::vector<int32_t> cur(M->nc_ptrs.begin(), M->nc_ptrs.end() - 1);
+    for (int32_t c = 0; c < nc; ++c)
+        for (int k = 0; k < 3; ++k) M->nc_data[cur[M->cells[3 * c + k] - 1]++] = c + 1;
+    // bounding_box, src/mesh.jl:53-69: plain min / max of the node coordinates
+    M->bb[0] = *std::min_element(M->x.begin(), M->x.end()); M->bb[2] = *std::max_element(M->x.begin(), M->x.end());
+    M->bb[1] = *std::min_element(M->y.begin(), M->y.end()); M->bb[3] = *std::max_element(M->y.begin(), M->y.end());
+    return true;
+}
+
+extern "C" {
+
 rt_msh *rt_msh_load(const char *path) {
     if (!path) { set_error("rt_msh_load: null path"); return nullptr; }
     std::ifstream f(path);
     if (!f) { set_error("rt_msh_load: cannot open %s", path); return nullptr; }
     rt_msh *M = new rt_msh();
+    {   // a file that starts with '{' is a Gridap JSON model
+        int ch;
+        while ((ch = f.peek()) != EOF && isspace(ch)) f.get();
+        if (ch == '{') {
+            std::stringstream buf;
+            buf << f.rdbuf();
+            std::string why;
+            if (!load_gridap_json(buf.str(), M, why) || !finish_msh(M, why)) {
+                set_error("rt_msh_load(%s): %s", path, why.c_str());
+                delete M;
+                return nullptr;
+            }
+            return M;
+        }
+    }
     std::string line;
     bool fmt_ok = false;
     auto fail = [&](const char *why) -> rt_msh * { set_error("rt_msh_load(%s): %s", path, why); delete M; return nullptr; };
@@ -219,20 +325,11 @@ rt_msh *rt_msh_load(const char *path) {
             if (!f) return fail("truncated $Elements");
         }
     }
-    if (!fmt_ok || M->x.empty() || M->cells.empty()) return fail("no 2-D triangles found");
-    const int32_t nn = (int32_t)M->x.size(), nc = (int32_t)(M->cells.size() / 3);
-    for (int32_t v : M->cells) if (v < 1 || v > nn) return fail("cell refers to an unknown node");
-    // node -> cells (get_faces(topology, 0, 2), src/mesh.jl:27): filled in cell order => ascending
-    M->nc_ptrs.assign(nn + 1, 0);
-    for (int32_t v : M->cells) M->nc_ptrs[v]++;
-    for (int32_t i = 0; i < nn; ++i) M->nc_ptrs[i + 1] += M->nc_ptrs[i];
-    M->nc_data.assign(M->cells.size(), 0);
-    std::vector<int32_t> cur(M->nc_ptrs.begin(), M->nc_ptrs.end() - 1);
-    for (int32_t c = 0; c < nc; ++c)
-        for (int k = 0; k < 3; ++k) M->nc_data[cur[M->cells[3 * c + k] - 1]++] = c + 1;
-    // bounding_box, src/mesh.jl:53-69: plain min / max of the node coordinates
-    M->bb[0] = *std::min_element(M->x.begin(), M->x.end()); M->bb[2] = *std::max_element(M->x.begin(), M->x.end());
-    M->bb[1] = *std::min_element(M->y.begin(), M->y.end()); M->bb[3] = *std::max_element(M->y.begin(), M->y.end());
+    if (!fmt_ok) return fail("no 2-D triangles found");
+    {
+        std::string why;
+        if (!finish_msh(M, why)) return fail(why.c_str());
+    }
     return M;
 }
 

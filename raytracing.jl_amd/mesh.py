@@ -149,9 +149,15 @@ class Mesh:
     """Flattened mesh for the segmentize! path (mirrors ``Mesh(model)``, ``src/mesh.jl:24-31``)."""
 
     @classmethod
+    def from_file(cls, path: str) -> "Mesh":
+        """Native ingest (``rt_msh_load`` of the C-ABI library) of a gmsh 4.1 ASCII ``.msh`` or a Gridap
+        ``.json`` model straight to the flat arrays, without going through the Python parsers."""
+        return cls.from_msh(path)
+
+    @classmethod
     def from_msh(cls, mshfile: str) -> "Mesh":
-        """Native ingest (``rt_msh_load`` of the C-ABI library): gmsh 4.1 ASCII straight to the
-        flat arrays, without going through the Python parser."""
+        """Native ingest (``rt_msh_load`` of the C-ABI library): gmsh 4.1 ASCII (or Gridap JSON) straight
+        to the flat arrays, without going through the Python parser."""
         from . import _capi
 
         x, y, cells, ptrs, data, bb = _capi.native_load_msh(mshfile)

@@ -93,6 +93,31 @@ def test_native_msh_ingest_matches_python_loader(rt, name):
     assert py.bb_min == nat.bb_min and py.bb_max == nat.bb_max
 
 
+def test_native_gridap_json_ingest_matches_python_loader(rt):
+    """The reference's tests load demo/pincell.json (test/runtests.jl:5-6): native reader vs the Python one."""
+    path = rt.data_path("pincell.json")
+    py = rt.Mesh(rt.DiscreteModelFromFile(path))
+    nat = rt.Mesh.from_file(path)
+    assert np.array_equal(nat.x, py.x) and np.array_equal(nat.y, py.y)
+    assert np.array_equal(nat.cell_nodes, py.cell_nodes)
+    assert np.array_equal(nat.node_cells_ptrs, py.node_cells_ptrs)
+    assert np.array_equal(nat.node_cells_data, py.node_cells_data)
+    assert np.array_equal(nat.bb, py.bb)
+    # and it is the same mesh as the gmsh file it was made from
+    msh = rt.Mesh.from_file(rt.data_path("pincell.msh"))
+    assert np.array_equal(nat.x, msh.x) and np.array_equal(nat.cell_nodes, msh.cell_nodes)
+
+
+def test_native_json_errors(capi, tmp_path):
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"grid": {"node_coordinates": [0, 0, 1, 0, 0, 1], "cell_node_ids": {"ptrs": [1, 5], "data": [1, 2, 3, 1]}}}')
+    with pytest.raises(capi.RtError, match="triangular"):
+        capi.native_load_msh(str(bad))
+    bad.write_text('{"nothing": 1}')
+    with pytest.raises(capi.RtError, match="grid"):
+        capi.native_load_msh(str(bad))
+
+
 def test_native_msh_errors(capi, tmp_path):
     with pytest.raises(capi.RtError, match="cannot open"):
         capi.native_load_msh(str(tmp_path / "missing.msh"))
