@@ -1344,7 +1344,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         return RT_SUCCESS;
     };
 
-    RT_HIP(hipEventRecord(t->ev[0], s));
+    if (!m->single_pass) RT_HIP(hipEventRecord(t->ev[0], s));  // single pass: the call is timed from ev[1], after the 2-µs prologue
     if (!m->single_pass) RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
     if (m->single_pass) {
         // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
@@ -1487,7 +1487,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         RT_HIP(hipStreamSynchronize(s));
     }
     RT_HIP(hipGetLastError());
-    RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
+    RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 1 : 0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
     RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
     RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan (+ volumes ./= n_azim_2 when fused)
     RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 3 : 4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
