@@ -157,43 +157,25 @@ def _main(real_stdout):
     # timed region (`drain`).
     dist_on = world > 1 or args.force_dist
     if dist_on:
-        side = torch.cuda.Stream(device=dev)
-        state = {"prev": None, "views": {}, "work": {}, "n": 0}
-
-        def issue_allreduce():
-            if state["prev"] is None:
-                return
-            k, vol = state["prev"]
-            state["prev"] = None
-            with torch.cuda.stream(side):  # the buffer's kernels finished with the previous (host-synchronous) call
-                state["work"][k] = dist.all_reduce(vol, op=dist.ReduceOp.SUM, async_op=True)
-
-        dmesh.set_enqueue_hook(issue_allreduce)
+        pipe = rtd.PipelinedVolumesAllReduce(device=dev)
+        views = {}
+        dmesh.set_enqueue_hook(pipe.hook)
 
     def step():
         if dist_on:
-            k = state["n"] & 1  # the library alternates between two volumes buffers: this call writes buffer k
-            w = state["work"].get(k)
-            if w is not None:   # its all-reduce of two steps ago must be over before it is zeroed (stream-level wait)
-                w.wait()
-                state["work"][k] = None
+            k = pipe.before_call()  # the library alternates between two volumes buffers: this call writes buffer k
         total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)  # hook: all-reduce of the previous step
         if dist_on:
-            if k not in state["views"]:  # first two calls: wrap the buffer once
+            if k not in views:  # first two calls: wrap the buffer once
                 ptr = dt.device_pointers()["volumes"]
-                state["views"][k] = torch.as_tensor(rtd.DevArray(ptr, dmesh.n_cells, "<f8", dt), device=dev)
-            state["prev"] = (k, state["views"][k])
-            state["n"] += 1
+                views[k] = torch.as_tensor(rtd.DevArray(ptr, dmesh.n_cells, "<f8", dt), device=dev)
+            pipe.after_call(k, views[k])
         return total
 
     def drain():
         """Issue and finish the all-reduce still owed for the last step (inside the timed region)."""
         if dist_on:
-            issue_allreduce()
-            for k, w in list(state["work"].items()):
-                if w is not None:
-                    w.wait()
-                    state["work"][k] = None
+            pipe.drain()
 
     def sync():
         torch.cuda.synchronize(dev)

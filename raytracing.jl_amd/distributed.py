@@ -19,7 +19,7 @@ from typing import Callable, Dict, List, Tuple
 import numpy as np
 
 __all__ = ["shard_ranges", "shard_arrays", "segmentize_shard", "allreduce_volumes",
-           "allgather_segments", "DevArray", "TRACK_FIELDS"]
+           "allgather_segments", "DevArray", "TRACK_FIELDS", "PipelinedVolumesAllReduce"]
 
 TRACK_FIELDS = ("px", "py", "phi", "cos_phi", "sin_phi", "A", "B", "C", "ell", "azim_idx")
 
@@ -128,3 +128,68 @@ def allgather_segments(local: dict, group=None) -> dict:
     torch.cumsum(counts, 0, out=offsets[1:])
     out["offsets"] = offsets
     return out
+
+
+class PipelinedVolumesAllReduce:
+    """All-reduce(sum) of every step's per-rank ``volumes``, one step late.
+
+    The library alternates between two ``volumes`` buffers from call to call (``rt_device_pointers``),
+    so the buffer of step i stays untouched while step i+1 runs.  ``hook`` — registered as the
+    mesh's enqueue hook (``rt_mesh_set_enqueue_hook``: called once a call's kernels are queued,
+    before the call waits for them) — issues the all-reduce of step i's buffer during step i+1, on
+    a side stream when the tensors live on a GPU, so that neither its launch nor its latency sits
+    between two steps.  Protocol per step::
+
+        k = p.before_call()        # buffer k is about to be zeroed: its all-reduce of two steps ago must be over
+        ... segmentize (calls p.hook() from inside) ...
+        p.after_call(k, volumes_tensor_of_this_call)
+
+    and ``p.drain()`` after the last step (inside any timed region).  The reduced values are left in
+    the library's buffers.  ``all_reduce`` is injectable for tests.
+    """
+
+    def __init__(self, group=None, device=None, all_reduce=None):
+        import torch
+        import torch.distributed as dist
+
+        self._dist = dist
+        self._group = group
+        self._all_reduce = all_reduce or (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        self._side = None
+        if device is not None and torch.device(device).type == "cuda":
+            self._side = torch.cuda.Stream(device=device)
+        self._torch = torch
+        self._prev = None
+        self._work = {}
+        self.n = 0
+
+    def hook(self):
+        if self._prev is None:
+            return
+        k, vol = self._prev
+        self._prev = None
+        if self._side is not None:
+            # the buffer's kernels finished with the previous (host-synchronous) call: nothing to wait for
+            with self._torch.cuda.stream(self._side):
+                self._work[k] = self._all_reduce(vol)
+        else:
+            self._work[k] = self._all_reduce(vol)
+
+    def before_call(self) -> int:
+        k = self.n & 1
+        w = self._work.get(k)
+        if w is not None:
+            w.wait()  # NCCL: a stream-level wait; gloo: blocks until done
+            self._work[k] = None
+        return k
+
+    def after_call(self, k: int, volumes):
+        self._prev = (k, volumes)
+        self.n += 1
+
+    def drain(self):
+        self.hook()
+        for k, w in list(self._work.items()):
+            if w is not None:
+                w.wait()
+                self._work[k] = None

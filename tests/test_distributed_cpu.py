@@ -74,3 +74,65 @@ def test_two_rank_gloo_shard_and_gather():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert sum(n for _, _, n in res) > 0
+
+
+def _pipe_worker(rank, world, port, q):
+    """The bench's pipelined all-reduce of volumes, with CPU tensors over gloo: a fake `segmentize` that
+    alternates between two buffers like the library and fires the enqueue hook in the middle of a call."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch
+        import torch.distributed as dist
+
+        from raytracing_jl_amd import distributed as rtd
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n_cells, steps = 257, 7
+        bufs = [torch.zeros(n_cells, dtype=torch.float64), torch.zeros(n_cells, dtype=torch.float64)]
+        pipe = rtd.PipelinedVolumesAllReduce(device="cpu")
+        base = torch.arange(n_cells, dtype=torch.float64)
+        reduced = {}
+
+        def local_volumes(step):  # what rank `rank` contributes at `step`
+            return (rank + 1) * base + 1000.0 * step
+
+        owner = {}  # buffer index -> step whose all-reduce result it will hold once waited for
+        for i in range(steps):
+            k = pipe.before_call()
+            if k in owner:  # before_call waited for the all-reduce of step i-2: its result is in bufs[k] now
+                reduced[owner.pop(k)] = bufs[k].clone()
+            bufs[k].zero_()          # k_prologue
+            pipe.hook()              # the library's enqueue hook: all-reduce of step i-1 starts here
+            bufs[k] += local_volumes(i)  # the march + scale of step i
+            pipe.after_call(k, bufs[k])
+            owner[k] = i
+        pipe.drain()
+        for k, i in owner.items():
+            reduced[i] = bufs[k].clone()
+        ok = len(reduced) == steps
+        for i in range(steps):
+            want = sum((r + 1) * base + 1000.0 * i for r in range(world))
+            ok = ok and torch.equal(reduced[i], want)
+        dist.destroy_process_group()
+        q.put((rank, bool(ok), steps))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_pipelined_volumes_allreduce():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
