@@ -145,8 +145,12 @@ def _main(real_stdout):
     rt.trace(tg)
     aq = tg.azimuthal_quadrature
     dmesh = _capi.DeviceMesh(tg.mesh, local_rank)
-    stream = torch.cuda.current_stream(dev)
-    dmesh.set_stream(stream.cuda_stream)  # kernels run on torch's current stream
+    # one explicit stream for everything: the library's kernels, torch's own ops and the stream-level waits
+    # of the pipelined all-reduce (torch's default stream has handle 0, which the library reads as "use
+    # your own stream" — the waits would then order nothing)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    dmesh.set_stream(stream.cuda_stream)
     dt, (lo, hi) = rtd.segmentize_shard(tg, rank, world, device=local_rank, dmesh=dmesh)
 
     # fill_volumes is the one reduction across tracks: every rank's partial `volumes` are summed by an RCCL
