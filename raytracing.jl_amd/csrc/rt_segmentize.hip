@@ -733,24 +733,26 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t *__restrict__ tile_
                                                      int64_t *__restrict__ total,
                                                      const unsigned long long *__restrict__ ctl,
                                                      unsigned long long *__restrict__ host_copy) {
-    __shared__ int64_t buf[1024];
+    __shared__ int64_t wsum[16];
     __shared__ int64_t carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int64_t base = 0; base < n_tiles; base += 1024) {
         const int64_t i = base + threadIdx.x;
         const int64_t v = i < n_tiles ? tile_sums[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            int64_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
+        int64_t incl = v;  // inclusive scan inside the wave, then across the 16 waves
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
         }
-        if (i < n_tiles) tile_sums[i] = carry + buf[threadIdx.x] - v;  // exclusive
+        if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
+        int64_t wave_off = 0;
+        for (int w = 0; w < wv; ++w) wave_off += wsum[w];
+        if (i < n_tiles) tile_sums[i] = carry + wave_off + incl - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += wave_off + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
