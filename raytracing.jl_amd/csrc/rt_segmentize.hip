@@ -700,59 +700,64 @@ constexpr int kScanBlock = 256;
 constexpr int kScanPer = 4;
 constexpr int kScanTile = kScanBlock * kScanPer;
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__restrict__ counts, int64_t n,
-                                                               int64_t *__restrict__ tile_sums) {
-    __shared__ int64_t red[kScanBlock / 64];
-    const int64_t i0 = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
-    int64_t s = 0;
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j)
-        if (i0 + j < n) s += counts[i0 + j];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int64_t tot = 0;
-        for (int w = 0; w < kScanBlock / 64; ++w) tot += red[w];
-        tile_sums[blockIdx.x] = tot;
-    }
-}
-
-// Start of a call: the control block (failure summary, total, pool cursor) and `volumes` are reset by one
-// small kernel instead of a host-to-device copy and a memset.
+// Start of a call: the control block (failure summary, total, pool cursor, scan ticket) and `volumes` are reset
+// by one small kernel instead of a host-to-device copy and a memset.
 __global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 32) ctl[i] = i == 1 ? ~0ull : 0ull;  // [1]: first failing uid, an atomicMin target
     if (i < n_cells) volumes[i] = 0.0;
 }
 
-// host_copy (optional): pinned host memory that receives the 32-word control block — the march (and
-// k_resolve) are done when this single workgroup runs, so `total`, the failure summary and the pool cursor
-// are final and the call needs no device-to-host copy after its last kernel.
-__global__ __launch_bounds__(1024) void k_scan_tiles(int64_t *__restrict__ tile_sums, int64_t n_tiles,
-                                                     int64_t *__restrict__ total,
-                                                     const unsigned long long *__restrict__ ctl,
-                                                     unsigned long long *__restrict__ host_copy) {
-    __shared__ int64_t wsum[16];
+// Pass 1 of the scan: the sum of every tile of kScanTile counts.  The block that finishes last (a ticket
+// in the control block, no waiting) then scans the tile sums into exclusive tile offsets, writes the
+// total, and — host_copy, optional — copies the 32-word control block to pinned host memory: the march (and
+// k_resolve) are over when this kernel runs, so `total`, the failure summary and the pool cursor are final
+// and the call needs no device-to-host copy after its last kernel.
+__global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__restrict__ counts, int64_t n,
+                                                               int64_t *__restrict__ tile_sums, int64_t n_tiles,
+                                                               int64_t *__restrict__ total,
+                                                               unsigned int *__restrict__ ticket,
+                                                               const unsigned long long *__restrict__ ctl,
+                                                               unsigned long long *__restrict__ host_copy) {
+    __shared__ int64_t red[kScanBlock / 64];
     __shared__ int64_t carry;
+    __shared__ int last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
+    const int64_t i0 = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
+    int64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j)
+        if (i0 + j < n) s += counts[i0 + j];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wv] = s;
     __syncthreads();
-    for (int64_t base = 0; base < n_tiles; base += 1024) {
+    if (threadIdx.x == 0) {
+        int64_t tot = 0;
+        for (int w = 0; w < kScanBlock / 64; ++w) tot += red[w];
+        __hip_atomic_store(&tile_sums[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned int)(n_tiles - 1);
+        carry = 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    for (int64_t base = 0; base < n_tiles; base += kScanBlock) {
         const int64_t i = base + threadIdx.x;
-        const int64_t v = i < n_tiles ? tile_sums[i] : 0;
-        int64_t incl = v;  // inclusive scan inside the wave, then across the 16 waves
+        const int64_t v = i < n_tiles ? __hip_atomic_load(&tile_sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int64_t incl = v;  // inclusive scan inside the wave, then across the block's waves
         for (int off = 1; off < 64; off <<= 1) {
             const int64_t up = __shfl_up(incl, off, 64);
             if (lane >= off) incl += up;
         }
-        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();  // red[] of the previous round has been read
+        if (lane == 63) red[wv] = incl;
         __syncthreads();
         int64_t wave_off = 0;
-        for (int w = 0; w < wv; ++w) wave_off += wsum[w];
+        for (int w = 0; w < wv; ++w) wave_off += red[w];
         if (i < n_tiles) tile_sums[i] = carry + wave_off + incl - v;  // exclusive
         __syncthreads();
-        if (threadIdx.x == 1023) carry += wave_off + incl;
+        if (threadIdx.x == kScanBlock - 1) carry += wave_off + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
@@ -895,7 +900,8 @@ struct rt_tracks {
     int64_t total = 0;
     DevBuf<int32_t> counts, status, element;
     DevBuf<int64_t> offsets, tile_sums;
-    // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag
+    // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag,
+    // 20 ticket of the scan's "last block" step
     DevBuf<unsigned long long> ctl;
 #ifdef RT_TIMING
     DevBuf<unsigned long long> dbg;
@@ -1263,7 +1269,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     int64_t *const d_total = reinterpret_cast<int64_t *>(t->ctl.p + 16);
     int32_t *const d_cursor = reinterpret_cast<int32_t *>(t->ctl.p + 18);
     unsigned long long *const h_res = t->h_ctl + 32;
-    unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tiles writes it)
+    unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tile_sums writes it)
     RT_HIP(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
     std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
     RT_HIP(t->volumes.reserve(m->n_cells));
@@ -1295,13 +1301,12 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     unsigned long long fi[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float f = 0;
 
-    // copy_out: k_scan_tiles also writes the control block to the pinned host copy; scale: k_scan_write also
+    // copy_out: k_scan_tile_sums' last block also writes the control block to the pinned host copy; scale: k_scan_write also
     // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
     auto scan_counts = [&](bool copy_out, bool scale) -> int {
         if (n > 0) {
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
-                               t->tile_sums.p);
-            hipLaunchKernelGGL(rt::k_scan_tiles, dim3(1), dim3(1024), 0, s, t->tile_sums.p, n_tiles, d_total,
+                               t->tile_sums.p, n_tiles, d_total, reinterpret_cast<unsigned int *>(t->ctl.p + 20),
                                (const unsigned long long *)t->ctl.p, copy_out ? h_res_dev : (unsigned long long *)nullptr);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, d_total, t->offsets.p, scale ? t->volumes.p : (double *)nullptr, m->n_cells,
