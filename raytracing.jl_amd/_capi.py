@@ -18,7 +18,7 @@ SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_status_message", "rt_device_count",
     "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
-    "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_volumes", "rt_device_pointers",
+    "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option",
     "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
 )
@@ -108,6 +108,8 @@ def lib():
     L.rt_fetch_offsets.argtypes = [_vp, _lp, _ip]
     L.rt_fetch_segments.restype = C.c_int32
     L.rt_fetch_segments.argtypes = [_vp, _dp, _dp, _dp, _dp, _dp, _ip]
+    L.rt_fetch_segments_pinned.restype = C.c_int32
+    L.rt_fetch_segments_pinned.argtypes = [_vp, C.POINTER(C.c_void_p)]
     L.rt_fetch_volumes.restype = C.c_int32
     L.rt_fetch_volumes.argtypes = [_vp, _dp]
     L.rt_device_pointers.restype = C.c_int32
@@ -234,10 +236,29 @@ class DeviceTracks:
         _check(lib().rt_fetch_offsets(self._h, off.ctypes.data_as(_lp), st.ctypes.data_as(_ip)))
         return off, st[: self.n]
 
+    def fetch_segments_pinned(self):
+        """The records in page-locked host buffers owned by this handle (``rt_fetch_segments_pinned``): numpy
+        views, valid until the next ``segmentize`` / ``fetch_segments_pinned`` / ``close`` of this handle —
+        the copy runs at the PCIe rate instead of page-faulting into fresh arrays."""
+        n = self.total
+        ptrs = (C.c_void_p * 6)()
+        _check(lib().rt_fetch_segments_pinned(self._h, ptrs))
+        out = {}
+        for i, k in enumerate(("px", "py", "qx", "qy", "ell", "element")):
+            ctype = C.c_double if i < 5 else C.c_int32
+            if n == 0:
+                out[k] = np.zeros(0, np.float64 if i < 5 else np.int32)
+                continue
+            a = np.ctypeslib.as_array((ctype * n).from_address(ptrs[i]))
+            a.flags.writeable = False
+            out[k] = a
+        self._pinned_views = out  # keep the handle alive as long as the views are reachable through it
+        return out
+
     def fetch_segments(self):
         n = self.total
-        out = {k: np.zeros(n, np.float64) for k in ("px", "py", "qx", "qy", "ell")}
-        out["element"] = np.zeros(n, np.int32)
+        out = {k: np.empty(n, np.float64) for k in ("px", "py", "qx", "qy", "ell")}
+        out["element"] = np.empty(n, np.int32)
         _check(lib().rt_fetch_segments(self._h, *[out[k].ctypes.data_as(_dp) for k in ("px", "py", "qx", "qy", "ell")],
                                        out["element"].ctypes.data_as(_ip)))
         return out

@@ -919,6 +919,8 @@ struct rt_tracks {
     DevBuf<double> s_px, s_py, s_qx, s_qy, s_ell, p_sum;
     double sum_ell = 0.0;
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
+    void *pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rt_fetch_segments_pinned
+    size_t pin_cap = 0;                                                     // records
     hipEvent_t ev[8] = {};
     double ms[8] = {};
     int64_t n_failed = 0, first_failed_uid = 0;
@@ -1014,6 +1016,7 @@ void free_tracks(rt_tracks *t) {
     t->dbg.release();
 #endif
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
+    for (void *&q : t->pin) { if (q) (void)hipHostFree(q); q = nullptr; }
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->volumes_prev.release(); t->delta_s.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
@@ -1558,6 +1561,27 @@ int32_t rt_fetch_segments(rt_tracks *t, double *px, double *py, double *qx, doub
     if (qy) RT_HIP(hipMemcpy(qy, t->sqy.p, nb, hipMemcpyDeviceToHost));
     if (ell) RT_HIP(hipMemcpy(ell, t->sell.p, nb, hipMemcpyDeviceToHost));
     if (element) RT_HIP(hipMemcpy(element, t->element.p, sizeof(int32_t) * (size_t)t->total, hipMemcpyDeviceToHost));
+    return RT_SUCCESS;
+}
+
+int32_t rt_fetch_segments_pinned(rt_tracks *t, void **host_ptrs) {
+    if (!t || !host_ptrs) { set_error("null argument"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    RT_HIP(hipSetDevice(t->mesh->device));
+    const size_t n = (size_t)t->total;
+    if (n > t->pin_cap) {
+        for (void *&q : t->pin) { if (q) (void)hipHostFree(q); q = nullptr; }
+        t->pin_cap = 0;
+        const size_t cap = n + n / 8 + 64;
+        for (int a = 0; a < 6; ++a) RT_HIP(hipHostMalloc(&t->pin[a], cap * (a < 5 ? sizeof(double) : sizeof(int32_t)), hipHostMallocDefault));
+        t->pin_cap = cap;
+    }
+    hipStream_t s = t->mesh->stream;
+    const void *src[6] = {t->spx.p, t->spy.p, t->sqx.p, t->sqy.p, t->sell.p, t->element.p};
+    for (int a = 0; a < 6 && n > 0; ++a)
+        RT_HIP(hipMemcpyAsync(t->pin[a], src[a], n * (a < 5 ? sizeof(double) : sizeof(int32_t)), hipMemcpyDeviceToHost, s));
+    RT_HIP(hipStreamSynchronize(s));
+    for (int a = 0; a < 6; ++a) host_ptrs[a] = t->pin[a];
     return RT_SUCCESS;
 }
 

@@ -42,9 +42,11 @@ class SegmentStore:
 
 
 def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, device: int = 0,
-               fetch: bool = True, walk: bool = True, check: bool = True) -> TrackGenerator:
+               fetch=True, walk: bool = True, check: bool = True) -> TrackGenerator:
     """``segmentize!(t; k=5, rtol=√eps)``.  ``fetch=False`` leaves the results on the device
-    (``t.device_tracks.device_pointers()``) for consumers that stay on the GPU.  ``walk=False``
+    (``t.device_tracks.device_pointers()``) for consumers that stay on the GPU; ``fetch="pinned"``
+    returns views of page-locked buffers owned by ``t.device_tracks`` (PCIe rate, no page faults;
+    valid until the next ``segmentize`` of ``t``) instead of fresh arrays.  ``walk=False``
     disables the certified walk step of the device march (every iteration then runs the
     literal locate + intersect step); results are identical either way.  ``check=False`` does
     not raise for failed tracks (the reference would have thrown at the first one) and leaves
@@ -68,7 +70,7 @@ def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, dev
         raise RuntimeError(_capi.status_message(st, uid))
     if fetch:
         off, t.track_status = dt.fetch_offsets()
-        s = dt.fetch_segments()
+        s = dt.fetch_segments_pinned() if fetch == "pinned" else dt.fetch_segments()
         t.segments = SegmentStore(off, s["px"], s["py"], s["qx"], s["qy"], s["ell"], s["element"])
         t.volumes = dt.fetch_volumes()
     return t

@@ -202,3 +202,21 @@ def test_bad_arguments_are_refused_not_launched(rt, traced):
     bad.cell_nodes = cells
     with pytest.raises(_capi.RtError, match="out of range"):
         _capi.DeviceMesh(bad, 0)
+
+
+def test_pinned_fetch_equals_plain_fetch(rt, traced):
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    aq = tg.azimuthal_quadrature
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    a = dt.fetch_segments()
+    b = dt.fetch_segments_pinned()
+    for k in a:
+        assert b[k].dtype == a[k].dtype and np.array_equal(a[k], b[k]), k
+    dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    c = dt.fetch_segments_pinned()  # buffers are reused
+    for k in a:
+        assert np.array_equal(a[k], c[k]), k

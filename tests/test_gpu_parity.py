@@ -117,3 +117,11 @@ def test_device_resident_results_as_torch_tensors(rt, traced, oracle_run):
     g = rtd.allgather_segments(local)  # world size 1: identity + offsets
     assert np.array_equal(g["offsets"].cpu().numpy(), ref["offsets"])
     rtd.allreduce_volumes(vol)  # no-op without a process group
+
+
+def test_pinned_fetch_through_the_host_mirror(rt, traced, oracle_run):
+    """segmentize(tg, fetch="pinned"): the same records as the default fetch, as views of page-locked buffers."""
+    tg = traced(8, 2e-2)
+    rt.segmentize(tg, fetch="pinned")
+    _compare(tg, oracle_run(tg))
+    assert not tg.segments.px.flags.writeable
