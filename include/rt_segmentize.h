@@ -123,8 +123,10 @@ int32_t rt_fetch_volumes(rt_tracks *tracks, double *volumes);
 /* Like rt_fetch_segments, but into page-locked host buffers owned by the handle (allocated on first use and
  * reused): host_ptrs[6] receives px, py, qx, qy, ell (double *) and element (int32_t *), `total` entries
  * each.  A fresh pageable destination costs a page fault per 4 KB while the copy runs (C3's 410 MB: 25-42 ms);
- * these buffers take the same records at the PCIe rate (7 ms).  The pointers stay valid until the next
- * rt_segmentize, rt_fetch_segments_pinned or rt_tracks_destroy on this handle. */
+ * these buffers take the same records at the PCIe rate (7 ms).  Page-locking itself is slow (≈45 ms for
+ * 410 MB), so one set of buffers survives its handle in a process-wide cache and serves the next handle.
+ * The pointers stay valid until the next rt_segmentize, rt_fetch_segments_pinned or rt_tracks_destroy on
+ * this handle. */
 int32_t rt_fetch_segments_pinned(rt_tracks *tracks, void **host_ptrs);
 
 /*

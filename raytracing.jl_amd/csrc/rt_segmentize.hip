@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -1007,6 +1008,8 @@ void free_mesh(rt_mesh *m) {
     delete m;
 }
 
+void pin_release_to_cache(rt_tracks *t);  // defined with rt_fetch_segments_pinned
+
 void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release();
@@ -1016,7 +1019,7 @@ void free_tracks(rt_tracks *t) {
     t->dbg.release();
 #endif
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
-    for (void *&q : t->pin) { if (q) (void)hipHostFree(q); q = nullptr; }
+    pin_release_to_cache(t);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->volumes_prev.release(); t->delta_s.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
@@ -1564,17 +1567,50 @@ int32_t rt_fetch_segments(rt_tracks *t, double *px, double *py, double *qx, doub
     return RT_SUCCESS;
 }
 
+// Page-locked host buffers are expensive to create (≈45 ms for C3's 410 MB) and cheap to keep: one set is kept
+// process-wide when a handle dies, so that a host that creates a fresh handle per call (the Julia shim) pays
+// for pinning once.
+namespace {
+struct PinSet { void *p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t cap = 0; };
+PinSet g_pin_cache;
+std::mutex g_pin_mutex;
+void pin_free(PinSet &ps) {
+    for (void *&q : ps.p) { if (q) (void)hipHostFree(q); q = nullptr; }
+    ps.cap = 0;
+}
+}  // namespace
+
+namespace {
+void pin_release_to_cache(rt_tracks *t) {
+    if (!t->pin_cap) return;
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    PinSet mine;
+    for (int a = 0; a < 6; ++a) { mine.p[a] = t->pin[a]; t->pin[a] = nullptr; }
+    mine.cap = t->pin_cap; t->pin_cap = 0;
+    if (mine.cap > g_pin_cache.cap) std::swap(mine, g_pin_cache);
+    pin_free(mine);
+}
+}  // namespace
+
 int32_t rt_fetch_segments_pinned(rt_tracks *t, void **host_ptrs) {
     if (!t || !host_ptrs) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
     RT_HIP(hipSetDevice(t->mesh->device));
     const size_t n = (size_t)t->total;
     if (n > t->pin_cap) {
-        for (void *&q : t->pin) { if (q) (void)hipHostFree(q); q = nullptr; }
-        t->pin_cap = 0;
-        const size_t cap = n + n / 8 + 64;
-        for (int a = 0; a < 6; ++a) RT_HIP(hipHostMalloc(&t->pin[a], cap * (a < 5 ? sizeof(double) : sizeof(int32_t)), hipHostMallocDefault));
-        t->pin_cap = cap;
+        pin_release_to_cache(t);
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mutex);
+            if (g_pin_cache.cap >= n) {
+                for (int a = 0; a < 6; ++a) { t->pin[a] = g_pin_cache.p[a]; g_pin_cache.p[a] = nullptr; }
+                t->pin_cap = g_pin_cache.cap; g_pin_cache.cap = 0;
+            }
+        }
+        if (n > t->pin_cap) {
+            const size_t cap = n + n / 8 + 64;
+            for (int a = 0; a < 6; ++a) RT_HIP(hipHostMalloc(&t->pin[a], cap * (a < 5 ? sizeof(double) : sizeof(int32_t)), hipHostMallocDefault));
+            t->pin_cap = cap;
+        }
     }
     hipStream_t s = t->mesh->stream;
     const void *src[6] = {t->spx.p, t->spy.p, t->sqx.p, t->sqy.p, t->sell.p, t->element.p};
