@@ -125,6 +125,12 @@ __device__ __forceinline__ bool near_bb(double x, double b, double atol) {
     return ((int)(x == b) | ((int)isfin(x) & (int)(fabs(x - b) <= tol))) != 0;
 }
 __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
+    // atol > 0 (every real call: atol = tiny_step; wave-uniform): rtol = 0 and the box is finite (rt_mesh_create
+    // checks), so x == b || (isfinite(x) && |x - b| <= atol) is |x - b| <= atol — 8 instead of ~60 instructions
+    // per march iteration
+    if (atol > 0.0)
+        return ((int)(fabs(x - m.bx1) <= atol) | (int)(fabs(x - m.bx0) <= atol) | (int)(fabs(y - m.by1) <= atol) |
+                (int)(fabs(y - m.by0) <= atol)) != 0;
     return ((int)near_bb(x, m.bx1, atol) | (int)near_bb(x, m.bx0, atol) | (int)near_bb(y, m.by1, atol) |
             (int)near_bb(y, m.by0, atol)) != 0;
 }

@@ -962,7 +962,10 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     }
     // --- node grid, per-cell walk records and certificate margins (rt_mesh_prep.hpp)
     const double W = bb[2] - bb[0], H = bb[3] - bb[1];
-    if (!(W > 0) || !(H > 0)) { set_error("empty bounding box"); return RT_ERR_INVALID; }
+    if (!(W > 0) || !(H > 0) || !std::isfinite(W) || !std::isfinite(H)) {  // also: inboundary() relies on a finite box
+        set_error("empty or non-finite bounding box");
+        return RT_ERR_INVALID;
+    }
     rtprep::Prep P = rtprep::prepare(x, y, n_nodes, cn.data(), n_cells, bb);
     const std::vector<int32_t> &gstart = P.gstart, &gnode = P.gnode;
     const double gh = P.gh, ginv = P.ginv;
