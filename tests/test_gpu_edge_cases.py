@@ -202,6 +202,12 @@ def test_bad_arguments_are_refused_not_launched(rt, traced):
     bad.cell_nodes = cells
     with pytest.raises(_capi.RtError, match="out of range"):
         _capi.DeviceMesh(bad, 0)
+    # the march's boundary test assumes a finite box (rt_device.hpp, inboundary)
+    unbounded = rt.Mesh.__new__(rt.Mesh)
+    unbounded.__dict__.update(tg.mesh.__dict__)
+    unbounded.bb_max = (float("inf"), tg.mesh.bb_max[1])
+    with pytest.raises(_capi.RtError, match="bounding box"):
+        _capi.DeviceMesh(unbounded, 0)
 
 
 def test_pinned_fetch_equals_plain_fetch(rt, traced):
