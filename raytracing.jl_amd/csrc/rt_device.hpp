@@ -26,18 +26,19 @@ constexpr int kMaxK = 8;                                // cap on the knn fallba
 
 // Walk record for (cell, entry edge): the cell's vertices rotated cyclically so that rotated
 // edge 0 = (v0, v1) is the entry edge, in the cell's own edge orientation (built on the host,
-// rt_mesh_prep.hpp).  128 B, 128-B aligned: one lane fetches its next cell with eight
-// independent 16-B loads of one cache line (one L2 round trip).
-struct __attribute__((aligned(128))) WalkRec {
-    int32_t next1, next2;  // record index (3*cell' + entry') across rotated edge 1 / 2; -1 on the boundary
-    int32_t cell;          // 0-based cell id
-    int32_t meta;          // bits 0..7: bound on non-vertex nodes nearer than the nearest vertex (255: no walk)
+// rt_mesh_prep.hpp).  80 B: one lane fetches its next cell with five independent 16-B loads — every load
+// instruction of such a per-lane gather costs the wave ~50 cycles when the lanes of a quad read the same
+// line and up to ~250 when they all differ (tools/micro/bench_gather.hip), so the record holds only what
+// cannot be had otherwise: v0 and v1 are the endpoints (a, b) of the predecessor's exit edge, already in the
+// walk state, and the cell id is record index / 3.
+constexpr int kWalkIdBits = 27;
+struct __attribute__((aligned(16))) WalkRec {
+    uint64_t hdr;          // bits 0..26 next1 + 1, 27..53 next2 + 1 (0: boundary), 54..61 extras bound, 62: v0 == a
     double dT;             // det of the barycentric system in the ORIGINAL node order, reference operation order
-    double pad0;
-    double x0, y0, x1, y1, x2, y2;         // rotated vertices; v2 is opposite the entry edge
+    double x2, y2;         // the vertex opposite the entry edge
     double e1A, e1B, e1C, e2A, e2B, e2C;   // general_form (src/intersection.jl:11-18) of rotated edges 1, 2
 };
-static_assert(sizeof(WalkRec) == 128, "WalkRec layout");
+static_assert(sizeof(WalkRec) == 80, "WalkRec layout");
 
 // Flattened mesh in HBM (SoA; all ids 0-based on the device, converted at upload).
 // What only the generic step reads (locate + intersections): kept behind a pointer in constant address space,
@@ -454,11 +455,11 @@ struct Walk {
 
 // State for the next walk step after a segment was emitted by the generic step in `cell` with
 // its exit point on edge `ko` (0..2).
-__device__ __forceinline__ void walk_enter(const DMesh &m, Walk &w, int32_t cell, int ko) {
-    const RT_G WalkRec *R = m.wrec + 3 * cell;  // entry edge 0 => vertices in the original node order
-    const double x1 = R->x0, y1 = R->y0, x2 = R->x1, y2 = R->y1, x3 = R->x2, y3 = R->y2;
+__device__ __forceinline__ void walk_enter(const DMesh &m, const DGeo &g, Walk &w, int32_t cell, int ko) {
+    const int32_t n1 = g.cn[3 * cell], n2 = g.cn[3 * cell + 1], n3 = g.cn[3 * cell + 2];
+    const double x1 = g.x[n1], y1 = g.y[n1], x2 = g.x[n2], y2 = g.y[n2], x3 = g.x[n3], y3 = g.y[n3];
     w.T = cell;
-    w.dT = R->dT;
+    w.dT = m.wrec[3 * cell].dT;
     w.ax = ko == 0 ? x1 : (ko == 1 ? x2 : x3);
     w.ay = ko == 0 ? y1 : (ko == 1 ? y2 : y3);
     w.bx = ko == 0 ? x2 : (ko == 1 ? x3 : x1);
@@ -472,16 +473,19 @@ enum WalkResult { kWalkGeneric = 0, kWalkSkip = 1, kWalkEmit = 2 };
 
 // Register copy of the walk record the lane needs next.
 struct NextRec {
-    int32_t n1, n2, cell, meta;
-    double dT, x0, y0, x1, y1, x2, y2, e1A, e1B, e1C, e2A, e2B, e2C;
+    uint64_t hdr;
+    double dT, x2, y2, e1A, e1B, e1C, e2A, e2B, e2C;
 };
 __device__ __forceinline__ void load_next(const DMesh &m, int32_t pred, NextRec &r) {
     const RT_G WalkRec *R = m.wrec + (pred >= 0 ? pred : 0);
-    r.n1 = R->next1; r.n2 = R->next2; r.cell = R->cell; r.meta = R->meta;
-    r.dT = R->dT;
-    r.x0 = R->x0; r.y0 = R->y0; r.x1 = R->x1; r.y1 = R->y1; r.x2 = R->x2; r.y2 = R->y2;
+    r.hdr = R->hdr; r.dT = R->dT;
+    r.x2 = R->x2; r.y2 = R->y2;
     r.e1A = R->e1A; r.e1B = R->e1B; r.e1C = R->e1C; r.e2A = R->e2A; r.e2B = R->e2B; r.e2C = R->e2C;
 }
+__device__ __forceinline__ int32_t rec_next1(uint64_t hdr) { return (int32_t)(hdr & ((1u << kWalkIdBits) - 1)) - 1; }
+__device__ __forceinline__ int32_t rec_next2(uint64_t hdr) { return (int32_t)((hdr >> kWalkIdBits) & ((1u << kWalkIdBits) - 1)) - 1; }
+__device__ __forceinline__ int32_t rec_extras(uint64_t hdr) { return (int32_t)(hdr >> (2 * kWalkIdBits)) & 255; }
+__device__ __forceinline__ bool rec_same(uint64_t hdr) { return ((hdr >> (2 * kWalkIdBits + 8)) & 1) != 0; }
 
 // One walk step at xp for the lane's predicted record.  On kWalkEmit: (qx,qy) is the exit point,
 // `ell` the segment length (entry point = previous exit point, bit-identical by symmetry of the
@@ -494,11 +498,14 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
                                          double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
                                          double &qy, double &ell) {
     const bool has = m.walk_ok && w.pred >= 0;
-    const int32_t n1 = nr.n1, n2 = nr.n2, Tn = nr.cell, meta = nr.meta;
+    const int32_t n1 = rec_next1(nr.hdr), n2 = rec_next2(nr.hdr), Tn = (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u);
     const double dTn = nr.dT;
-    const double x0 = nr.x0, y0 = nr.y0, x1 = nr.x1, y1 = nr.y1, x2 = nr.x2, y2 = nr.y2;
+    // the entry edge (v0, v1) of T' is the exit edge (a, b) of T, in T''s orientation
+    const bool same = rec_same(nr.hdr);
+    const double x0 = same ? w.ax : w.bx, y0 = same ? w.ay : w.by, x1 = same ? w.bx : w.ax, y1 = same ? w.by : w.ay;
+    const double x2 = nr.x2, y2 = nr.y2;
     const double e1A = nr.e1A, e1B = nr.e1B, e1C = nr.e1C, e2A = nr.e2A, e2B = nr.e2B, e2C = nr.e2C;
-    bool ok = has && (meta & 255) <= kk;
+    bool ok = has && rec_extras(nr.hdr) <= kk;
     // --- certificate 1: the track line clears every vertex of T' by d_vertex and crosses the entry edge
     const double s0 = tA * x0 + tB * y0 + tC, s1 = tA * x1 + tB * y1 + tC, s2 = tA * x2 + tB * y2 + tC;
     ok = ok && fabs(s0) >= m.d_vertex && fabs(s1) >= m.d_vertex && fabs(s2) >= m.d_vertex;
@@ -562,7 +569,9 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
 // edge at a very small angle takes hundreds of such steps (src/track.jl:147-150); this keeps each
 // of them to a few dozen instructions instead of a full march iteration.
 __device__ __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const NextRec &nr, double xpx, double xpy) {
-    const double x0 = nr.x0, y0 = nr.y0, x1 = nr.x1, y1 = nr.y1, x2 = nr.x2, y2 = nr.y2;
+    const bool same = rec_same(nr.hdr);
+    const double x0 = same ? w.ax : w.bx, y0 = same ? w.ay : w.by, x1 = same ? w.bx : w.ax, y1 = same ? w.by : w.ay;
+    const double x2 = nr.x2, y2 = nr.y2;
     const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     const double sg = area2 > 0 ? 1.0 : -1.0;
     const double aa = fabs(area2);
@@ -581,7 +590,7 @@ __device__ __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, c
     const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
     const double dab = da < db ? da : db;
     const bool tie = dc == dab || dcp == dab || dc == dcp;
-    const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < nr.cell);
+    const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u));
     return !tie && t_first;
 }
 

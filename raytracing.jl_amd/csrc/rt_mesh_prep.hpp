@@ -33,17 +33,20 @@ static_assert(sizeof(CellRecHost) == 144, "CellRec layout");
 
 // Rotated walk record for (cell, entry edge e): vertices rotated cyclically so that rotated
 // edge 0 = (v0, v1) is the entry edge, in the cell's own edge orientation.  Must match
-// rt::WalkRec (rt_device.hpp): 128 bytes.
+// rt::WalkRec (rt_device.hpp): 80 bytes = five 16-B loads per lane (the fetch costs the march
+// ~50-250 cycles per load instruction, tools/micro/bench_gather.hip).  v0 and v1 are not stored:
+// they are the endpoints of the predecessor's exit edge, which the walk state already holds
+// (same nodes, hence the same bits), in the same or the opposite order (`same` flag).
+constexpr int kWalkIdBits = 27;  // record ids + 1 must fit: 3 * n_cells + 1 < 2^27
 struct WalkRecHost {
-    int32_t next1, next2;  // record index 3*cell' + entry' across rotated edge 1 / 2, -1 on the boundary
-    int32_t cell;          // 0-based cell id
-    int32_t meta;          // bits 0..7 extras bound (255: no walk), bit 8: a vertex lies near the domain boundary
-    double dT;             // det of the barycentric system in the ORIGINAL node order (reference operation order)
-    double pad0;
-    double x0, y0, x1, y1, x2, y2;
+    uint64_t hdr;   // bits 0..26 next1 + 1, 27..53 next2 + 1 (record 3*cell' + entry' across rotated edge 1 / 2,
+                    // 0 on the boundary), 54..61 extras bound (255: no walk), 62: v0 is the `a` of the
+                    // predecessor's exit edge (a, b) — else v0 = b
+    double dT;      // det of the barycentric system in the ORIGINAL node order (reference operation order)
+    double x2, y2;  // the vertex opposite the entry edge
     double e1A, e1B, e1C, e2A, e2B, e2C;  // general_form of rotated edges 1 = (v1,v2) and 2 = (v2,v0)
 };
-static_assert(sizeof(WalkRecHost) == 128, "WalkRec layout");
+static_assert(sizeof(WalkRecHost) == 80, "WalkRec layout");
 
 struct Prep {
     std::vector<WalkRecHost> wrec;  // [3*n_cells]
@@ -208,6 +211,7 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         R.meta = extras > 254 ? 254 : extras;
     }
     // ---- rotated walk records
+    if ((uint64_t)3 * (uint64_t)n_cells + 1 >= (1ull << kWalkIdBits)) { P.walk_ok = false; P.note = "too many cells for the packed walk records"; }
     P.wrec.assign((size_t)3 * n_cells, WalkRecHost{});
     P.adjr.assign((size_t)3 * n_cells, -1);
     for (int32_t c = 0; c < n_cells; ++c)
@@ -224,26 +228,22 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                 }
             P.adjr[3 * c + k] = ki >= 0 ? 3 * nb + ki : -1;
         }
-    const double near_b = 1e-6 * std::max(W, H);
     for (int32_t c = 0; c < n_cells; ++c) {
         const CellRecHost &R = P.rec[c];
         const double x1 = R.vx[0], y1 = R.vy[0], x2 = R.vx[1], y2 = R.vy[1], x3 = R.vx[2], y3 = R.vy[2];
         // det of [x1 x2 x3; y1 y2 y3; 1 1 1] as StaticArrays evaluates it (src/mesh.jl:166-168)
         const double dT = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
-        bool near = false;
-        for (int k = 0; k < 3; ++k)
-            near = near || R.vx[k] - bb[0] < near_b || bb[2] - R.vx[k] < near_b || R.vy[k] - bb[1] < near_b ||
-                   bb[3] - R.vy[k] < near_b;
         for (int e = 0; e < 3; ++e) {
             WalkRecHost &Wr = P.wrec[3 * c + e];
-            const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
-            Wr.next1 = P.adjr[3 * c + i1];
-            Wr.next2 = P.adjr[3 * c + i2];
-            Wr.cell = c;
-            Wr.meta = (R.meta & 255) | (near ? 256 : 0);
+            const int i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+            // orientation of the entry edge relative to the neighbour's exit edge (a, b) = (its v_q, v_q+1)
+            bool same = false;
+            const int32_t back = P.adjr[3 * c + e];  // record (neighbour, its edge q) across the entry edge
+            if (back >= 0) same = cn[3 * c + e] == cn[3 * (back / 3) + back % 3];
+            Wr.hdr = (uint64_t)(P.adjr[3 * c + i1] + 1) | ((uint64_t)(P.adjr[3 * c + i2] + 1) << kWalkIdBits) |
+                     ((uint64_t)(R.meta & 255) << (2 * kWalkIdBits)) | ((uint64_t)(same ? 1 : 0) << (2 * kWalkIdBits + 8));
             Wr.dT = dT;
-            Wr.pad0 = 0.0;
-            Wr.x0 = R.vx[i0]; Wr.y0 = R.vy[i0]; Wr.x1 = R.vx[i1]; Wr.y1 = R.vy[i1]; Wr.x2 = R.vx[i2]; Wr.y2 = R.vy[i2];
+            Wr.x2 = R.vx[i2]; Wr.y2 = R.vy[i2];
             Wr.e1A = R.eA[i1]; Wr.e1B = R.eB[i1]; Wr.e1C = R.eC[i1];
             Wr.e2A = R.eA[i2]; Wr.e2B = R.eB[i2]; Wr.e2C = R.eC[i2];
         }

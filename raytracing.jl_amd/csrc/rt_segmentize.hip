@@ -362,7 +362,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             // first segment of a seeded piece: the seed itself (k_seed), then march on from its exit point
             element = sp.s_el[pi];
             px = sp.s_px[pi]; py = sp.s_py[pi]; qx = sp.s_qx[pi]; qy = sp.s_qy[pi]; ell = sp.s_ell[pi];
-            walk_enter(m, wk, element, sp.s_eq[pi]);
+            const int seq = sp.s_eq[pi];
+            if (m.walk_ok && seq >= 0) walk_enter(m, load_geo(m.geo), wk, element, seq);
+            else { wk.T = element; wk.pred = -1; }
             seed_pending = false;
         } else {
         // The reference locates first and tests the boundary second (:122-125); the locate
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             creep_run = 0;
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
-            if (m.walk_ok && eq >= 0) walk_enter(m, wk, element, eq);
+            if (m.walk_ok && eq >= 0) walk_enter(m, g, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
         }
         }
