@@ -260,8 +260,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    volatile int32_t *chunk_lds = reinterpret_cast<volatile int32_t *>(march_smem + (FUSE ? (size_t)m.n_cells * sizeof(double) : 0)) +
-                                  wib * kMaxChunks;
+    // (an LDS-address-space pointer: through a generic one these become FLAT accesses that drain vmcnt)
+    typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
+    lds_i32 *chunk_lds = (lds_i32 *)(march_smem + (FUSE ? (size_t)m.n_cells * sizeof(double) : 0)) + wib * kMaxChunks;
     if (MODE == kStage) {
         for (int c = lane; c < kMaxChunks; c += 64) chunk_lds[c] = -1;
         if (FUSE)
@@ -603,8 +604,12 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr+4, ...
     const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub+2, ...
-    volatile double *tx = tiles_x[k], *ty = tiles_y[k];
-    volatile int32_t *te = reinterpret_cast<volatile int32_t *>(tiles_x[k]);  // the x tile is reused for the cell ids
+    // LDS-address-space pointers: through generic pointers the tile accesses become FLAT instructions, which
+    // take the vector-memory path (and its in-order counter) beside the global loads and stores
+    typedef __attribute__((address_space(3))) volatile double lds_f64;
+    typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
+    lds_f64 *tx = (lds_f64 *)tiles_x[k], *ty = (lds_f64 *)tiles_y[k];
+    lds_i32 *te = (lds_i32 *)tiles_x[k];  // the x tile is reused for the cell ids
     const int64_t slot = (SPLIT ? (int64_t)sp.vw_wave[w] : w) * 64 + 16 * q + tl;  // lanes 0..15: their track's count / offset
     int32_t cnt = 0;
     int64_t off = 0;
