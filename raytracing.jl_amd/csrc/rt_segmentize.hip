@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -937,6 +938,17 @@ struct rt_tracks {
 
 namespace {
 
+// Wait for a stream the way a latency-bound caller wants it: hipStreamSynchronize may sleep on an interrupt and
+// wake well after the last kernel ended.  Poll for the first milliseconds, then sleep.
+hipError_t wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) return hipStreamSynchronize(s);
+    }
+}
+
 template <typename T>
 int upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s) {
     RT_HIP(b.reserve(n > 0 ? n : 1));
@@ -1468,7 +1480,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             int32_t cur[4] = {0, 0, 0, 0};
             if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
-            RT_HIP(hipStreamSynchronize(s));
+            RT_HIP(wait_stream(s));
             memcpy(fi, h_res, sizeof(fi));
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
