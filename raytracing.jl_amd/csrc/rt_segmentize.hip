@@ -318,6 +318,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     if (MODE == kFill) base = offsets[u];
     if (MODE == kFill || FUSE) w = out.delta_s[t.azim[u] - 1];
     int32_t my_chunk = -1;
+    RT_G double *row_qx = nullptr, *row_qy = nullptr;  // this lane's slots of row 0 of its current chunk
+    RT_G int32_t *row_el = nullptr;
     int i = 0;
     int32_t it = 0;
     const int32_t cap = (int32_t)(prm.iter_cap < 0x7fffffff ? prm.iter_cap : 0x7fffffff);
@@ -484,15 +486,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 }
             }
             if (my_chunk >= 0) {
-                const int64_t o = stage_slot(my_chunk, r, lane);
+                if (r == 0) {  // per-lane addresses of the chunk's row 0, kept in VGPRs (the staging pointers are
+                               // SGPR tuples that do not survive the generic branch unspilled)
+                    const int64_t o0 = stage_slot(my_chunk, 0, lane);
+                    row_qx = stg.qx + o0; row_qy = stg.qy + o0; row_el = stg.element + o0;
+                }
                 // A walk-step record starts where the lane's previous record ended (p = previous q, bit for
                 // bit) and ℓ = ‖p − q‖ is a function of the two: only q and the cell are staged (20 B instead
                 // of 44) and k_compact3 rebuilds p and ℓ.  Records of the generic step / a seed keep their
                 // own p and are marked by a negative element.
                 const bool derived = res == kWalkEmit && !from_seed;
-                stg.qx[o] = qx; stg.qy[o] = qy;
-                stg.element[o] = derived ? element + 1 : -(element + 1);
-                if (!derived) { stg.px[o] = px; stg.py[o] = py; }
+                row_qx[r * 16] = qx; row_qy[r * 16] = qy;
+                row_el[r * 16] = derived ? element + 1 : -(element + 1);
+                if (!derived) {
+                    const int64_t o = stage_slot(my_chunk, r, lane);
+                    stg.px[o] = px; stg.py[o] = py;
+                }
             }
             if (FUSE) atomicAdd(&hist[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
         }
