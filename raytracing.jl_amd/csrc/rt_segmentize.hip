@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -251,6 +252,19 @@ __device__ __forceinline__ unsigned long long rt_tick(double dep) {
     return t;
 }
 #endif
+// k_march's staging pointers are needed once per 32 iterations (chunk hand-out, row addresses) and on rare
+// records: they are read from the kernel-argument segment with scalar loads where they are used instead of
+// living in 19 SGPRs across the whole loop (which the kernel was spilling to VGPR lanes and reloading on
+// its hot path).  The struct mirrors k_march's parameter list.
+struct MarchArgsLayout {
+    DMesh m; DTracks t; DParams prm; int32_t *counts; int32_t *status; const int64_t *offsets; DOut out; DStage stg;
+    unsigned long long *fail_info; DSplit sp;
+};
+__device__ __forceinline__ const RT_K DStage *march_stage_args() {
+    const RT_K char *ka = (const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr();
+    return (const RT_K DStage *)(ka + offsetof(MarchArgsLayout, stg));
+}
+
 template <int MODE, int WAVES, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
@@ -265,6 +279,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
     lds_i32 *chunk_lds = (lds_i32 *)(march_smem + (FUSE ? (size_t)m.n_cells * sizeof(double) : 0)) + wib * kMaxChunks;
     if (MODE == kStage) {
+        // the argument-segment view of `stg` must be the argument itself (guards MarchArgsLayout against drift:
+        // a mismatch voids the attempt the way a pool overflow does, and the host reports it)
+        const RT_K DStage *sk = march_stage_args();
+        if (sk->cursor != stg.cursor || sk->qx != stg.qx || sk->element != stg.element || sk->pool_chunks != stg.pool_chunks) {
+            if (threadIdx.x == 0) stg.cursor[1] = 2;
+            return;
+        }
         for (int c = lane; c < kMaxChunks; c += 64) chunk_lds[c] = -1;
         if (FUSE)
             for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) hist[c] = 0.0;
@@ -331,8 +352,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
     const int kk = prm.k > 2 ? prm.k : 2;
     double lqx = 0.0, lqy = 0.0;  // exit point of the last emitted segment
+    // The walk step's mesh constants, held in VGPRs: as SGPRs they share a tuple of the argument load that the
+    // register allocator spills as a whole and reloads (8 v_readlane) several times per iteration.
+    DMesh mh = m;
+    asm volatile("" : "+v"(mh.d_vertex), "+v"(mh.eps_iso), "+v"(mh.l_min), "+v"(mh.wrec));
     NextRec nr;
-    load_next(m, -1, nr);
+    load_next(mh, -1, nr);
     // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
     // band.  Run as its own loop so that the 64 lanes of the wave, whose bands differ in length
     // (≈1/sin ϕ or 1/|cos ϕ| steps), reach their first locate together.
@@ -380,12 +405,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             break;  // :130-132
         }
-        load_next(m, wk.pred, nr);
+        load_next(mh, wk.pred, nr);
 #ifdef RT_TIMING
         const unsigned long long tB_ = rt_tick(RT_TIMING == 2 ? nr.e2C : xpx);
         tacc0 += tB_ - tA_;
 #endif
-        res = walk_step(m, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+        res = walk_step(mh, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
 #ifdef RT_TIMING
         tC_ = rt_tick(ell + (double)res);
         tacc1 += tC_ - tB_;
@@ -398,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             xpx = xpx + sx; xpy = xpy + sy;
             // creep on while the reference would keep locating T: each pass stands for one more march
             // iteration that ends in the same `continue`
-            while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && walk_still_skip(m, wk, nr, xpx, xpy)) {
+            while (it < cap && !inboundary(m, xpx, xpy, prm.tiny_step) && walk_still_skip(mh, wk, nr, xpx, xpy)) {
                 ++it;
                 xpx = xpx + sx; xpy = xpy + sy;
             }
@@ -472,11 +497,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                     int32_t c = chunk_lds[jL];
                     if (c == -1) {
                         if (lane == L) {
-                            c = atomicAdd((int32_t *)&stg.cursor[0], 1);
-                            if (c >= stg.pool_chunks) { c = -2; stg.cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
+                            const RT_K DStage *sk = march_stage_args();
+                            RT_G int32_t *cursor = sk->cursor;
+                            c = atomicAdd((int32_t *)&cursor[0], 1);
+                            if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
                             else {
-                                stg.ctab[wave_id * kMaxChunks + jL] = c;
-                                stg.cowner[c] = (int32_t)(wave_id * kMaxChunks + jL);
+                                sk->ctab[wave_id * kMaxChunks + jL] = c;
+                                sk->cowner[c] = (int32_t)(wave_id * kMaxChunks + jL);
                             }
                             chunk_lds[jL] = c;
                         }
@@ -489,7 +516,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 if (r == 0) {  // per-lane addresses of the chunk's row 0, kept in VGPRs (the staging pointers are
                                // SGPR tuples that do not survive the generic branch unspilled)
                     const int64_t o0 = stage_slot(my_chunk, 0, lane);
-                    row_qx = stg.qx + o0; row_qy = stg.qy + o0; row_el = stg.element + o0;
+                    const RT_K DStage *sk = march_stage_args();
+                    row_qx = sk->qx + o0; row_qy = sk->qy + o0; row_el = sk->element + o0;
                 }
                 // A walk-step record starts where the lane's previous record ended (p = previous q, bit for
                 // bit) and ℓ = ‖p − q‖ is a function of the two: only q and the cell are staged (20 B instead
@@ -500,7 +528,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 row_el[r * 16] = derived ? element + 1 : -(element + 1);
                 if (!derived) {
                     const int64_t o = stage_slot(my_chunk, r, lane);
-                    stg.px[o] = px; stg.py[o] = py;
+                    const RT_K DStage *sk = march_stage_args();
+                    sk->px[o] = px; sk->py[o] = py;
                 }
             }
             if (FUSE) atomicAdd(&hist[element], w * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
