@@ -125,6 +125,10 @@ __device__ __forceinline__ bool near_bb(double x, double b, double atol) {
     const double tol = atol > 0.0 ? atol : kRtolDefault * (ax > ab ? ax : ab);
     return ((int)(x == b) | ((int)isfin(x) & (int)(fabs(x - b) <= tol))) != 0;
 }
+// atol == 0 (never in practice): out of line, so that its constants do not occupy scalar registers in the march
+__device__ __noinline__ bool inboundary_general(double bx0, double by0, double bx1, double by1, double x, double y, double atol) {
+    return ((int)near_bb(x, bx1, atol) | (int)near_bb(x, bx0, atol) | (int)near_bb(y, by1, atol) | (int)near_bb(y, by0, atol)) != 0;
+}
 __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
     // atol > 0 (every real call: atol = tiny_step; wave-uniform): rtol = 0 and the box is finite (rt_mesh_create
     // checks), so x == b || (isfinite(x) && |x - b| <= atol) is |x - b| <= atol — 8 instead of ~60 instructions
@@ -132,8 +136,7 @@ __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, d
     if (atol > 0.0)
         return ((int)(fabs(x - m.bx1) <= atol) | (int)(fabs(x - m.bx0) <= atol) | (int)(fabs(y - m.by1) <= atol) |
                 (int)(fabs(y - m.by0) <= atol)) != 0;
-    return ((int)near_bb(x, m.bx1, atol) | (int)near_bb(x, m.bx0, atol) | (int)near_bb(y, m.by1, atol) |
-            (int)near_bb(y, m.by0, atol)) != 0;
+    return inboundary_general(m.bx0, m.by0, m.bx1, m.by1, x, y, atol);
 }
 
 // ------------------------------------------------------- point_in_triangle ---------------
