@@ -554,13 +554,15 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
         }
     }
     // --- advance the state to T' (only when emitting)
-    const bool em = res == kWalkEmit;
-    w.T = em ? Tn : w.T;
-    w.dT = em ? dTn : w.dT;
-    w.ax = em ? (exit1 ? x1 : x2) : w.ax; w.ay = em ? (exit1 ? y1 : y2) : w.ay;
-    w.bx = em ? (exit1 ? x2 : x0) : w.bx; w.by = em ? (exit1 ? y2 : y0) : w.by;
-    w.cx = em ? (exit1 ? x0 : x1) : w.cx; w.cy = em ? (exit1 ? y0 : y1) : w.cy;
-    w.pred = em ? (exit1 ? n1 : n2) : w.pred;
+    if (res == kWalkEmit) {
+        asm volatile("" ::: "memory");  // keep this a branch: as selects the update is twice the instructions
+        w.T = Tn;
+        w.dT = dTn;
+        w.ax = exit1 ? x1 : x2; w.ay = exit1 ? y1 : y2;
+        w.bx = exit1 ? x2 : x0; w.by = exit1 ? y2 : y0;
+        w.cx = exit1 ? x0 : x1; w.cy = exit1 ? y0 : y1;
+        w.pred = exit1 ? n1 : n2;
+    }
     return res;
 }
 
