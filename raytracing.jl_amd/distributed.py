@@ -179,7 +179,11 @@ class PipelinedVolumesAllReduce:
         k = self.n & 1
         w = self._work.get(k)
         if w is not None:
-            w.wait()  # NCCL: a stream-level wait; gloo: blocks until done
+            # two steps old: normally long finished, and a completion seen by the host orders everything
+            # launched from now on after it — no wait has to go into the stream
+            done = getattr(w, "is_completed", None)
+            if done is None or not done():
+                w.wait()  # NCCL: a stream-level wait; gloo: blocks until done
             self._work[k] = None
         return k
 
