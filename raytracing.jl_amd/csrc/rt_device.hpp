@@ -539,6 +539,7 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
     int res = ok ? kWalkEmit : kWalkGeneric;
     if (ok && !clearly_out) {
+        asm volatile("" ::: "memory");  // a real branch: hoisted, the division runs on every iteration for nothing
         const double lamT = numT / w.dT;
         if (lamT >= 0.0 - kRtolDefault) {
             // scan order of find_element: nearest of {a, b, c, c'}; T is met before T' iff that is c,
