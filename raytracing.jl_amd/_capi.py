@@ -221,8 +221,14 @@ class DeviceTracks:
         self.total = None
 
     def segmentize(self, tiny_step: float, k: int, rtol: float, delta_s, n_azim_2: int) -> int:
-        ds, dsp = _f64(delta_s)
-        self.total = int(_check(lib().rt_segmentize(self._h, tiny_step, k, rtol, dsp, n_azim_2)))
+        c = getattr(self, "_ds_cache", None)
+        if c is None or c[0] is not delta_s:
+            ds, dsp = _f64(delta_s)
+            c = (delta_s, ds, dsp)
+            # repeated calls with the same float64 array object reuse its pointer (no copy was made, so the
+            # pointer sees the live data)
+            self._ds_cache = c if ds is delta_s else None
+        self.total = int(_check(lib().rt_segmentize(self._h, tiny_step, k, rtol, c[2], n_azim_2)))
         return self.total
 
     def failed(self):
