@@ -282,8 +282,10 @@ class DeviceTracks:
         return {k: (arr[i] or 0) for i, k in enumerate(names)}
 
     def timing(self):
-        ms = np.zeros(8, np.float64)
-        _check(lib().rt_last_timing(self._h, ms.ctypes.data_as(_dp), 8))
+        ms = getattr(self, "_ms_buf", None)
+        if ms is None:
+            ms = self._ms_buf = (C.c_double * 8)()
+        _check(lib().rt_last_timing(self._h, ms, 8))
         # compact: staging -> CSR compaction (single-pass mode) or the second, writing march (two-pass mode)
         return dict(total=float(ms[0]), plan=float(ms[1]), march=float(ms[2]), scan=float(ms[3]), compact=float(ms[4]),
                     volumes=float(ms[5]))
