@@ -71,6 +71,31 @@ rt_mesh *rt_mesh_create(int32_t device, const double *x, const double *y, int32_
                         const int32_t *cell_nodes, int32_t n_cells, const int32_t *node_cells_ptrs,
                         const int32_t *node_cells_data, const double *bb);
 void rt_mesh_destroy(rt_mesh *mesh);
+/*
+ * Diagnostics of the mesh preprocessing: which regime the march of this mesh runs in.  The device march takes,
+ * per iteration, either the literal step (find_element + intersections, src/mesh.jl:103-146,
+ * src/intersection.jl:34-119) or a "walk step" that predicts the next cell through the edge adjacency and proves
+ * with per-record certificates that the reference's procedure gives the same answer; both give
+ * bit-identical records.  info[i], i < n_info (RT_MESH_INFO_*): see the index names below.  `note` (may be NULL)
+ * receives a 0-terminated remark of the preprocessing (why records were switched off), at most note_cap bytes.
+ */
+#define RT_MESH_INFO_WALK_ENABLED 0      /* 1: the walk step is in use (available and not switched off by "walk"=0) */
+#define RT_MESH_INFO_RECORDS 1           /* (cell, entry edge) records = 3 * n_cells */
+#define RT_MESH_INFO_RECORDS_WALK 2      /* records on which the walk step's certificates can hold */
+#define RT_MESH_INFO_EPS_MIN 3           /* smallest / largest barycentric isolation margin among those records */
+#define RT_MESH_INFO_EPS_MAX 4
+#define RT_MESH_INFO_D_VERTEX 5          /* clearance of the track line from a cell's vertices required by the walk step */
+#define RT_MESH_INFO_L_MIN 6             /* shortest chord the walk step handles */
+#define RT_MESH_INFO_CELLS_FRAGILE 7     /* cells whose own barycentric test is too noisy at the sqrt(eps) level */
+#define RT_MESH_INFO_CELLS_DEGENERATE 8  /* cells of (numerically) zero area */
+#define RT_MESH_INFO_EDGES_NONMANIFOLD 9 /* edges shared by more than two cells */
+#define RT_MESH_INFO_EXTRAS_MAX 10       /* largest scan-rank bound among the walk records */
+#define RT_MESH_INFO_PREP_MS 11          /* host time of the preprocessing inside rt_mesh_create */
+#define RT_MESH_INFO_KAPPA 12            /* expected segments per unit track length (Cauchy-Crofton) */
+#define RT_MESH_INFO_WALK_AVAILABLE 13   /* 1: at least one record can be walked */
+#define RT_MESH_INFO_COUNT 14
+int32_t rt_mesh_info(rt_mesh *mesh, double *info, int32_t n_info, char *note, int32_t note_cap);
+
 /* Enqueue all later work of this mesh's track sets on an existing hipStream_t (NULL = the
  * library's own stream). */
 int32_t rt_mesh_set_stream(rt_mesh *mesh, void *hip_stream);
@@ -104,6 +129,8 @@ void rt_tracks_destroy(rt_tracks *tracks);
  *   px,py,qx,qy,ell[total]   segment.p, segment.q, segment.ℓ   (src/segment.jl:23-33)
  *   element[total]           segment.element, 1-based Int32
  *   volumes[n_cells]         t.volumes
+ * `k` is find_element's knn width (src/mesh.jl:123): any k >= 0 is honoured (k < 0: RT_ERR_INVALID, where
+ * NearestNeighbors throws); n_azim_2 must cover every track's azim_idx (else RT_ERR_INVALID).
  * Returns the total number of segments (>= 0) or a negative RT_ERR_* code.  A non-OK track
  * status is not an error of this call: the caller decides (the shims throw the reference's
  * message for the first failing uid).
@@ -147,6 +174,11 @@ int32_t rt_device_pointers(rt_tracks *tracks, void **ptrs_dev);
  * fill, ms[5] volumes.  Unused slots are 0.  n = capacity of ms (>= 6).
  */
 int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
+
+/* Counters of the last rt_segmentize on this handle: stats[0] segment records, stats[1] records produced by the
+ * literal step (the walk step produced the rest; track pieces' seeds in split mode count as neither), stats[2]
+ * staging chunks used, stats[3] staging chunks allocated.  n = capacity of stats (>= 4). */
+int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side rows around the hot path: they run on the CPU, like in the

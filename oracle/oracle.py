@@ -114,7 +114,7 @@ class OracleMesh:
         return int(self._lib.orc_nn(self._h, x, y))
 
     def knn(self, x, y, k, skip=0):
-        out = np.zeros(8, np.int32)
+        out = np.zeros(max(int(k), 1), np.int32)
         n = self._lib.orc_knn(self._h, x, y, k, skip, out)
         return out[:n].copy()
 

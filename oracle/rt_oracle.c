@@ -138,12 +138,18 @@ static int kd_build(orc_mesh *m, int32_t lo, int32_t hi) {
     return id;
 }
 
-/* best-k list, ascending by squared distance; ties keep the earlier-found entry first */
-typedef struct { int k, n; double d2[8]; int32_t id[8]; } knn_heap;
+/* best-k list, ascending by (squared distance, node id): a total order, so that exactly equidistant nodes rank
+ * the same way whatever order a search structure visits them in (NearestNeighbors' own tie order is not
+ * specified; the device ranks the same way, csrc/rt_device.hpp node_before).  `k` is any width. */
+typedef struct { int k, n; double *d2; int32_t *id; } knn_heap;
+static inline int node_before(double d2a, int32_t ida, double d2b, int32_t idb) {
+    return d2a < d2b || (d2a == d2b && ida < idb);
+}
 static inline void knn_push(knn_heap *h, double d2, int32_t id) {
-    if (h->n == h->k && !(d2 < h->d2[h->n - 1])) return;
+    if (h->k <= 0) return;
+    if (h->n == h->k && !node_before(d2, id, h->d2[h->n - 1], h->id[h->n - 1])) return;
     int i = h->n < h->k ? h->n++ : h->n - 1;
-    while (i > 0 && h->d2[i - 1] > d2) { h->d2[i] = h->d2[i - 1]; h->id[i] = h->id[i - 1]; i--; }
+    while (i > 0 && node_before(d2, id, h->d2[i - 1], h->id[i - 1])) { h->d2[i] = h->d2[i - 1]; h->id[i] = h->id[i - 1]; i--; }
     h->d2[i] = d2; h->id[i] = id;
 }
 static void kd_query(const orc_mesh *m, int32_t node, double qx, double qy, knn_heap *h, int32_t skip) {
@@ -163,9 +169,13 @@ static void kd_query(const orc_mesh *m, int32_t node, double qx, double qy, knn_
     kd_query(m, near, qx, qy, h, skip);
     if (h->n < h->k || diff * diff <= h->d2[h->n - 1]) kd_query(m, far, qx, qy, h, skip);
 }
-/* k nearest nodes (0-based ids) other than `skip`, ascending by distance */
+/* k nearest nodes (0-based ids) other than `skip`, ascending by distance; `out` holds k entries */
 static int knn_nodes(const orc_mesh *m, double qx, double qy, int k, int32_t skip, int32_t *out) {
-    knn_heap h; h.k = k > 8 ? 8 : k; h.n = 0;
+    if (k <= 0) return 0;
+    double d2_small[16]; int32_t id_small[16];
+    knn_heap h; h.k = k; h.n = 0;
+    h.d2 = k <= 16 ? d2_small : (double *)malloc(sizeof(double) * (size_t)k);
+    h.id = k <= 16 ? id_small : (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
     if (m->use_bruteforce) {
         for (int32_t id = 0; id < m->n_nodes; id++) {
             if (id == skip) continue;
@@ -176,6 +186,7 @@ static int knn_nodes(const orc_mesh *m, double qx, double qy, int k, int32_t ski
         kd_query(m, 0, qx, qy, &h, skip);
     }
     for (int i = 0; i < h.n; i++) out[i] = h.id[i];
+    if (k > 16) { free(h.d2); free(h.id); }
     return h.n;
 }
 
@@ -250,16 +261,19 @@ static int32_t find_element(const orc_mesh *m, double x, double y, int k) {
         int32_t cell = m->nc_data[i];
         if (point_in_triangle(m, cell, x, y)) return cell;
     }
-    int32_t ids[8];
-    int n = knn_nodes(m, x, y, k, nn_id, ids); /* knn(kdtree, x, k, true, i -> i == nn_id) */
-    for (int j = 0; j < n; j++) {
+    int32_t ids_small[16];
+    int32_t *ids = k <= 16 ? ids_small : (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
+    int n = knn_nodes(m, x, y, k, nn_id, ids); /* knn(kdtree, x, k, true, i -> i == nn_id): any k */
+    int32_t found = -1;
+    for (int j = 0; j < n && found < 0; j++) {
         int32_t node = ids[j];
         for (int32_t i = m->nc_ptrs[node]; i < m->nc_ptrs[node + 1]; i++) {
             int32_t cell = m->nc_data[i];
-            if (point_in_triangle(m, cell, x, y)) return cell;
+            if (point_in_triangle(m, cell, x, y)) { found = cell; break; }
         }
     }
-    return -1;
+    if (k > 16) free(ids);
+    return found;
 }
 
 /* inboundary, src/mesh.jl:91-95 (atol > 0 => rtol = 0) */
@@ -509,8 +523,9 @@ void orc_fill_volumes(void *mv, int64_t n_tracks, const int64_t *seg_offsets, co
 int32_t orc_find_element(void *mv, double x, double y, int32_t k) { return find_element((orc_mesh *)mv, x, y, k); }
 int32_t orc_nn(void *mv, double x, double y) { int32_t id = -1; knn_nodes((orc_mesh *)mv, x, y, 1, -1, &id); return id + 1; }
 int32_t orc_knn(void *mv, double x, double y, int32_t k, int32_t skip1, int32_t *out) {
-    int32_t ids[8]; int n = knn_nodes((orc_mesh *)mv, x, y, k, skip1 - 1, ids);
-    for (int i = 0; i < n; i++) out[i] = ids[i] + 1;
+    /* `out` holds k entries */
+    int n = knn_nodes((orc_mesh *)mv, x, y, k, skip1 - 1, out);
+    for (int i = 0; i < n; i++) out[i] = out[i] + 1;
     return n;
 }
 int32_t orc_point_in_triangle(void *mv, int32_t cell, double x, double y) { return point_in_triangle((orc_mesh *)mv, cell, x, y); }

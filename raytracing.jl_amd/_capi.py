@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RT_SEGMENTIZE_LIB") or os.path.join(_CSRC, "librt_seg
 # every symbol include/rt_segmentize.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_status_message", "rt_device_count",
-    "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
+    "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_info", "rt_last_stats", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option",
@@ -91,6 +91,10 @@ def lib():
     L.rt_mesh_create.restype = _vp
     L.rt_mesh_create.argtypes = [C.c_int32, _dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp]
     L.rt_mesh_destroy.argtypes = [_vp]
+    L.rt_mesh_info.restype = C.c_int32
+    L.rt_mesh_info.argtypes = [_vp, _dp, C.c_int32, C.c_char_p, C.c_int32]
+    L.rt_last_stats.restype = C.c_int32
+    L.rt_last_stats.argtypes = [_vp, _lp, C.c_int32]
     L.rt_mesh_set_stream.restype = C.c_int32
     L.rt_mesh_set_stream.argtypes = [_vp, _vp]
     L.rt_mesh_get_stream.restype = _vp
@@ -171,6 +175,22 @@ class DeviceMesh:
         self._h = L.rt_mesh_create(device, xp, yp, self.n_nodes, cnp, self.n_cells, ptrp, datp, bbp)
         if not self._h:
             raise RtError(f"rt_mesh_create failed: {last_error()}")
+
+    INFO_NAMES = ("walk_enabled", "records", "records_walk", "eps_min", "eps_max", "d_vertex", "l_min", "cells_fragile",
+                  "cells_degenerate", "edges_nonmanifold", "extras_max", "prep_ms", "kappa", "walk_available")
+
+    def info(self) -> dict:
+        """``rt_mesh_info``: which regime the march of this mesh runs in (walk step on / off, how many
+        (cell, entry edge) records carry valid certificates, the margins) + the preprocessing's remark."""
+        v = (C.c_double * len(self.INFO_NAMES))()
+        note = C.create_string_buffer(256)
+        _check(lib().rt_mesh_info(self._h, v, len(self.INFO_NAMES), note, 256))
+        d = {k: float(v[i]) for i, k in enumerate(self.INFO_NAMES)}
+        for k in ("walk_enabled", "records", "records_walk", "cells_fragile", "cells_degenerate", "edges_nonmanifold",
+                  "extras_max", "walk_available"):
+            d[k] = int(d[k])
+        d["note"] = note.value.decode("utf-8", "replace")
+        return d
 
     def set_stream(self, stream_ptr: int | None):
         _check(lib().rt_mesh_set_stream(self._h, stream_ptr))
@@ -280,6 +300,13 @@ class DeviceTracks:
         _check(lib().rt_device_pointers(self._h, arr))
         names = ("offsets", "status", "px", "py", "qx", "qy", "ell", "element", "volumes")
         return {k: (arr[i] or 0) for i, k in enumerate(names)}
+
+    def stats(self) -> dict:
+        """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
+        v = (C.c_int64 * 4)()
+        _check(lib().rt_last_stats(self._h, v, 4))
+        return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
+                    chunks_used=int(v[2]), chunks_allocated=int(v[3]))
 
     def timing(self):
         ms = getattr(self, "_ms_buf", None)

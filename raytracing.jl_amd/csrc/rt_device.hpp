@@ -13,6 +13,9 @@
 // through by-reference structs would otherwise be loaded with flat_* instructions (which wait
 // on both vmcnt and lgkmcnt) instead of global_load_*.
 #define RT_G __attribute__((address_space(1)))
+// The geometry below is plain arithmetic: it also compiles for the host, where tests/host_march.hip runs it
+// against the CPU checker without a GPU (test infrastructure; the library itself never marches on the host).
+#define RT_HD __host__ __device__
 
 namespace rt {
 
@@ -22,7 +25,7 @@ __host__ __device__ inline RT_G T *as_global(T *p) { return (RT_G T *)p; }
 constexpr double kRtolDefault = 1.4901161193847656e-8;  // sqrt(eps(Float64)) = Base.rtoldefault
 constexpr double kHalfPi = 1.5707963267948966;          // Float64(pi)/2, src/intersection.jl:153
 constexpr int kMaxIter = 10000;                         // const MAX_ITER, src/track.jl:104
-constexpr int kMaxK = 8;                                // cap on the knn fallback width `k`
+constexpr int kMaxK = 8;                                // width of the in-register k-best list; larger `k` stream on
 
 // Walk record for (cell, entry edge): the cell's vertices rotated cyclically so that rotated
 // edge 0 = (v0, v1) is the entry edge, in the cell's own edge orientation (built on the host,
@@ -32,8 +35,10 @@ constexpr int kMaxK = 8;                                // cap on the knn fallba
 // cannot be had otherwise: v0 and v1 are the endpoints (a, b) of the predecessor's exit edge, already in the
 // walk state, and the cell id is record index / 3.
 constexpr int kWalkIdBits = 27;
+constexpr int kExtrasNever = 15;  // extras field of a record the walk step must not use (rt_mesh_prep.hpp)
 struct __attribute__((aligned(16))) WalkRec {
-    uint64_t hdr;          // bits 0..26 next1 + 1, 27..53 next2 + 1 (0: boundary), 54..61 extras bound, 62: v0 == a
+    uint64_t hdr;          // bits 0..26 next1 + 1, 27..53 next2 + 1 (0: boundary), 54..57 extras bound (15: never),
+                           // 58..62 isolation margin code (eps = 2^(code - 20)), 63: v0 == a
     double dT;             // det of the barycentric system in the ORIGINAL node order, reference operation order
     double x2, y2;         // the vertex opposite the entry edge
     double e1A, e1B, e1C, e2A, e2B, e2C;   // general_form (src/intersection.jl:11-18) of rotated edges 1, 2
@@ -61,7 +66,7 @@ struct DGeo {
 struct DMesh {
     const RT_G WalkRec *wrec;    // [3*n_cells] rotated walk records
     const RT_G int32_t *adjr;    // [3*n_cells] record index reached across edge k of cell c; -1 on the boundary
-    double eps_iso, d_vertex, l_min;     // certificate margins of the walk step
+    double d_vertex, l_min;      // mesh-wide certificate margins of the walk step (the isolation margin is per record)
     int32_t walk_ok;
     int32_t n_cells;
     double bx0, by0, bx1, by1;   // bounding box (bb_min, bb_max)
@@ -69,7 +74,7 @@ struct DMesh {
 };
 
 // The generic step's data, fetched with scalar loads where it is needed.
-__device__ __forceinline__ DGeo load_geo(const RT_K DGeo *p) {
+RT_HD __forceinline__ DGeo load_geo(const RT_K DGeo *p) {
     DGeo g;
     g.x = p->x; g.y = p->y; g.cn = p->cn; g.ncp = p->ncp; g.ncd = p->ncd; g.gstart = p->gstart; g.gnode = p->gnode;
     g.gx0 = p->gx0; g.gy0 = p->gy0; g.gh = p->gh; g.ginv = p->ginv;
@@ -95,19 +100,19 @@ struct DParams {
 };
 
 // ---------------------------------------------------------------- Base.isapprox ----------
-__device__ __forceinline__ bool isfin(double v) { return fabs(v) <= 1.7976931348623157e308; }
+RT_HD __forceinline__ bool isfin(double v) { return fabs(v) <= 1.7976931348623157e308; }
 
 // isapprox(x, y; rtol) scalar form with atol = 0
-__device__ __forceinline__ bool isapprox_s(double x, double y, double rtol) {
+RT_HD __forceinline__ bool isapprox_s(double x, double y, double rtol) {
     if (x == y) return true;
     if (!(isfin(x) && isfin(y))) return false;
     const double ax = fabs(x), ay = fabs(y);
     return fabs(x - y) <= rtol * (ax > ay ? ax : ay);
 }
-__device__ __forceinline__ double norm2(double a, double b) { return sqrt(a * a + b * b); }
+RT_HD __forceinline__ double norm2(double a, double b) { return sqrt(a * a + b * b); }
 
 // isapprox(p, q) for Point2D with default tolerances (array form: 2-norms)
-__device__ __forceinline__ bool isapprox_v2(double px, double py, double qx, double qy) {
+RT_HD __forceinline__ bool isapprox_v2(double px, double py, double qx, double qy) {
     const double d = norm2(px - qx, py - qy);
     if (isfin(d)) {
         const double np = norm2(px, py), nq = norm2(qx, qy);
@@ -120,16 +125,16 @@ __device__ __forceinline__ bool isapprox_v2(double px, double py, double qx, dou
 // x == b || (isfinite(x) && isfinite(b) && |x - b| <= max(atol, rtol·max(|x|,|b|))) with rtol = 0 when
 // atol > 0 and √eps otherwise.  Evaluated without branches (it runs once per march iteration and a
 // short-circuit form costs ~25 divergent branches there); the bounding box is finite.
-__device__ __forceinline__ bool near_bb(double x, double b, double atol) {
+RT_HD __forceinline__ bool near_bb(double x, double b, double atol) {
     const double ax = fabs(x), ab = fabs(b);
     const double tol = atol > 0.0 ? atol : kRtolDefault * (ax > ab ? ax : ab);
     return ((int)(x == b) | ((int)isfin(x) & (int)(fabs(x - b) <= tol))) != 0;
 }
 // atol == 0 (never in practice): out of line, so that its constants do not occupy scalar registers in the march
-__device__ __noinline__ bool inboundary_general(double bx0, double by0, double bx1, double by1, double x, double y, double atol) {
+RT_HD __noinline__ bool inboundary_general(double bx0, double by0, double bx1, double by1, double x, double y, double atol) {
     return ((int)near_bb(x, bx1, atol) | (int)near_bb(x, bx0, atol) | (int)near_bb(y, by1, atol) | (int)near_bb(y, by0, atol)) != 0;
 }
-__device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
+RT_HD __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {
     // atol > 0 (every real call: atol = tiny_step; wave-uniform): rtol = 0 and the box is finite (rt_mesh_create
     // checks), so x == b || (isfinite(x) && |x - b| <= atol) is |x - b| <= atol — 8 instead of ~60 instructions
     // per march iteration
@@ -143,7 +148,7 @@ __device__ __forceinline__ bool inboundary(const DMesh &m, double x, double y, d
 // src/mesh.jl:158-176: λ = [x1 x2 x3; y1 y2 y3; 1 1 1] \ [x, y, 1] by the closed form
 // StaticArrays uses for 3x3 (cofactors / det, det = col1 · (col2 × col3)); inside iff every
 // λ ∈ [0 - tol, 1 + tol], tol = sqrt(eps).
-__device__ __forceinline__ bool point_in_triangle(const DGeo &m, int32_t cell, double x, double y) {
+RT_HD __forceinline__ bool point_in_triangle(const DGeo &m, int32_t cell, double x, double y) {
     const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
     const double x1 = m.x[n1], y1 = m.y[n1];
     const double x2 = m.x[n2], y2 = m.y[n2];
@@ -165,10 +170,15 @@ struct KBest {
     int32_t id[kMaxK];
     int32_t n, k;
 };
-__device__ __forceinline__ void kbest_push(KBest &b, double d2, int32_t id) {
-    if (b.n == b.k && !(d2 < b.d2[b.n - 1])) return;
+// Nodes are ranked by (squared distance, id): a total order, so that the result does not depend on the order in
+// which a search structure happens to visit exactly equidistant nodes.
+RT_HD __forceinline__ bool node_before(double d2a, int32_t ida, double d2b, int32_t idb) {
+    return d2a < d2b || (d2a == d2b && ida < idb);
+}
+RT_HD __forceinline__ void kbest_push(KBest &b, double d2, int32_t id) {
+    if (b.n == b.k && !node_before(d2, id, b.d2[b.n - 1], b.id[b.n - 1])) return;
     int i = (b.n < b.k) ? b.n++ : b.n - 1;
-    while (i > 0 && b.d2[i - 1] > d2) {
+    while (i > 0 && node_before(d2, id, b.d2[i - 1], b.id[i - 1])) {
         b.d2[i] = b.d2[i - 1];
         b.id[i] = b.id[i - 1];
         --i;
@@ -179,7 +189,7 @@ __device__ __forceinline__ void kbest_push(KBest &b, double d2, int32_t id) {
 
 // Lower bound on the distance from (qx,qy) to any node outside the visited block of buckets
 // [ix-r, ix+r] x [iy-r, iy+r]; +inf once the block covers the whole grid.
-__device__ __forceinline__ double ring_bound(const DGeo &m, double qx, double qy, int ix, int iy, int r) {
+RT_HD __forceinline__ double ring_bound(const DGeo &m, double qx, double qy, int ix, int iy, int r) {
     const double inf = __builtin_huge_val();
     double lb = inf;
     if (ix - r > 0) lb = fmin(lb, qx - (m.gx0 + (double)(ix - r) * m.gh));
@@ -189,7 +199,7 @@ __device__ __forceinline__ double ring_bound(const DGeo &m, double qx, double qy
     return lb;
 }
 
-__device__ __forceinline__ void bucket_of(const DGeo &m, double qx, double qy, int &ix, int &iy) {
+RT_HD __forceinline__ void bucket_of(const DGeo &m, double qx, double qy, int &ix, int &iy) {
     double fx = floor((qx - m.gx0) * m.ginv), fy = floor((qy - m.gy0) * m.ginv);
     fx = fx < 0.0 ? 0.0 : fx;
     fy = fy < 0.0 ? 0.0 : fy;
@@ -198,11 +208,11 @@ __device__ __forceinline__ void bucket_of(const DGeo &m, double qx, double qy, i
 }
 
 // nn(kdtree, x): the nearest node (0-based id).
-__device__ __forceinline__ int32_t nearest_node(const DGeo &m, double qx, double qy) {
+RT_HD __forceinline__ int32_t nearest_node(const DGeo &m, double qx, double qy) {
     int ix, iy;
     bucket_of(m, qx, qy, ix, iy);
     double best = __builtin_huge_val();
-    int32_t best_id = -1;
+    int32_t best_id = 0x7fffffff;
     const int rmax = m.gnx > m.gny ? m.gnx : m.gny;
     for (int r = 0; r <= rmax; ++r) {
         const int y0 = iy - r, y1 = iy + r;
@@ -222,21 +232,60 @@ __device__ __forceinline__ int32_t nearest_node(const DGeo &m, double qx, double
                     const int32_t id = m.gnode[s];
                     const double dx = qx - m.x[id], dy = qy - m.y[id];
                     const double d2 = dx * dx + dy * dy;
-                    if (d2 < best) { best = d2; best_id = id; }
+                    if (node_before(d2, id, best, best_id)) { best = d2; best_id = id; }
                 }
             }
         }
         const double lb = ring_bound(m, qx, qy, ix, iy, r) - 1e-9 * m.gh;
         if (lb == __builtin_huge_val()) break;
-        if (best_id >= 0 && lb > 0.0 && best < lb * lb) break;
+        if (best_id != 0x7fffffff && lb > 0.0 && best < lb * lb) break;
     }
-    return best_id;
+    return best_id == 0x7fffffff ? -1 : best_id;
+}
+
+// The node that follows (d2_prev, id_prev) in the (squared distance, id) order, other than `skip`; -1 when there is
+// none.  One exact ring search per call: the streaming form of knn for widths beyond the in-register list.
+RT_HD __noinline__ int32_t next_nearest_node(const DGeo &m, double qx, double qy, double d2_prev, int32_t id_prev,
+                                                  int32_t skip, double &d2_out) {
+    int ix, iy;
+    bucket_of(m, qx, qy, ix, iy);
+    double best = __builtin_huge_val();
+    int32_t best_id = 0x7fffffff;
+    const int rmax = m.gnx > m.gny ? m.gnx : m.gny;
+    for (int r = 0; r <= rmax; ++r) {
+        const int y0 = iy - r, y1 = iy + r;
+        for (int by = (y0 < 0 ? 0 : y0); by <= (y1 >= m.gny ? m.gny - 1 : y1); ++by) {
+            const int xl = ix - r < 0 ? 0 : ix - r, xr = ix + r >= m.gnx ? m.gnx - 1 : ix + r;
+            const bool full = (by == y0) || (by == y1);
+            for (int part = 0; part < (full ? 1 : 2); ++part) {
+                int b0, b1;
+                if (full) { b0 = by * m.gnx + xl; b1 = by * m.gnx + xr + 1; }
+                else {
+                    const int bx = part == 0 ? ix - r : ix + r;
+                    if (bx < 0 || bx >= m.gnx) continue;
+                    b0 = by * m.gnx + bx; b1 = b0 + 1;
+                }
+                for (int32_t s = m.gstart[b0]; s < m.gstart[b1]; ++s) {
+                    const int32_t id = m.gnode[s];
+                    if (id == skip) continue;
+                    const double dx = qx - m.x[id], dy = qy - m.y[id];
+                    const double d2 = dx * dx + dy * dy;
+                    if (node_before(d2_prev, id_prev, d2, id) && node_before(d2, id, best, best_id)) { best = d2; best_id = id; }
+                }
+            }
+        }
+        const double lb = ring_bound(m, qx, qy, ix, iy, r) - 1e-9 * m.gh;
+        if (lb == __builtin_huge_val()) break;
+        if (best_id != 0x7fffffff && lb > 0.0 && best < lb * lb) break;
+    }
+    d2_out = best;
+    return best_id == 0x7fffffff ? -1 : best_id;
 }
 
 // knn(kdtree, x, k, true, i -> i == skip): the k nearest nodes other than `skip`, ascending.
-__device__ __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int k, int32_t skip, KBest &kb) {
+RT_HD __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int k, int32_t skip, KBest &kb) {
     kb.n = 0;
-    kb.k = k > kMaxK ? kMaxK : k;
+    kb.k = k > kMaxK ? kMaxK : k;  // (callers pass k <= kMaxK; wider searches stream, see find_element_fallback)
     if (kb.k <= 0) return;
     int ix, iy;
     bucket_of(m, qx, qy, ix, iy);
@@ -268,7 +317,7 @@ __device__ __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy,
     }
 }
 
-__device__ __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node, double x, double y) {
+RT_HD __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node, double x, double y) {
     for (int32_t s = m.ncp[node]; s < m.ncp[node + 1]; ++s) {
         const int32_t c = m.ncd[s];
         if (point_in_triangle(m, c, x, y)) return c;
@@ -280,9 +329,23 @@ __device__ __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t 
 // followed, on failure, by find_element(mesh, xp, k) (src/track.jl:122,139).  The second
 // call repeats the first one's tests and then looks at nodes 3..k of the same sorted list,
 // so one sorted list of max(2,k) nodes serves both.
-__device__ __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double y, int k, int32_t nn_id) {
-    KBest kb;
+RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double y, int k, int32_t nn_id) {
     const int kk = k > 2 ? k : 2;
+    if (kk > kMaxK) {
+        // wide `k` (src/mesh.jl:123 takes any): the same sorted node list, produced one node at a time
+        double d2p = -1.0;
+        int32_t idp = -1;
+        for (int j = 0; j < kk; ++j) {
+            double d2;
+            const int32_t nd = next_nearest_node(m, x, y, d2p, idp, nn_id, d2);
+            if (nd < 0) break;
+            const int32_t c = first_cell_containing(m, nd, x, y);
+            if (c >= 0) return c;
+            d2p = d2; idp = nd;
+        }
+        return -1;
+    }
+    KBest kb;
     knearest_nodes(m, x, y, kk, nn_id, kb);
     const int first = kb.n < 2 ? kb.n : 2;
     for (int j = 0; j < first; ++j) {
@@ -298,7 +361,7 @@ __device__ __noinline__ int32_t find_element_fallback(const DGeo &m, double x, d
 }
 
 // find_element (src/mesh.jl:103-146), 0-based cell id or -1.
-__device__ __forceinline__ int32_t find_element(const DGeo &m, double x, double y, int k) {
+RT_HD __forceinline__ int32_t find_element(const DGeo &m, double x, double y, int k) {
     const int32_t nn_id = nearest_node(m, x, y);
     if (nn_id < 0) return -1;
     const int32_t c = first_cell_containing(m, nn_id, x, y);
@@ -310,7 +373,7 @@ __device__ __forceinline__ int32_t find_element(const DGeo &m, double x, double 
 // general_form (src/intersection.jl:11-18) of edge p1->p2, intersection with the track line
 // (src/intersection.jl:127-138) and point_in_segment (src/segment.jl:39-44).
 // Returns 0 = no valid intersection, 1 = valid (x,y), 2 = parallel.
-__device__ __forceinline__ int edge_hit(double tA, double tB, double tC, double p1x, double p1y, double p2x,
+RT_HD __forceinline__ int edge_hit(double tA, double tB, double tC, double p1x, double p1y, double p2x,
                                         double p2y, double &x, double &y) {
     double eA = p1y - p2y;
     double eB = p2x - p1x;
@@ -332,7 +395,7 @@ __device__ __forceinline__ int edge_hit(double tA, double tB, double tC, double 
 }
 
 // order_intersection_points (src/intersection.jl:151-159)
-__device__ __forceinline__ bool order_points(double phi, double x1, double y1, double x2, double y2, double &px,
+RT_HD __forceinline__ bool order_points(double phi, double x1, double y1, double x2, double y2, double &px,
                                              double &py, double &qx, double &qy) {
     const bool first = (phi < kHalfPi) ? (x1 < x2) : (x1 > x2);
     px = first ? x1 : x2;
@@ -346,7 +409,7 @@ __device__ __forceinline__ bool order_points(double phi, double x1, double y1, d
 // branch in which the reference reads an unassigned variable (n_int == 3, all coincident).
 // `eq` receives the index (0..2) of the cell edge the exit point q lies on (-1 if q was not
 // produced): the walk step uses it to predict the next cell through the adjacency table.
-__device__ __forceinline__ bool intersections(const DGeo &m, int32_t cell, double phi, double tA, double tB,
+RT_HD __forceinline__ bool intersections(const DGeo &m, int32_t cell, double phi, double tA, double tB,
                                               double tC, double &px, double &py, double &qx, double &qy, int &eq) {
     eq = -1;
     const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
@@ -399,7 +462,7 @@ struct GenericOut {
     double px, py, qx, qy, ell;
     int32_t element, eq;
 };
-__device__ __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
+RT_HD __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
                                          double tA, double tB, double tC, GenericOut &o) {
     const int32_t element = find_element(m, xpx, xpy, k);  // src/track.jl:122 and :138-139
     o.element = element;
@@ -415,7 +478,7 @@ __device__ __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, 
 
 // Does the reference's iteration at xp end in a tiny step (`continue` at src/track.jl:147-150 or :156-159)?
 // False when it emits a segment or fails to locate / intersect.  Used by the cooperative creep of k_march.
-__device__ __noinline__ bool generic_tiny_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element,
+RT_HD __noinline__ bool generic_tiny_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element,
                                                double phi, double tA, double tB, double tC) {
     const int32_t element = find_element(m, xpx, xpy, k);
     if (element < 0) return false;
@@ -441,13 +504,17 @@ __device__ __noinline__ bool generic_tiny_step(const DGeo &m, double xpx, double
 //
 // Why only T and T' can contain xp (up to the √eps barycentric tolerance): xp lies within
 // tiny_step of the interior of the shared edge and, by the isolation certificate, at least
-// eps_iso (barycentric) away from the other two edges of T'; eps_iso is sized on the host so
-// that this distance exceeds every other cell's tolerance band.  find_element scans the cell
+// eps (barycentric) away from the other two edges of T'; eps is computed per record on the host
+// (rt_mesh_prep.hpp) by clipping the acceptance region of every nearby cell — the cell scaled by
+// 1 + 3·(√eps + rounding noise) about its centroid — against the record's region, so that no cell
+// other than T and T' can pass the reference's test at xp.  find_element scans the cell
 // lists of nodes in order of distance and returns the first cell that passes; T' always
-// passes; T passes iff the exact λ below is ≥ -√eps ("shallow crossing").  T is scanned
-// before T' iff the nearest of {a, b, c, c'} is c, or it is a or b and T < T' (lists are
-// ascending in cell id).  `meta` bounds how many other nodes can precede, so the scan stays
-// inside the window find_element(xp) / find_element(xp, k) covers.
+// passes (its own λ are ≥ -√eps/4 by certificate 2, and cells whose λ are too noisy for that
+// statement are never walked into); T passes iff its three exact λ below are within
+// [-√eps, 1 + √eps] ("shallow crossing").  T is scanned before T' iff the nearest of
+// {a, b, c, c'} is c, or it is a or b and T < T' (lists are ascending in cell id).  `extras`
+// bounds how many other nodes can precede, so the scan stays inside the window
+// find_element(xp) / find_element(xp, k) covers.
 struct Walk {
     int32_t T;       // cell of the last emitted segment (prev_element), -1 at the start
     int32_t pred;    // walk record index of the predicted next cell (3*cell' + entry edge), -1: none
@@ -458,7 +525,7 @@ struct Walk {
 
 // State for the next walk step after a segment was emitted by the generic step in `cell` with
 // its exit point on edge `ko` (0..2).
-__device__ __forceinline__ void walk_enter(const DMesh &m, const DGeo &g, Walk &w, int32_t cell, int ko) {
+RT_HD __forceinline__ void walk_enter(const DMesh &m, const DGeo &g, Walk &w, int32_t cell, int ko) {
     const int32_t n1 = g.cn[3 * cell], n2 = g.cn[3 * cell + 1], n3 = g.cn[3 * cell + 2];
     const double x1 = g.x[n1], y1 = g.y[n1], x2 = g.x[n2], y2 = g.y[n2], x3 = g.x[n3], y3 = g.y[n3];
     w.T = cell;
@@ -479,25 +546,54 @@ struct NextRec {
     uint64_t hdr;
     double dT, x2, y2, e1A, e1B, e1C, e2A, e2B, e2C;
 };
-__device__ __forceinline__ void load_next(const DMesh &m, int32_t pred, NextRec &r) {
+RT_HD __forceinline__ void load_next(const DMesh &m, int32_t pred, NextRec &r) {
     const RT_G WalkRec *R = m.wrec + (pred >= 0 ? pred : 0);
     r.hdr = R->hdr; r.dT = R->dT;
     r.x2 = R->x2; r.y2 = R->y2;
     r.e1A = R->e1A; r.e1B = R->e1B; r.e1C = R->e1C; r.e2A = R->e2A; r.e2B = R->e2B; r.e2C = R->e2C;
 }
-__device__ __forceinline__ int32_t rec_next1(uint64_t hdr) { return (int32_t)(hdr & ((1u << kWalkIdBits) - 1)) - 1; }
-__device__ __forceinline__ int32_t rec_next2(uint64_t hdr) { return (int32_t)((hdr >> kWalkIdBits) & ((1u << kWalkIdBits) - 1)) - 1; }
-__device__ __forceinline__ int32_t rec_extras(uint64_t hdr) { return (int32_t)(hdr >> (2 * kWalkIdBits)) & 255; }
-__device__ __forceinline__ bool rec_same(uint64_t hdr) { return ((hdr >> (2 * kWalkIdBits + 8)) & 1) != 0; }
+RT_HD __forceinline__ int32_t rec_next1(uint64_t hdr) { return (int32_t)(hdr & ((1u << kWalkIdBits) - 1)) - 1; }
+RT_HD __forceinline__ int32_t rec_next2(uint64_t hdr) { return (int32_t)((hdr >> kWalkIdBits) & ((1u << kWalkIdBits) - 1)) - 1; }
+RT_HD __forceinline__ int32_t rec_extras(uint64_t hdr) { return (int32_t)(hdr >> (2 * kWalkIdBits)) & 15; }
+// the record's isolation margin 2^(code - 20), assembled as a double: exponent field 1023 - 20 + code
+RT_HD __forceinline__ double rec_eps(uint64_t hdr) {
+    const uint32_t hi = (((uint32_t)(hdr >> 32) >> 26) & 31u) + 1003u;
+    return __builtin_bit_cast(double, (uint64_t)hi << 52);
+}
+RT_HD __forceinline__ bool rec_same(uint64_t hdr) { return (hdr >> 63) != 0; }
 
 // One walk step at xp for the lane's predicted record.  On kWalkEmit: (qx,qy) is the exit point,
 // `ell` the segment length (entry point = previous exit point, bit-identical by symmetry of the
 // edge's general form), and `w` is advanced to the new cell.  On kWalkSkip the reference takes
 // its `prev_element == element` branch (src/track.jl:147-150).  kWalkGeneric: no decision.
+// `kk` = min(max(k, 2), 14): the node window of find_element(xp) followed by find_element(xp, k);
+// `fwd` = ϕ < π/2 (order_intersection_points, src/intersection.jl:151-159).
 // Written straight-line (all certificates are folded into one predicate; a lane without a
 // prediction reads record 0 and is masked out) except for the rare exact shallow-crossing test:
 // on a 64-wide wave, selects are cheaper than divergent early exits.
-__device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, double tA, double tB,
+RT_HD __forceinline__ bool shallow_T_first(const Walk &w, double numT, double x2, double y2, int32_t Tn, double xpx,
+                                                double xpy, bool &tie) {
+    // T still passes the reference's barycentric test at xp iff all three λ, exactly as point_in_triangle
+    // evaluates them (src/mesh.jl:166-174; a, b, c are a cyclic rotation of the cell's nodes, which maps the
+    // three closed forms onto each other), lie in [0 - √eps, 1 + √eps]
+    const double lo = 0.0 - kRtolDefault, hi = 1.0 + kRtolDefault;
+    const double lc = numT / w.dT;
+    const double la = ((w.by - w.cy) * xpx + (w.cx - w.bx) * xpy + (w.bx * w.cy - w.cx * w.by)) / w.dT;
+    const double lb = ((w.cy - w.ay) * xpx + (w.ax - w.cx) * xpy + (w.cx * w.ay - w.ax * w.cy)) / w.dT;
+    tie = false;
+    if (!((lo <= lc && lc <= hi) && (lo <= la && la <= hi) && (lo <= lb && lb <= hi))) return false;
+    // scan order of find_element: nearest of {a, b, c, c'}; T is met before T' iff that is c,
+    // or it is a or b and T < T' (node -> cells lists ascend in cell id)
+    const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
+    const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
+    const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
+    const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
+    const double dab = da < db ? da : db;
+    tie = dc == dab || dcp == dab || dc == dcp;  // exactly equidistant nodes: generic step
+    return (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn);
+}
+
+RT_HD __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, bool fwd, double tA, double tB,
                                          double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
                                          double &qy, double &ell) {
     const bool has = m.walk_ok && w.pred >= 0;
@@ -515,14 +611,15 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     const bool p0 = s0 > 0, p1 = s1 > 0, p2 = s2 > 0;
     ok = ok && (p0 != p1);
     const bool exit1 = p1 != p2;  // the line leaves through rotated edge 1 = (v1,v2), else edge 2 = (v2,v0)
-    // --- certificate 2: xp is inside T', at least eps_iso (barycentric) from edges 1 and 2
+    // --- certificate 2: xp is inside T', at least the record's eps (barycentric) from edges 1 and 2
     const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     const double sg = area2 > 0 ? 1.0 : -1.0;
     const double aa = fabs(area2);
     const double c0 = sg * ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0));  // ~ distance from the entry edge
     const double c1 = sg * ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1));
     const double c2 = sg * ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2));
-    ok = ok && c0 >= -0.25 * kRtolDefault * aa && c1 >= m.eps_iso * aa && c2 >= m.eps_iso * aa;
+    const double eps_aa = rec_eps(nr.hdr) * aa;
+    ok = ok && c0 >= -0.25 * kRtolDefault * aa && c1 >= eps_aa && c2 >= eps_aa;
     // --- exit point: intersection(track.ABC, ABC) — src/intersection.jl:127-138
     const double eA = exit1 ? e1A : e2A, eB = exit1 ? e1B : e2B, eC = exit1 ? e1C : e2C;
     const double a = tB * eA;
@@ -532,27 +629,20 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
     qy = (tA * eC - eA * tC) / det;
     ell = norm2(ppx - qx, ppy - qy);  // Segment ctor, src/segment.jl:31-33
     ok = ok && ell >= m.l_min;
+    // order_intersection_points (src/intersection.jl:151-159) compares the two x coordinates: the entry point stays
+    // the entry point only if it is strictly on the expected side (near ϕ = π/2 rounding may decide otherwise)
+    ok = ok && (fwd ? ppx < qx : ppx > qx);
     // --- shallow crossing: does T still pass the reference's barycentric test at xp?  λ of T for the
     //     vertex opposite its exit edge, exactly as point_in_triangle evaluates it (src/mesh.jl:166-168);
-    //     the division is skipped when the quotient is clearly below -√eps
+    //     the divisions are skipped when that quotient is clearly below -√eps
     const double numT = (w.ay - w.by) * xpx + (w.bx - w.ax) * xpy + (w.ax * w.by - w.bx * w.ay);
     const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
     int res = ok ? kWalkEmit : kWalkGeneric;
     if (ok && !clearly_out) {
-        asm volatile("" ::: "memory");  // a real branch: hoisted, the division runs on every iteration for nothing
-        const double lamT = numT / w.dT;
-        if (lamT >= 0.0 - kRtolDefault) {
-            // scan order of find_element: nearest of {a, b, c, c'}; T is met before T' iff that is c,
-            // or it is a or b and T < T' (node -> cells lists ascend in cell id)
-            const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
-            const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
-            const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
-            const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
-            const double dab = da < db ? da : db;
-            const bool tie = dc == dab || dcp == dab || dc == dcp;  // exactly equidistant nodes: generic step
-            const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn);
-            res = tie ? kWalkGeneric : (t_first ? kWalkSkip : kWalkEmit);
-        }
+        asm volatile("" ::: "memory");  // a real branch: hoisted, the divisions run on every iteration for nothing
+        bool tie;
+        const bool t_first = shallow_T_first(w, numT, x2, y2, Tn, xpx, xpy, tie);
+        res = tie ? kWalkGeneric : (t_first ? kWalkSkip : kWalkEmit);
     }
     // --- advance the state to T' (only when emitting)
     if (res == kWalkEmit) {
@@ -574,7 +664,7 @@ __device__ __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec 
 // the exit point and ℓ do not change while the lane creeps by tiny_step.  A track that crosses an
 // edge at a very small angle takes hundreds of such steps (src/track.jl:147-150); this keeps each
 // of them to a few dozen instructions instead of a full march iteration.
-__device__ __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const NextRec &nr, double xpx, double xpy) {
+RT_HD __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const NextRec &nr, double xpx, double xpy) {
     const bool same = rec_same(nr.hdr);
     const double x0 = same ? w.ax : w.bx, y0 = same ? w.ay : w.by, x1 = same ? w.bx : w.ax, y1 = same ? w.by : w.ay;
     const double x2 = nr.x2, y2 = nr.y2;
@@ -584,19 +674,13 @@ __device__ __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, c
     const double c0 = sg * ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0));
     const double c1 = sg * ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1));
     const double c2 = sg * ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2));
-    if (!(c0 >= -0.25 * kRtolDefault * aa && c1 >= m.eps_iso * aa && c2 >= m.eps_iso * aa)) return false;
+    const double eps_aa = rec_eps(nr.hdr) * aa;
+    if (!(c0 >= -0.25 * kRtolDefault * aa && c1 >= eps_aa && c2 >= eps_aa)) return false;
     const double numT = (w.ay - w.by) * xpx + (w.bx - w.ax) * xpy + (w.ax * w.by - w.bx * w.ay);
     const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
     if (clearly_out) return false;
-    const double lamT = numT / w.dT;
-    if (!(lamT >= 0.0 - kRtolDefault)) return false;
-    const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
-    const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
-    const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
-    const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
-    const double dab = da < db ? da : db;
-    const bool tie = dc == dab || dcp == dab || dc == dcp;
-    const bool t_first = (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u));
+    bool tie;
+    const bool t_first = shallow_T_first(w, numT, x2, y2, (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u), xpx, xpy, tie);
     return !tie && t_first;
 }
 

@@ -3,33 +3,46 @@
 // Builds what the device march needs beyond the reference's own tables:
 //  * the uniform node grid used by the exact (k-)nearest-node search (replaces the kd-tree,
 //    src/mesh.jl:38-42);
-//  * per-cell records for the walk step of the march (csrc/rt_device.hpp, `CellRec`):
-//    neighbour across each edge, vertex coordinates, and each edge's normalised general
-//    form computed exactly as `general_form` does (src/intersection.jl:11-18) so that the
-//    device reproduces the reference's intersection points bit for bit;
-//  * per cell, an upper bound on how many non-vertex nodes can be nearer to a point of the
-//    cell than the cell's nearest vertex (bounds the rank at which `find_element`'s node scan,
-//    src/mesh.jl:107-132, reaches the cell);
-//  * global certificate margins derived from the mesh's shape statistics.
+//  * rotated walk records per (cell, entry edge) for the walk step of the march (csrc/rt_device.hpp,
+//    `WalkRec`): successor records across the two possible exit edges, the vertex opposite the
+//    entry edge, and the exit edges' normalised general forms computed exactly as `general_form`
+//    does (src/intersection.jl:11-18) so that the device reproduces the reference's intersection
+//    points bit for bit;
+//  * the walk step's certificates, PER RECORD (a sliver somewhere in the mesh only costs the walk
+//    step in its own neighbourhood):
+//      - `extras`: how many non-vertex nodes can be nearer to a point of the cell than the cell's
+//        nearest vertex (bounds the rank at which `find_element`'s node scan, src/mesh.jl:107-132,
+//        reaches the cell);
+//      - `eps`: the barycentric isolation margin — with xp at least eps (barycentric) inside the
+//        record's cell T' from its two exit edges (and not more than tol/4 outside its entry edge),
+//        no cell other than T' and the predecessor T can pass the reference's √eps barycentric test
+//        (src/mesh.jl:166-174) at xp.  Computed by clipping every nearby cell's acceptance region
+//        (the cell scaled by 1 + 3·tol' about its centroid, tol' = √eps + the rounding noise of the
+//        reference's own evaluation in that cell) against the record's region;
+//      - cells whose own barycentric test is too noisy at the √eps level (tiny area far from the
+//        origin) or degenerate are never walked into; degenerate cells also switch off the records
+//        around them.
 // This TU is compiled with -ffp-contract=off, like everything else in the library.
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 namespace rtprep {
 
-struct CellRecHost {  // must match rt::CellRec (rt_device.hpp): 144 bytes
-    int32_t adj[3];   // neighbour cell across edge k = (v_k, v_{k+1 mod 3}); -1 on the boundary
-    int32_t meta;     // bits 0..7: extras bound (255 = walk step disabled for this cell)
+struct CellRecHost {
+    int32_t adj[3];   // neighbour cell across edge k = (v_k, v_{k+1 mod 3}); -1 on the boundary / non-manifold edge
+    int32_t extras;   // extras bound, capped at kExtrasNever
     double vx[3], vy[3];
     double eA[3], eB[3], eC[3];
-    double pad;
+    int32_t cls;      // 0 normal, 1 fragile (not walked into; acceptance region inflated), 2 wild (degenerate)
+    double fp_err;    // bound on |λ computed by the reference - λ exact| for points near the cell
+    double lmax, area2;
 };
-static_assert(sizeof(CellRecHost) == 144, "CellRec layout");
 
 // Rotated walk record for (cell, entry edge e): vertices rotated cyclically so that rotated
 // edge 0 = (v0, v1) is the entry edge, in the cell's own edge orientation.  Must match
@@ -37,10 +50,13 @@ static_assert(sizeof(CellRecHost) == 144, "CellRec layout");
 // ~50-250 cycles per load instruction, tools/micro/bench_gather.hip).  v0 and v1 are not stored:
 // they are the endpoints of the predecessor's exit edge, which the walk state already holds
 // (same nodes, hence the same bits), in the same or the opposite order (`same` flag).
-constexpr int kWalkIdBits = 27;  // record ids + 1 must fit: 3 * n_cells + 1 < 2^27
+constexpr int kWalkIdBits = 27;      // record ids + 1 must fit: 3 * n_cells + 1 < 2^27
+constexpr int kExtrasNever = 15;     // extras field value that no `k` satisfies: walk step off for the record
+constexpr int kEpsCodeMin = 0;       // eps = 2^(code - 20): 2^-20 ≈ 9.5e-7 ... 2^-2
+constexpr int kEpsCodeMax = 18;      // larger margins: record disabled (μ0, μ1 ≥ 1/2 cannot both hold inside)
 struct WalkRecHost {
     uint64_t hdr;   // bits 0..26 next1 + 1, 27..53 next2 + 1 (record 3*cell' + entry' across rotated edge 1 / 2,
-                    // 0 on the boundary), 54..61 extras bound (255: no walk), 62: v0 is the `a` of the
+                    // 0 on the boundary), 54..57 extras bound (15: no walk), 58..62 eps code, 63: v0 is the `a` of the
                     // predecessor's exit edge (a, b) — else v0 = b
     double dT;      // det of the barycentric system in the ORIGINAL node order (reference operation order)
     double x2, y2;  // the vertex opposite the entry edge
@@ -57,13 +73,16 @@ struct Prep {
     std::vector<int32_t> gstart, gnode;
     // records
     std::vector<CellRecHost> rec;
-    // certificate margins
-    double eps_iso = 1e-6;   // barycentric isolation margin
+    // certificate margins that stay global
     double d_vertex = 1e-7;  // absolute clearance of the track line from a cell's vertices
     double l_min = 1e-6;     // minimum chord length handled by the walk step
-    bool walk_ok = true;     // false: mesh is not an edge-manifold triangulation -> generic path only
+    bool walk_ok = true;     // false: no record can be walked (see note)
     double kappa = 0.0;      // expected segments per unit track length: Σ cell perimeters / (π · area) (Cauchy–Crofton)
     std::string note;
+    // diagnostics (rt_mesh_info)
+    int64_t n_records = 0, n_records_walk = 0;
+    int32_t n_cells_fragile = 0, n_cells_wild = 0, n_edges_nonmanifold = 0, extras_max = 0;
+    double eps_min = 0.0, eps_max = 0.0;  // over the records the walk step can use
 };
 
 struct P2 { double x, y; };
@@ -72,6 +91,7 @@ struct P2 { double x, y; };
 inline void clip(std::vector<P2> &poly, double nx, double ny, double c) {
     std::vector<P2> out;
     const size_t n = poly.size();
+    out.reserve(n + 2);
     for (size_t i = 0; i < n; ++i) {
         const P2 a = poly[i], b = poly[(i + 1) % n];
         const double da = nx * a.x + ny * a.y - c, db = nx * b.x + ny * b.y - c;
@@ -83,6 +103,9 @@ inline void clip(std::vector<P2> &poly, double nx, double ny, double c) {
     }
     poly.swap(out);
 }
+
+constexpr double kTol = 1.4901161193847656e-8;  // sqrt(eps(Float64)): the reference's barycentric tolerance
+constexpr double kUlp = 1.1102230246251565e-16;
 
 inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int32_t *cn /*0-based*/,
                     int32_t n_cells, const double *bb) {
@@ -99,8 +122,8 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
     std::vector<int32_t> bucket(n_nodes);
     auto bucket_of = [&](double px, double py, int &ix, int &iy) {
         double fx = std::floor((px - bb[0]) * P.ginv), fy = std::floor((py - bb[1]) * P.ginv);
-        ix = fx < 0 ? 0 : (fx > gnx - 1 ? gnx - 1 : (int)fx);
-        iy = fy < 0 ? 0 : (fy > gny - 1 ? gny - 1 : (int)fy);
+        ix = !(fx > 0) ? 0 : (fx > gnx - 1 ? gnx - 1 : (int)fx);
+        iy = !(fy > 0) ? 0 : (fy > gny - 1 ? gny - 1 : (int)fy);
     };
     for (int32_t i = 0; i < n_nodes; ++i) {
         int ix, iy;
@@ -114,21 +137,23 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         for (int32_t i = 0; i < n_nodes; ++i) P.gnode[cur[bucket[i]]++] = i;
     }
 
-    // ---- adjacency through an edge map
+    // ---- adjacency through an edge map; an edge shared by more than two cells has no neighbour on any side
+    //      (the walk step never crosses it)
     P.rec.assign(n_cells, CellRecHost{});
-    std::unordered_map<uint64_t, int64_t> edge_owner;  // key -> cell*3 + k of the first owner
+    std::unordered_map<uint64_t, int64_t> edge_owner;  // key -> cell*3 + k of the first owner; -1: paired; -2: non-manifold
     edge_owner.reserve((size_t)n_cells * 2);
     auto key = [](int32_t a, int32_t b) { return ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b); };
     for (int32_t c = 0; c < n_cells; ++c)
         for (int k = 0; k < 3; ++k) P.rec[c].adj[k] = -1;
-    for (int32_t c = 0; c < n_cells && P.walk_ok; ++c) {
+    std::vector<uint64_t> bad_edges;
+    for (int32_t c = 0; c < n_cells; ++c) {
         for (int k = 0; k < 3; ++k) {
             const int32_t a = cn[3 * c + k], b = cn[3 * c + (k + 1) % 3];
             const uint64_t kk = key(a, b);
             auto it = edge_owner.find(kk);
             if (it == edge_owner.end()) edge_owner.emplace(kk, (int64_t)c * 3 + k);
-            else if (it->second < 0) { P.walk_ok = false; P.note = "edge shared by more than two cells"; break; }
-            else {
+            else if (it->second == -1) { it->second = -2; bad_edges.push_back(kk); }
+            else if (it->second >= 0) {
                 const int32_t c2 = (int32_t)(it->second / 3), k2 = (int32_t)(it->second % 3);
                 P.rec[c].adj[k] = c2;
                 P.rec[c2].adj[k2] = c;
@@ -136,13 +161,30 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
             }
         }
     }
+    if (!bad_edges.empty()) {
+        P.n_edges_nonmanifold = (int32_t)bad_edges.size();
+        for (int32_t c = 0; c < n_cells; ++c)
+            for (int k = 0; k < 3; ++k) {
+                auto it = edge_owner.find(key(cn[3 * c + k], cn[3 * c + (k + 1) % 3]));
+                if (it != edge_owner.end() && it->second == -2) {
+                    const int32_t nb = P.rec[c].adj[k];
+                    if (nb >= 0)
+                        for (int q = 0; q < 3; ++q)
+                            if (P.rec[nb].adj[q] == c) P.rec[nb].adj[q] = -1;
+                    P.rec[c].adj[k] = -1;
+                }
+            }
+        P.note = "edge shared by more than two cells (not crossed by the walk step)";
+    }
 
-    // ---- per-cell geometry + shape statistics
-    double alt_min = INFINITY, alt_max = 0, sin_min = 1.0, l_max = 0, perim = 0, area = 0;
+    // ---- per-cell geometry, shape statistics, noise class
+    const double cmax_x = std::max(std::fabs(bb[0]), std::fabs(bb[2])), cmax_y = std::max(std::fabs(bb[1]), std::fabs(bb[3]));
+    double l_max = 0, perim = 0, area = 0;
+    std::vector<int32_t> wild;
     for (int32_t c = 0; c < n_cells; ++c) {
         CellRecHost &R = P.rec[c];
         for (int k = 0; k < 3; ++k) { R.vx[k] = x[cn[3 * c + k]]; R.vy[k] = y[cn[3 * c + k]]; }
-        double len[3];
+        double lmax_c = 0;
         for (int k = 0; k < 3; ++k) {
             const int j = (k + 1) % 3;
             // general_form(p1, p2), src/intersection.jl:11-18 — same operations, same order
@@ -151,55 +193,65 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
             const double C = R.vx[k] * R.vy[j] - R.vx[j] * R.vy[k];
             const double nrm = std::sqrt(A * A + B * B + C * C);
             R.eA[k] = A / nrm; R.eB[k] = B / nrm; R.eC[k] = C / nrm;
-            len[k] = std::hypot(R.vx[k] - R.vx[j], R.vy[k] - R.vy[j]);
-            l_max = std::max(l_max, len[k]);
-            perim += len[k];
+            const double len = std::hypot(R.vx[k] - R.vx[j], R.vy[k] - R.vy[j]);
+            lmax_c = std::max(lmax_c, len);
+            perim += len;
         }
+        l_max = std::max(l_max, lmax_c);
         const double area2 = std::fabs((R.vx[1] - R.vx[0]) * (R.vy[2] - R.vy[0]) - (R.vx[2] - R.vx[0]) * (R.vy[1] - R.vy[0]));
         area += 0.5 * area2;
-        if (!(area2 > 0)) { R.meta = 255; continue; }
-        for (int k = 0; k < 3; ++k) {
-            const double alt = area2 / len[k];
-            alt_min = std::min(alt_min, alt); alt_max = std::max(alt_max, alt);
-            const double s = area2 / (len[k] * len[(k + 2) % 3]);  // sin of the angle at vertex k
-            sin_min = std::min(sin_min, s);
-        }
+        R.lmax = lmax_c; R.area2 = area2;
+        // Rounding noise of the reference's λ = ((y2-y3)·x + (x3-x2)·y + (x2·y3 - x3·y2)) / d near this cell: the
+        // products x_i·y_j carry an absolute error of u·|x||y| each — the formula is not translation invariant — and
+        // d carries the same; |λ| ≤ 2 in the region of interest.
+        const double ax = std::max({std::fabs(R.vx[0]), std::fabs(R.vx[1]), std::fabs(R.vx[2])}) + lmax_c;
+        const double ay = std::max({std::fabs(R.vy[0]), std::fabs(R.vy[1]), std::fabs(R.vy[2])}) + lmax_c;
+        const double Lx = std::max({R.vx[0], R.vx[1], R.vx[2]}) - std::min({R.vx[0], R.vx[1], R.vx[2]});
+        const double Ly = std::max({R.vy[0], R.vy[1], R.vy[2]}) - std::min({R.vy[0], R.vy[1], R.vy[2]});
+        const double err_abs = kUlp * (3.0 * ax * ay + 6.0 * (Ly * ax + Lx * ay));
+        R.fp_err = area2 > 0 ? 3.0 * err_abs / area2 : INFINITY;
+        R.cls = 0;
+        if (!(R.fp_err <= 0.5 * kTol) || !(area2 >= 1e-5 * lmax_c * lmax_c)) R.cls = 1;
+        if (!(R.fp_err <= 0.05) || !std::isfinite(area2) || !(area2 > 0)) R.cls = 2;
+        if (R.cls == 1) ++P.n_cells_fragile;
+        if (R.cls == 2) { ++P.n_cells_wild; wild.push_back(c); }
     }
     P.kappa = area > 0 ? perim / (3.141592653589793 * area) : 0.0;
-    if (!(alt_min > 0) || !std::isfinite(alt_min)) { P.walk_ok = false; P.note = "degenerate cells"; }
-    const double tol = 1.4901161193847656e-8;
-    if (P.walk_ok) {
-        P.eps_iso = std::max(1e-6, 8.0 * tol * (alt_max / alt_min) / std::max(sin_min, 1e-3));
-        P.d_vertex = 1e-6 * l_max;
+    if (wild.size() > 4096) { P.walk_ok = false; P.note = "too many degenerate cells for the walk certificates"; }
+    {
+        // The track line must clear a cell's vertices by d_vertex: 100x the slack of point_in_segment (src/segment.jl:39-44,
+        // ≈0.75e-8·|edge| beyond an endpoint) and 100x the rounding error of the computed intersection point, which grows
+        // like 1/sin(track, edge) ≤ |edge| / (2 d_vertex): err ≈ 7.5e-16·|far corner|·|edge|/d_vertex.
+        const double corner = std::hypot(cmax_x, cmax_y);
+        P.d_vertex = std::max(1e-6 * l_max, 3e-7 * std::sqrt(corner * l_max));
         // chords shorter than this go to the generic step (the reference's isapprox(p, q) skip,
         // src/track.jl:156, triggers below ~1.5e-8 * |p|)
-        P.l_min = std::max(1e-6 * l_max, 8.0 * tol * std::hypot(std::max(std::fabs(bb[0]), std::fabs(bb[2])), std::max(std::fabs(bb[1]), std::fabs(bb[3]))));
-        if (P.eps_iso > 1e-3) { P.walk_ok = false; P.note = "mesh too distorted for the walk certificates"; }
+        P.l_min = std::max(1e-6 * l_max, 8.0 * kTol * corner);
     }
 
     // ---- extras bound: non-vertex nodes m that beat all three vertices somewhere in the
     //      (slightly inflated) cell:  |p-m|^2 < |p-v_i|^2  <=>  2 p·(v_i - m) < |v_i|^2 - |m|^2
     for (int32_t c = 0; c < n_cells && P.walk_ok; ++c) {
         CellRecHost &R = P.rec[c];
-        if (R.meta == 255) continue;
+        if (R.cls != 0) { R.extras = kExtrasNever; continue; }
         const double cx = (R.vx[0] + R.vx[1] + R.vx[2]) / 3, cy = (R.vy[0] + R.vy[1] + R.vy[2]) / 3;
-        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, lmax = 0;
+        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         P2 tri[3];
         for (int k = 0; k < 3; ++k) {
             tri[k] = {cx + (R.vx[k] - cx) * 1.001, cy + (R.vy[k] - cy) * 1.001};
             xmin = std::min(xmin, tri[k].x); xmax = std::max(xmax, tri[k].x);
             ymin = std::min(ymin, tri[k].y); ymax = std::max(ymax, tri[k].y);
-            lmax = std::max(lmax, std::hypot(R.vx[k] - R.vx[(k + 1) % 3], R.vy[k] - R.vy[(k + 1) % 3]));
         }
         int ix0, iy0, ix1, iy1;
-        bucket_of(xmin - lmax, ymin - lmax, ix0, iy0);
-        bucket_of(xmax + lmax, ymax + lmax, ix1, iy1);
+        bucket_of(xmin - R.lmax, ymin - R.lmax, ix0, iy0);
+        bucket_of(xmax + R.lmax, ymax + R.lmax, ix1, iy1);
         int extras = 0;
-        for (int by = iy0; by <= iy1; ++by)
-            for (int32_t s = P.gstart[by * gnx + ix0]; s < P.gstart[by * gnx + ix1 + 1]; ++s) {
+        std::vector<P2> poly;
+        for (int by = iy0; by <= iy1 && extras < kExtrasNever; ++by)
+            for (int32_t s = P.gstart[by * gnx + ix0]; s < P.gstart[by * gnx + ix1 + 1] && extras < kExtrasNever; ++s) {
                 const int32_t m = P.gnode[s];
                 if (m == cn[3 * c] || m == cn[3 * c + 1] || m == cn[3 * c + 2]) continue;
-                std::vector<P2> poly(tri, tri + 3);
+                poly.assign(tri, tri + 3);
                 const double mm = x[m] * x[m] + y[m] * y[m];
                 for (int k = 0; k < 3 && !poly.empty(); ++k) {
                     const double nx = 2 * (R.vx[k] - x[m]), ny = 2 * (R.vy[k] - y[m]);
@@ -208,10 +260,124 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                 }
                 if (poly.size() >= 1) ++extras;
             }
-        R.meta = extras > 254 ? 254 : extras;
+        R.extras = std::min(extras, kExtrasNever);
     }
+
+    // ---- isolation margin per record.  Cell buckets: every cell is listed in the buckets its acceptance region's
+    //      bounding box touches, so a query with T''s bounding box finds every cell whose region can reach T'.
+    std::vector<int8_t> epscode((size_t)3 * n_cells, (int8_t)(kEpsCodeMax + 1));
+    if (P.walk_ok) {
+        auto accept_scale = [&](const CellRecHost &U) { return 1.0 + 3.0 * 1.01 * (kTol + 2.0 * U.fp_err) + 1e-13; };
+        std::vector<int32_t> cstart((size_t)gnx * gny + 1, 0), clist;
+        auto cell_box = [&](int32_t c, int &ix0, int &iy0, int &ix1, int &iy1) {
+            const CellRecHost &U = P.rec[c];
+            const double ux = (U.vx[0] + U.vx[1] + U.vx[2]) / 3, uy = (U.vy[0] + U.vy[1] + U.vy[2]) / 3;
+            const double s = U.cls == 2 ? 1.0 : accept_scale(U);
+            double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+            for (int k = 0; k < 3; ++k) {
+                const double px = ux + (U.vx[k] - ux) * s, py = uy + (U.vy[k] - uy) * s;
+                xmin = std::min(xmin, px); xmax = std::max(xmax, px); ymin = std::min(ymin, py); ymax = std::max(ymax, py);
+            }
+            const double pad = 1e-12 * (std::fabs(xmin) + std::fabs(xmax) + std::fabs(ymin) + std::fabs(ymax) + 1.0);
+            bucket_of(xmin - pad, ymin - pad, ix0, iy0);
+            bucket_of(xmax + pad, ymax + pad, ix1, iy1);
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<int32_t> cur;
+            if (pass == 1) {
+                for (size_t b = 0; b < (size_t)gnx * gny; ++b) cstart[b + 1] += cstart[b];
+                clist.assign((size_t)cstart[(size_t)gnx * gny], 0);
+                cur.assign(cstart.begin(), cstart.end() - 1);
+            }
+            for (int32_t c = 0; c < n_cells; ++c) {
+                if (P.rec[c].cls == 2) continue;  // degenerate cells are handled through `wild`
+                int ix0, iy0, ix1, iy1;
+                cell_box(c, ix0, iy0, ix1, iy1);
+                for (int by = iy0; by <= iy1; ++by)
+                    for (int bx = ix0; bx <= ix1; ++bx) {
+                        if (pass == 0) cstart[(size_t)by * gnx + bx + 1]++;
+                        else clist[cur[(size_t)by * gnx + bx]++] = c;
+                    }
+            }
+        }
+        std::vector<int32_t> stamp(n_cells, -1), cand;
+        std::vector<P2> acc, pa, pb;
+        const double theta = 0.25 * kTol * 1.5;  // the record's region reaches this far (barycentric) beyond its entry edge
+        for (int32_t c = 0; c < n_cells; ++c) {
+            const CellRecHost &R = P.rec[c];
+            if (R.cls != 0 || R.extras >= kExtrasNever) continue;
+            // a degenerate cell within the scan reach of this cell (its nodes can precede the cell's own in the node
+            // scan of find_element) makes the reference's result unpredictable here
+            bool near_wild = false;
+            const double bx0 = std::min({R.vx[0], R.vx[1], R.vx[2]}), bx1 = std::max({R.vx[0], R.vx[1], R.vx[2]});
+            const double by0 = std::min({R.vy[0], R.vy[1], R.vy[2]}), by1 = std::max({R.vy[0], R.vy[1], R.vy[2]});
+            for (int32_t wc : wild) {
+                const CellRecHost &U = P.rec[wc];
+                const double reach = 2.0 * R.lmax + 1e-9 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1));
+                const double ux0 = std::min({U.vx[0], U.vx[1], U.vx[2]}), ux1 = std::max({U.vx[0], U.vx[1], U.vx[2]});
+                const double uy0 = std::min({U.vy[0], U.vy[1], U.vy[2]}), uy1 = std::max({U.vy[0], U.vy[1], U.vy[2]});
+                if (!(ux0 > bx1 + reach || ux1 < bx0 - reach || uy0 > by1 + reach || uy1 < by0 - reach)) { near_wild = true; break; }
+            }
+            if (near_wild) continue;
+            // candidates: cells whose acceptance region's bounding box touches this cell's (slightly padded) box
+            cand.clear();
+            {
+                const double pad = 1e-7 * R.lmax + 1e-12 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1) + 1.0);
+                int ix0, iy0, ix1, iy1;
+                bucket_of(bx0 - pad, by0 - pad, ix0, iy0);
+                bucket_of(bx1 + pad, by1 + pad, ix1, iy1);
+                for (int by = iy0; by <= iy1; ++by)
+                    for (int bx = ix0; bx <= ix1; ++bx)
+                        for (int32_t s = cstart[(size_t)by * gnx + bx]; s < cstart[(size_t)by * gnx + bx + 1]; ++s) {
+                            const int32_t u = clist[s];
+                            if (u != c && stamp[u] != c) { stamp[u] = c; cand.push_back(u); }
+                        }
+            }
+            // barycentric coordinates of this cell: mu_k(p) = (nk·p - ck), zero on the edge opposite vertex k
+            const double a2s = (R.vx[1] - R.vx[0]) * (R.vy[2] - R.vy[0]) - (R.vx[2] - R.vx[0]) * (R.vy[1] - R.vy[0]);
+            double mnx[3], mny[3], mc[3];
+            for (int k = 0; k < 3; ++k) {
+                const int i1 = (k + 1) % 3, i2 = (k + 2) % 3;  // the edge opposite vertex k runs i1 -> i2
+                mnx[k] = -(R.vy[i2] - R.vy[i1]) / a2s;
+                mny[k] = (R.vx[i2] - R.vx[i1]) / a2s;
+                mc[k] = mnx[k] * R.vx[i1] + mny[k] * R.vy[i1];
+            }
+            double need[3] = {0, 0, 0};
+            for (int32_t u : cand) {
+                const CellRecHost &U = P.rec[u];
+                const double ux = (U.vx[0] + U.vx[1] + U.vx[2]) / 3, uy = (U.vy[0] + U.vy[1] + U.vy[2]) / 3;
+                const double s = accept_scale(U);
+                for (int e = 0; e < 3; ++e) {
+                    if (u == R.adj[e]) continue;  // the predecessor T of this record is evaluated exactly on the device
+                    // rotated roles: entry edge (v_e, v_e+1) is opposite vertex e+2; exit edges opposite vertices e and e+1
+                    const int k0 = e, k1 = (e + 1) % 3, k2 = (e + 2) % 3;
+                    acc.clear();
+                    for (int k = 0; k < 3; ++k) acc.push_back({ux + (U.vx[k] - ux) * s, uy + (U.vy[k] - uy) * s});
+                    clip(acc, -mnx[k2], -mny[k2], -(mc[k2] - theta));  // mu_k2 >= -theta
+                    if (acc.empty()) continue;
+                    pa = acc;
+                    clip(pa, mnx[k0] - mnx[k1], mny[k0] - mny[k1], mc[k0] - mc[k1]);  // mu_k0 <= mu_k1: min is mu_k0
+                    for (const P2 &p : pa) need[e] = std::max(need[e], mnx[k0] * p.x + mny[k0] * p.y - mc[k0]);
+                    pb = acc;
+                    clip(pb, mnx[k1] - mnx[k0], mny[k1] - mny[k0], mc[k1] - mc[k0]);  // mu_k1 <= mu_k0: min is mu_k1
+                    for (const P2 &p : pb) need[e] = std::max(need[e], mnx[k1] * p.x + mny[k1] * p.y - mc[k1]);
+                }
+            }
+            for (int e = 0; e < 3; ++e) {
+                const double eps = 2.0 * need[e] + 1e-9;
+                int code = kEpsCodeMin;
+                while (code <= kEpsCodeMax && std::ldexp(1.0, code - 20) < eps) ++code;
+                epscode[(size_t)3 * c + e] = (int8_t)code;
+            }
+        }
+    }
+
     // ---- rotated walk records
-    if ((uint64_t)3 * (uint64_t)n_cells + 1 >= (1ull << kWalkIdBits)) { P.walk_ok = false; P.note = "too many cells for the packed walk records"; }
+    {
+        uint64_t limit = 1ull << kWalkIdBits;
+        if (const char *env = std::getenv("RT_TEST_WALK_RECORD_LIMIT")) limit = std::strtoull(env, nullptr, 10);  // tests only
+        if ((uint64_t)3 * (uint64_t)n_cells + 1 >= limit) { P.walk_ok = false; P.note = "too many cells for the packed walk records"; }
+    }
     P.wrec.assign((size_t)3 * n_cells, WalkRecHost{});
     P.adjr.assign((size_t)3 * n_cells, -1);
     for (int32_t c = 0; c < n_cells; ++c)
@@ -228,6 +394,8 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                 }
             P.adjr[3 * c + k] = ki >= 0 ? 3 * nb + ki : -1;
         }
+    P.n_records = (int64_t)3 * n_cells;
+    P.eps_min = INFINITY; P.eps_max = 0.0;
     for (int32_t c = 0; c < n_cells; ++c) {
         const CellRecHost &R = P.rec[c];
         const double x1 = R.vx[0], y1 = R.vy[0], x2 = R.vx[1], y2 = R.vy[1], x3 = R.vx[2], y3 = R.vy[2];
@@ -240,14 +408,25 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
             bool same = false;
             const int32_t back = P.adjr[3 * c + e];  // record (neighbour, its edge q) across the entry edge
             if (back >= 0) same = cn[3 * c + e] == cn[3 * (back / 3) + back % 3];
+            int code = epscode[(size_t)3 * c + e];
+            int extras = R.extras;
+            if (!P.walk_ok || code > kEpsCodeMax || back < 0) { extras = kExtrasNever; code = kEpsCodeMax; }
+            if (extras < kExtrasNever) {
+                ++P.n_records_walk;
+                const double eps = std::ldexp(1.0, code - 20);
+                P.eps_min = std::min(P.eps_min, eps); P.eps_max = std::max(P.eps_max, eps);
+                P.extras_max = std::max(P.extras_max, extras);
+            }
             Wr.hdr = (uint64_t)(P.adjr[3 * c + i1] + 1) | ((uint64_t)(P.adjr[3 * c + i2] + 1) << kWalkIdBits) |
-                     ((uint64_t)(R.meta & 255) << (2 * kWalkIdBits)) | ((uint64_t)(same ? 1 : 0) << (2 * kWalkIdBits + 8));
+                     ((uint64_t)(extras & 15) << (2 * kWalkIdBits)) | ((uint64_t)(code & 31) << (2 * kWalkIdBits + 4)) |
+                     ((uint64_t)(same ? 1 : 0) << 63);
             Wr.dT = dT;
             Wr.x2 = R.vx[i2]; Wr.y2 = R.vy[i2];
             Wr.e1A = R.eA[i1]; Wr.e1B = R.eB[i1]; Wr.e1C = R.eC[i1];
             Wr.e2A = R.eA[i2]; Wr.e2B = R.eB[i2]; Wr.e2C = R.eC[i2];
         }
     }
+    if (P.n_records_walk == 0) { P.eps_min = 0.0; if (P.walk_ok) { P.walk_ok = false; if (P.note.empty()) P.note = "no cell passes the walk certificates"; } }
     return P;
 }
 

@@ -350,12 +350,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     Walk wk;
     wk.T = -1; wk.pred = -1;
     wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
-    const int kk = prm.k > 2 ? prm.k : 2;
+    // node window of find_element(xp) then find_element(xp, k) as the walk records count it (extras field: 0..14, 15 = never)
+    const int kk = prm.k > 2 ? (prm.k < rt::kExtrasNever - 1 ? prm.k : rt::kExtrasNever - 1) : 2;
+    const bool fwd = phi < kHalfPi;  // order_intersection_points, src/intersection.jl:153
     double lqx = 0.0, lqy = 0.0;  // exit point of the last emitted segment
     // The walk step's mesh constants, held in VGPRs: as SGPRs they share a tuple of the argument load that the
     // register allocator spills as a whole and reloads (8 v_readlane) several times per iteration.
     DMesh mh = m;
-    asm volatile("" : "+v"(mh.d_vertex), "+v"(mh.eps_iso), "+v"(mh.l_min), "+v"(mh.wrec));
+    asm volatile("" : "+v"(mh.d_vertex), "+v"(mh.l_min), "+v"(mh.wrec));
     NextRec nr;
     load_next(mh, -1, nr);
     // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         const unsigned long long tB_ = rt_tick(RT_TIMING == 2 ? nr.e2C : xpx);
         tacc0 += tB_ - tA_;
 #endif
-        res = walk_step(mh, wk, nr, kk, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+        res = walk_step(mh, wk, nr, kk, fwd, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
 #ifdef RT_TIMING
         tC_ = rt_tick(ell + (double)res);
         tacc1 += tC_ - tB_;
@@ -466,6 +468,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             }
             creep_run = 0;
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
+            if (MODE != kFill) {
+                // per-call statistic (rt_last_stats): records the generic step produced — the walk step made the rest
+                const unsigned long long act = __ballot(1);
+                if (lane == __ffsll((long long)act) - 1) atomicAdd(&fail_info[15], (unsigned long long)__popcll(act));
+            }
             if (m.walk_ok && eq >= 0) walk_enter(m, g, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
         }
@@ -934,6 +941,10 @@ struct rt_mesh {
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
+    // diagnostics of the host preprocessing (rt_mesh_info)
+    int64_t n_records = 0, n_records_walk = 0;
+    int32_t n_cells_fragile = 0, n_cells_wild = 0, n_edges_nonmanifold = 0, extras_max = 0;
+    double eps_min = 0.0, eps_max = 0.0, prep_ms = 0.0;
 };
 
 struct rt_tracks {
@@ -965,6 +976,8 @@ struct rt_tracks {
     DevBuf<int32_t> vorder, vw_wave, vw_k, w_base, w_P, s_el, s_eq, p_count, p_flags, p_valid, p_rel;
     DevBuf<double> s_px, s_py, s_qx, s_qy, s_ell, p_sum;
     double sum_ell = 0.0;
+    int32_t azim_min = 1, azim_max = 0;  // range of azim_idx (checked against n_azim_2 by rt_segmentize)
+    int64_t n_generic_records = 0;       // rt_last_stats
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     void *pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rt_fetch_segments_pinned
     size_t pin_cap = 0;                                                     // records
@@ -1023,7 +1036,9 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
         set_error("empty or non-finite bounding box");
         return RT_ERR_INVALID;
     }
+    const auto t_prep0 = std::chrono::steady_clock::now();
     rtprep::Prep P = rtprep::prepare(x, y, n_nodes, cn.data(), n_cells, bb);
+    m->prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count();
     const std::vector<int32_t> &gstart = P.gstart, &gnode = P.gnode;
     const double gh = P.gh, ginv = P.ginv;
     const int gnx = P.gnx, gny = P.gny;
@@ -1053,11 +1068,15 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     d.geo = (const RT_K rt::DGeo *)m->geo.p;
     d.bx0 = bb[0]; d.by0 = bb[1]; d.bx1 = bb[2]; d.by1 = bb[3];
     d.n_cells = n_cells;
-    d.wrec = as_global(m->wrec.p); d.adjr = as_global(m->adjr.p); d.eps_iso = P.eps_iso; d.d_vertex = P.d_vertex; d.l_min = P.l_min;
+    d.wrec = as_global(m->wrec.p); d.adjr = as_global(m->adjr.p); d.d_vertex = P.d_vertex; d.l_min = P.l_min;
     d.walk_ok = P.walk_ok ? 1 : 0;
     m->walk_available = P.walk_ok;
     m->kappa = P.kappa;
     m->prep_note = P.note;
+    m->n_records = P.n_records; m->n_records_walk = P.n_records_walk;
+    m->n_cells_fragile = P.n_cells_fragile; m->n_cells_wild = P.n_cells_wild;
+    m->n_edges_nonmanifold = P.n_edges_nonmanifold; m->extras_max = P.extras_max;
+    m->eps_min = P.eps_min; m->eps_max = P.eps_max;
     return RT_SUCCESS;
 }
 
@@ -1238,6 +1257,15 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
             for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
     }
     for (size_t i = 0; i < n; ++i) t->sum_ell += ell[i];
+    if (n > 0) {
+        t->azim_min = *std::min_element(azim_idx, azim_idx + n);
+        t->azim_max = *std::max_element(azim_idx, azim_idx + n);
+        if (t->azim_min < 1) {  // δs[azim_idx] is read on the device (fill_volumes, src/trackgenerator.jl:379-382)
+            set_error("rt_tracks_create: azim_idx must be 1-based (smallest value %d)", t->azim_min);
+            delete t;
+            return nullptr;
+        }
+    }
     // split plan: pieces per wave of 64 consecutive uids, canonical numbering, dispatch order
     std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P;
     // Splitting pays when the batch has too few waves to fill the chip (the march is then bound by its
@@ -1309,6 +1337,14 @@ void rt_tracks_destroy(rt_tracks *tracks) {
 int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s,
                       int32_t n_azim_2) {
     if (!t || !delta_s || n_azim_2 <= 0) { set_error("rt_segmentize: bad arguments"); return RT_ERR_INVALID; }
+    if (k < 0) {  // knn(kdtree, x, k, ...) rejects a negative k (src/mesh.jl:123); any k >= 0 is honoured
+        set_error("rt_segmentize: k = %d (must be >= 0)", k);
+        return RT_ERR_INVALID;
+    }
+    if (t->n > 0 && t->azim_max > n_azim_2) {
+        set_error("rt_segmentize: track azim_idx reaches %d but delta_s has n_azim_2 = %d entries", t->azim_max, n_azim_2);
+        return RT_ERR_INVALID;
+    }
     rt_mesh *m = t->mesh;
     RT_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
@@ -1581,6 +1617,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
             fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
 #endif
     t->total = total;
+    t->n_generic_records = (int64_t)fi[15];
     t->n_failed = (int64_t)fi[0];
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
     t->first_failed_status = 0;
@@ -1694,6 +1731,30 @@ int32_t rt_device_pointers(rt_tracks *t, void **p) {
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
     p[0] = t->offsets.p; p[1] = t->status.p; p[2] = t->spx.p; p[3] = t->spy.p; p[4] = t->sqx.p;
     p[5] = t->sqy.p; p[6] = t->sell.p; p[7] = t->element.p; p[8] = t->volumes.p;
+    return RT_SUCCESS;
+}
+
+int32_t rt_mesh_info(rt_mesh *m, double *info, int32_t n_info, char *note, int32_t note_cap) {
+    if (!m || (n_info > 0 && !info) || n_info < 0 || note_cap < 0) { set_error("rt_mesh_info: bad argument"); return RT_ERR_INVALID; }
+    const double v[RT_MESH_INFO_COUNT] = {
+        (double)(m->d.walk_ok ? 1 : 0), (double)m->n_records, (double)m->n_records_walk, m->eps_min, m->eps_max,
+        m->d.d_vertex, m->d.l_min, (double)m->n_cells_fragile, (double)m->n_cells_wild, (double)m->n_edges_nonmanifold,
+        (double)m->extras_max, m->prep_ms, m->kappa, (double)(m->walk_available ? 1 : 0)};
+    for (int i = 0; i < n_info && i < RT_MESH_INFO_COUNT; ++i) info[i] = v[i];
+    if (note && note_cap > 0) {
+        strncpy(note, m->prep_note.c_str(), (size_t)note_cap - 1);
+        note[note_cap - 1] = 0;
+    }
+    return RT_SUCCESS;
+}
+
+int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
+    if (!t || !stats || n < 4) { set_error("rt_last_stats: bad argument"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    stats[0] = t->total;
+    stats[1] = t->n_generic_records;
+    stats[2] = t->chunks_needed_last;
+    stats[3] = t->pool_chunks;
     return RT_SUCCESS;
 }
 

@@ -1,0 +1,200 @@
+// host_march.hip — TEST INFRASTRUCTURE.  Runs the device march's per-lane logic on the host.
+//
+// The geometry of the march (csrc/rt_device.hpp: walk_step and its certificates, find_element,
+// intersections) and the mesh preprocessing (csrc/rt_mesh_prep.hpp) are plain FP64 arithmetic that
+// compiles for the host as well.  This file drives them with the control flow of one lane of k_march
+// (csrc/rt_segmentize.hip; reference: _segmentize_track!, src/track.jl:106-178), so that the walk
+// step's certificates can be fuzzed against the CPU checker on thousands of meshes without a GPU:
+// walk on == walk off == checker, bit for bit (tests/test_walk_certificates_cpu.py, tools/fuzz_cpu.py).
+// It is not part of the product: the library never marches on the host, nothing in raytracing.jl_amd/
+// builds or loads this file, and the GPU parity tests go through the C ABI on the real kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -fno-fast-math -fPIC -shared (tests/hostmarch.py).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../raytracing.jl_amd/csrc/rt_device.hpp"
+#include "../raytracing.jl_amd/csrc/rt_mesh_prep.hpp"
+
+namespace {
+
+struct Rec { double px, py, qx, qy, ell; int32_t element; };
+
+struct Result {
+    std::vector<int64_t> offsets;
+    std::vector<int32_t> status;
+    std::vector<Rec> recs;
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+Result g_res;
+
+// counters: [0] walk emits, [1] walk skips (incl. creep passes), [2] generic emits, [3] generic iterations in total,
+// [4] generic iterations taken although a prediction existed (a certificate refused)
+void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, double phi, double cs, double sn, double tA,
+                 double tB, double tC, double track_ell, double tiny, int k, double rtol, int64_t iter_cap,
+                 std::vector<Rec> &out, int32_t &status, int64_t *cnt) {
+    using namespace rt;
+    const double sx = tiny * cs, sy = tiny * sn;  // advance_step, src/point.jl:43
+    double xpx = px0 + sx, xpy = py0 + sy;        // src/track.jl:114
+    int i = 0;
+    int64_t it = 0;
+    int32_t prev_element = -1;
+    int st = 0;
+    double sum_ell = 0.0;
+    Walk wk;
+    wk.T = -1; wk.pred = -1;
+    wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
+    const int kk = k > 2 ? (k < kExtrasNever - 1 ? k : kExtrasNever - 1) : 2;
+    const bool fwd = phi < kHalfPi;
+    double lqx = 0.0, lqy = 0.0;
+    NextRec nr;
+    while (st == 0 && inboundary(m, xpx, xpy, tiny)) {  // start band
+        if (++it > iter_cap) { st = 4; break; }
+        xpx = xpx + sx; xpy = xpy + sy;
+    }
+    while (st == 0 && i < kMaxIter) {
+        if (++it > iter_cap) { st = 4; break; }
+        double px, py, qx, qy, ell;
+        int32_t element = -1;
+        if (inboundary(m, xpx, xpy, tiny)) {
+            if (i == 0) { xpx = xpx + sx; xpy = xpy + sy; continue; }
+            break;
+        }
+        load_next(m, wk.pred, nr);
+        int res = walk_step(m, wk, nr, kk, fwd, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+        if (res == kWalkSkip) {
+            ++cnt[1];
+            xpx = xpx + sx; xpy = xpy + sy;
+            while (it < iter_cap && !inboundary(m, xpx, xpy, tiny) && walk_still_skip(m, wk, nr, xpx, xpy)) {
+                ++it; ++cnt[1];
+                xpx = xpx + sx; xpy = xpy + sy;
+            }
+            continue;
+        }
+        px = lqx; py = lqy; element = wk.T;
+        if (res == kWalkGeneric) {
+            ++cnt[3];
+            if (m.walk_ok && wk.pred >= 0) ++cnt[4];
+            element = find_element(g, xpx, xpy, k);
+            if (element < 0) { st = 1; break; }
+            if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }
+            int eq;
+            if (!intersections(g, element, phi, tA, tB, tC, px, py, qx, qy, eq)) { st = 3; break; }
+            if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }
+            ell = norm2(px - qx, py - qy);
+            if (m.walk_ok && eq >= 0) walk_enter(m, g, wk, element, eq);
+            else { wk.T = element; wk.pred = -1; }
+            ++cnt[2];
+        } else {
+            ++cnt[0];
+        }
+        out.push_back({px, py, qx, qy, ell, element + 1});
+        sum_ell += ell;
+        lqx = qx; lqy = qy;
+        xpx = qx + sx; xpy = qy + sy;
+        prev_element = element;
+        ++i;
+    }
+    if (st == 0 && !isapprox_s(track_ell, sum_ell, rtol)) st = 2;
+    status = st;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Preprocess the mesh (rtprep::prepare) and march every track on the host.  Ids as at the C ABI: cell_nodes and
+// node_cells_data 1-based, node_cells_ptrs 0-based.  walk = 0: literal step only.  Returns the number of records
+// (held until the next call; hostmarch_fetch copies them) or -1.
+int64_t hostmarch_run(const double *x, const double *y, int32_t n_nodes, const int32_t *cell_nodes, int32_t n_cells,
+                      const int32_t *ncp, const int32_t *ncd1, const double *bb, int64_t n_tracks, const double *px,
+                      const double *py, const double *phi, const double *cs, const double *sn, const double *A,
+                      const double *B, const double *C, const double *ell, double tiny, int32_t k, double rtol,
+                      int64_t iter_cap, int32_t walk, int32_t n_threads, double *info /* [8] or NULL */) {
+    std::vector<int32_t> cn(3 * (size_t)n_cells), ncd((size_t)ncp[n_nodes] > 0 ? ncp[n_nodes] : 1);
+    for (size_t i = 0; i < cn.size(); ++i) cn[i] = cell_nodes[i] - 1;
+    for (int32_t i = 0; i < ncp[n_nodes]; ++i) ncd[i] = ncd1[i] - 1;
+    rtprep::Prep P = rtprep::prepare(x, y, n_nodes, cn.data(), n_cells, bb);
+    rt::DGeo g{};
+    g.x = rt::as_global(x); g.y = rt::as_global(y); g.cn = rt::as_global((const int32_t *)cn.data());
+    g.ncp = rt::as_global(ncp); g.ncd = rt::as_global((const int32_t *)ncd.data());
+    g.gstart = rt::as_global((const int32_t *)P.gstart.data()); g.gnode = rt::as_global((const int32_t *)P.gnode.data());
+    g.gx0 = bb[0]; g.gy0 = bb[1]; g.gh = P.gh; g.ginv = P.ginv; g.gnx = P.gnx; g.gny = P.gny; g.n_nodes = n_nodes;
+    rt::DMesh m{};
+    m.wrec = rt::as_global(reinterpret_cast<const rt::WalkRec *>(P.wrec.data()));
+    m.adjr = rt::as_global((const int32_t *)P.adjr.data());
+    m.d_vertex = P.d_vertex; m.l_min = P.l_min; m.walk_ok = (P.walk_ok && walk) ? 1 : 0; m.n_cells = n_cells;
+    m.bx0 = bb[0]; m.by0 = bb[1]; m.bx1 = bb[2]; m.by1 = bb[3];
+    m.geo = nullptr;
+    if (info) {
+        info[0] = P.walk_ok ? 1 : 0; info[1] = (double)P.n_records; info[2] = (double)P.n_records_walk; info[3] = P.eps_min;
+        info[4] = P.eps_max; info[5] = P.d_vertex; info[6] = (double)P.n_cells_fragile; info[7] = (double)P.n_cells_wild;
+    }
+    const int nt = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<std::vector<Rec>> part(nt);
+    std::vector<int64_t> counts(n_tracks, 0);
+    g_res = Result();
+    g_res.status.assign(n_tracks, 0);
+    std::vector<std::vector<int64_t>> cnt(nt, std::vector<int64_t>(8, 0));
+    // contiguous blocks of tracks per thread, so that the concatenation is in uid order
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            const int64_t u0 = n_tracks * t / nt, u1 = n_tracks * (t + 1) / nt;
+            for (int64_t u = u0; u < u1; ++u) {
+                const size_t before = part[t].size();
+                int32_t st = 0;
+                march_track(m, g, px[u], py[u], phi[u], cs[u], sn[u], A[u], B[u], C[u], ell[u], tiny, k, rtol, iter_cap,
+                            part[t], st, cnt[t].data());
+                counts[u] = (int64_t)(part[t].size() - before);
+                g_res.status[u] = st;
+            }
+        });
+    for (auto &t : th) t.join();
+    g_res.offsets.assign(n_tracks + 1, 0);
+    for (int64_t u = 0; u < n_tracks; ++u) g_res.offsets[u + 1] = g_res.offsets[u] + counts[u];
+    for (int t = 0; t < nt; ++t) {
+        g_res.recs.insert(g_res.recs.end(), part[t].begin(), part[t].end());
+        for (int j = 0; j < 8; ++j) g_res.stats[j] += cnt[t][j];
+    }
+    return (int64_t)g_res.recs.size();
+}
+
+void hostmarch_fetch(int64_t *offsets, int32_t *status, double *px, double *py, double *qx, double *qy, double *ell,
+                     int32_t *element, int64_t *stats) {
+    memcpy(offsets, g_res.offsets.data(), sizeof(int64_t) * g_res.offsets.size());
+    memcpy(status, g_res.status.data(), sizeof(int32_t) * g_res.status.size());
+    for (size_t i = 0; i < g_res.recs.size(); ++i) {
+        const Rec &r = g_res.recs[i];
+        px[i] = r.px; py[i] = r.py; qx[i] = r.qx; qy[i] = r.qy; ell[i] = r.ell; element[i] = r.element;
+    }
+    memcpy(stats, g_res.stats, sizeof(g_res.stats));
+}
+
+// Host-only view of the preprocessing (no march): the per-record certificate fields, for tests.
+// extras[3*n_cells], epscode[3*n_cells] (-1 where the walk step is off), cls[n_cells].
+int32_t hostmarch_prep(const double *x, const double *y, int32_t n_nodes, const int32_t *cell_nodes, int32_t n_cells,
+                       const double *bb, int32_t *extras, int32_t *epscode, int32_t *cls, double *info /* [8] */,
+                       char *note, int32_t note_cap) {
+    std::vector<int32_t> cn(3 * (size_t)n_cells);
+    for (size_t i = 0; i < cn.size(); ++i) cn[i] = cell_nodes[i] - 1;
+    rtprep::Prep P = rtprep::prepare(x, y, n_nodes, cn.data(), n_cells, bb);
+    for (size_t r = 0; r < P.wrec.size(); ++r) {
+        const uint64_t h = P.wrec[r].hdr;
+        const int ex = (int)(h >> 54) & 15, code = (int)(h >> 58) & 31;
+        extras[r] = ex;
+        epscode[r] = ex >= rtprep::kExtrasNever ? -1 : code;
+    }
+    for (int32_t c = 0; c < n_cells; ++c) cls[c] = P.rec[c].cls;
+    info[0] = P.walk_ok ? 1 : 0; info[1] = (double)P.n_records; info[2] = (double)P.n_records_walk; info[3] = P.eps_min;
+    info[4] = P.eps_max; info[5] = P.d_vertex; info[6] = (double)P.n_cells_fragile; info[7] = (double)P.n_cells_wild;
+    if (note && note_cap > 0) { strncpy(note, P.note.c_str(), (size_t)note_cap - 1); note[note_cap - 1] = 0; }
+    return 0;
+}
+
+}  // extern "C"

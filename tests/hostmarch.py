@@ -1,0 +1,102 @@
+"""ctypes wrapper of tests/host_march.hip — TEST INFRASTRUCTURE (see that file's header): the device march's
+per-lane logic and the mesh preprocessing compiled for the host, to fuzz the walk step's certificates against the
+CPU checker without a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "host_march.hip")
+_OUT = os.path.join(_HERE, "build", "libhostmarch.so")
+_CSRC = os.path.join(_HERE, "..", "raytracing.jl_amd", "csrc")
+_lib = None
+_dp, _ip, _lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+def build() -> str:
+    deps = [_SRC, os.path.join(_CSRC, "rt_device.hpp"), os.path.join(_CSRC, "rt_mesh_prep.hpp")]
+    if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
+        os.makedirs(os.path.dirname(_OUT), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off",
+                               "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-Wno-unused-function", "-o", _OUT, _SRC])
+    return _OUT
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.hostmarch_run.restype = C.c_int64
+        L.hostmarch_run.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp, C.c_int64] + [_dp] * 9 + \
+            [C.c_double, C.c_int32, C.c_double, C.c_int64, C.c_int32, C.c_int32, _dp]
+        L.hostmarch_fetch.argtypes = [_lp, _ip] + [_dp] * 5 + [_ip, _lp]
+        L.hostmarch_prep.restype = C.c_int32
+        L.hostmarch_prep.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip, _ip, _ip, _dp, C.c_char_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+INFO = ("walk_ok", "records", "records_walk", "eps_min", "eps_max", "d_vertex", "cells_fragile", "cells_degenerate")
+
+
+def run(tg, *, k=5, rtol=None, walk=True, iter_cap=4000000, n_threads=0):
+    """March every track of ``tg`` on the host with the device header's logic.  Returns a dict shaped like the
+    checker's (offsets, status, element, px, py, qx, qy, ell, total) + ``stats`` and ``info``."""
+    mesh = tg.mesh
+    x, y = _f(mesh.x), _f(mesh.y)
+    cn = _i(np.asarray(mesh.cell_nodes).reshape(-1))
+    ptr = _i(np.asarray(mesh.node_cells_ptrs) - int(mesh.node_cells_ptrs[0]))
+    dat = _i(mesh.node_cells_data)
+    bb = _f(mesh.bb)
+    arrs = [_f(a) for a in (tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell)]
+    n = len(arrs[0])
+    info = np.zeros(8)
+    p = lambda a, t: a.ctypes.data_as(t)
+    total = lib().hostmarch_run(p(x, _dp), p(y, _dp), len(x), p(cn, _ip), len(cn) // 3, p(ptr, _ip), p(dat, _ip), p(bb, _dp),
+                                n, *[p(a, _dp) for a in arrs], float(tg.tiny_step), int(k),
+                                float(rtol if rtol is not None else 1.4901161193847656e-8), int(iter_cap),
+                                1 if walk else 0, int(n_threads), p(info, _dp))
+    if total < 0:
+        raise RuntimeError("hostmarch_run failed")
+    out = {k2: np.zeros(total, np.float64) for k2 in ("px", "py", "qx", "qy", "ell")}
+    out["element"] = np.zeros(total, np.int32)
+    out["offsets"] = np.zeros(n + 1, np.int64)
+    out["status"] = np.zeros(max(n, 1), np.int32)
+    stats = np.zeros(8, np.int64)
+    lib().hostmarch_fetch(p(out["offsets"], _lp), p(out["status"], _ip), *[p(out[k2], _dp) for k2 in ("px", "py", "qx", "qy", "ell")],
+                          p(out["element"], _ip), p(stats, _lp))
+    out["status"] = out["status"][:n]
+    out["total"] = int(total)
+    out["stats"] = dict(walk_emits=int(stats[0]), walk_skips=int(stats[1]), generic_emits=int(stats[2]),
+                        generic_iterations=int(stats[3]), refused=int(stats[4]))
+    out["info"] = {k2: float(info[i]) for i, k2 in enumerate(INFO)}
+    return out
+
+
+def prep(mesh):
+    """The preprocessing's per-record certificate fields: extras[n_cells,3], epscode[n_cells,3] (-1: walk off),
+    cls[n_cells], info dict, note."""
+    x, y = _f(mesh.x), _f(mesh.y)
+    cn = _i(np.asarray(mesh.cell_nodes).reshape(-1))
+    bb = _f(mesh.bb)
+    nc = len(cn) // 3
+    extras, code, cls = np.zeros(3 * nc, np.int32), np.zeros(3 * nc, np.int32), np.zeros(nc, np.int32)
+    info = np.zeros(8)
+    note = C.create_string_buffer(256)
+    p = lambda a, t: a.ctypes.data_as(t)
+    lib().hostmarch_prep(p(x, _dp), p(y, _dp), len(x), p(cn, _ip), nc, p(bb, _dp), p(extras, _ip), p(code, _ip), p(cls, _ip),
+                         p(info, _dp), note, 256)
+    return dict(extras=extras.reshape(nc, 3), epscode=code.reshape(nc, 3), cls=cls,
+                info={k2: float(info[i]) for i, k2 in enumerate(INFO)}, note=note.value.decode())

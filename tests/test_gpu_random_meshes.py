@@ -12,27 +12,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _random_model(rt, seed, n_interior, w=1.0, h=1.0, nb=12, x0=0.0, y0=0.0, cluster=False):
-    from scipy.spatial import Delaunay
+def _random_model(rt, seed, n_interior, **kw):
+    from meshgen import random_model
 
-    rng = np.random.default_rng(seed)
-    tx = np.arange(nb) * (w / nb)
-    ty = np.arange(nb) * (h / nb)
-    pts = [(x0 + v, y0) for v in tx] + [(x0 + w, y0 + v) for v in ty] + [(x0 + w - v, y0 + h) for v in tx] + \
-          [(x0, y0 + h - v) for v in ty]
-    inner = rng.uniform(0.02, 0.98, (n_interior, 2))
-    if cluster:  # a tight cluster: many tiny cells next to large ones
-        inner[: n_interior // 3] = 0.5 + 0.01 * rng.standard_normal((n_interior // 3, 2))
-        inner = np.clip(inner, 0.02, 0.98)
-    pts += [(x0 + w * a, y0 + h * b) for a, b in inner]
-    xy = np.asarray(pts, dtype=np.float64)
-    tri = Delaunay(xy)
-    cells = np.sort(tri.simplices.astype(np.int32) + 1, axis=1)
-    # drop degenerate (zero-area) triangles Delaunay may emit on the collinear boundary points
-    a, b, c = xy[cells[:, 0] - 1], xy[cells[:, 1] - 1], xy[cells[:, 2] - 1]
-    area2 = np.abs((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1]))
-    cells = cells[area2 > 1e-14]
-    return rt.DiscreteModel(xy, cells)
+    return random_model(rt, seed, n_interior, **kw)
 
 
 def _oracle(orc, tg):

@@ -1,0 +1,159 @@
+"""The walk step's certificates without a GPU: the device march's per-lane logic and the mesh preprocessing,
+compiled for the host (tests/host_march.hip — test infrastructure built from the product's own headers), against
+the CPU checker.  Walk step on == walk step off == checker, bit for bit, on every mesh class, and the
+preprocessing's per-record switches behave as documented.  The kernels themselves are tested on the GPU
+(tests/test_gpu_*.py); tools/fuzz_cpu.py runs the same comparison over hundreds of seeds."""
+import os
+
+import numpy as np
+import pytest
+
+import hostmarch as hm
+import meshgen
+
+FIELDS = ("px", "py", "qx", "qy", "ell")
+
+
+def _oracle(orc, tg, **kw):
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    return om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                         tiny_step=tg.tiny_step, iter_cap=4000000, n_threads=0, **kw)
+
+
+def _same(r, ref, what):
+    assert r["total"] == ref["total"], what
+    assert np.array_equal(r["status"], ref["status"]), ("per-track status", what)
+    assert np.array_equal(r["offsets"], ref["offsets"]), ("segment counts", what)
+    assert np.array_equal(r["element"], ref["element"]), ("element ids", what)
+    for k in FIELDS:
+        assert np.array_equal(r[k], ref[k]), (k, what)
+
+
+def _both_modes(rt, orc, model, n_azim, delta, k=5):
+    tg = rt.TrackGenerator(model, n_azim, delta)
+    rt.trace(tg)
+    ref = _oracle(orc, tg, k=k)
+    on = hm.run(tg, k=k, walk=True)
+    off = hm.run(tg, k=k, walk=False)
+    _same(on, ref, "walk on")
+    _same(off, ref, "walk off")
+    assert off["stats"]["walk_emits"] == 0
+    return tg, ref, on
+
+
+@pytest.mark.parametrize("n_azim,delta", [(8, 2e-2), (32, 5e-3)])
+def test_pincell_walk_on_off_checker(rt, orc, pincell, n_azim, delta):
+    tg, ref, on = _both_modes(rt, orc, pincell, n_azim, delta)
+    s, info = on["stats"], on["info"]
+    assert info["walk_ok"] == 1 and info["records_walk"] == info["records"] - 160  # all but the 160 boundary-entry records
+    assert info["cells_fragile"] == 0 and info["cells_degenerate"] == 0
+    assert s["walk_emits"] >= 0.97 * ref["total"] - tg.n_total_tracks  # every track's first step is literal
+    print(f"pincell nφ={n_azim}: {ref['total']} segments, {s}")
+
+
+CASES = [("lattice", s) for s in range(4)] + [("lattice_far", s) for s in range(2)] + [("sliver", s) for s in range(4)] + \
+        [("sliver_fine", s) for s in range(4)] + [("random", s) for s in range(3)] + [("cluster", s) for s in range(3)]
+
+
+def _make(rt, kind, seed):
+    if kind == "lattice":
+        return meshgen.lattice_model(rt, 100 + seed, 10 + 3 * seed, 10 + 3 * seed, jitter=(0.1, 0.25, 0.4, 0.3)[seed]), 1.0
+    if kind == "lattice_far":
+        return meshgen.lattice_model(rt, 110 + seed, 12, 12, jitter=0.3, w=2.5, h=0.4, x0=(100.0, -1000.0)[seed], y0=50.0), 0.4
+    if kind == "sliver":
+        return meshgen.sliver_model(rt, 120 + seed, 9 + 2 * seed, 9 + 2 * seed, gap=(1e-2, 1e-3, 1e-4, 1e-4)[seed]), 1.0
+    if kind == "sliver_fine":
+        return meshgen.sliver_model(rt, 130 + seed, 8 + 2 * seed, 8 + 2 * seed, gap=(1e-5, 1e-6, 1e-7, 1e-6)[seed], x0=-3.25, y0=2.5), 1.0
+    if kind == "random":
+        return meshgen.random_model(rt, 140 + seed, 150 + 200 * seed), 1.0
+    return meshgen.random_model(rt, 150 + seed, 300 + 150 * seed, cluster=True), 1.0
+
+
+@pytest.mark.parametrize("kind,seed", CASES)
+def test_mesh_classes_walk_on_off_checker(rt, orc, kind, seed):
+    model, scale = _make(rt, kind, seed)
+    n_azim = (8, 16, 32, 4)[seed % 4]
+    tg, ref, on = _both_modes(rt, orc, model, n_azim, 0.01 * scale)
+    s, info = on["stats"], on["info"]
+    assert info["walk_ok"] == 1, "one bad cell must not switch the walk step off mesh-wide"
+    assert s["walk_emits"] > 0
+    frac = s["walk_emits"] / max(ref["total"], 1)
+    if kind == "lattice":
+        assert info["records_walk"] >= 0.85 * info["records"] and frac > 0.8, (info, s)
+    print(f"{kind} seed {seed}: {model.num_cells} cells, {ref['total']} segments, {frac:.1%} by the walk step, "
+          f"{int(info['records_walk'])}/{int(info['records'])} records walkable, eps ≤ {info['eps_max']:.1e}, "
+          f"{int(np.count_nonzero(ref['status']))} tracks on which the reference itself throws")
+
+
+@pytest.mark.parametrize("k", [1, 2, 8, 12, 40])
+def test_knn_width_any_k(rt, orc, k):
+    """find_element(mesh, x, k) takes any k (src/mesh.jl:123): wider than the in-register list (8) the node list is
+    streamed; on a sliver mesh the fallback is really used."""
+    model = meshgen.sliver_model(rt, 7, 10, 10, gap=1e-6)
+    tg, ref, on = _both_modes(rt, orc, model, 16, 0.01, k=k)
+    print(f"k={k}: {int(np.count_nonzero(ref['status'] == 1))} tracks fail to locate")
+
+
+def test_wider_k_locates_more(rt, orc):
+    """On a distorted mesh a wider k must rescue tracks (the reference's own advice, src/track.jl:141)."""
+    model = meshgen.random_model(rt, 18, 568)
+    tg = rt.TrackGenerator(model, 16, 0.01)
+    rt.trace(tg)
+    fails = {}
+    for k in (2, 5, 12, 40):
+        ref = _oracle(orc, tg, k=k)
+        _same(hm.run(tg, k=k, walk=True), ref, f"k={k}")
+        fails[k] = int(np.count_nonzero(ref["status"] == 1))
+    print("locate failures by k:", fails)
+    assert fails[40] <= fails[12] <= fails[5] <= fails[2]
+    assert fails[12] < fails[2]
+
+
+def test_nonmanifold_edge_is_not_crossed_but_walk_stays_on(rt, orc):
+    """An edge shared by three cells (a cell stacked on another): only those records are switched off."""
+    model = meshgen.lattice_model(rt, 3, 8, 8)
+    xy = model.node_coordinates
+    cells = np.asarray(model.cell_node_ids)
+    # an interior edge (a, b) of cell 40: shared with exactly one other cell
+    a, b, c = next((u, v, w) for u, v, w in (cells[40], cells[40][[1, 2, 0]], cells[40][[2, 0, 1]])
+                   if sum(1 for cc in cells if u in cc and v in cc) == 2)
+    # a third cell on edge (a, b): its apex is the centroid of cell 40 (it overlaps cell 40)
+    xy2 = np.vstack([xy, xy[[a - 1, b - 1, c - 1]].mean(axis=0)])
+    extra = np.sort(np.array([a, b, len(xy2)], np.int32))
+    model2 = rt.DiscreteModel(xy2, np.vstack([cells, extra]))
+    p = hm.prep(rt.Mesh(model2))
+    assert p["info"]["walk_ok"] == 1 and "more than two cells" in p["note"]
+    assert (p["epscode"][40] == -1).all(), "the overlapped cell must not be walked into"
+    tg = rt.TrackGenerator(model2, 8, 0.02)
+    rt.trace(tg)
+    ref = _oracle(orc, tg)
+    _same(hm.run(tg, walk=True), ref, "walk on")
+    _same(hm.run(tg, walk=False), ref, "walk off")
+
+
+def test_degenerate_cell_switches_off_its_neighbourhood_only(rt, orc):
+    model = meshgen.lattice_model(rt, 5, 10, 10)
+    xy = model.node_coordinates.copy()
+    cells = np.asarray(model.cell_node_ids)
+    a, b, c = cells[55]
+    xy[c - 1] = 0.5 * (xy[a - 1] + xy[b - 1])  # collapse cell 55 to a segment (its neighbours become distorted)
+    model2 = rt.DiscreteModel(xy, cells)
+    mesh = rt.Mesh(model2)
+    p = hm.prep(mesh)
+    assert p["info"]["cells_degenerate"] >= 1 and p["cls"][55] == 2
+    assert p["info"]["walk_ok"] == 1 and 0 < p["info"]["records_walk"] < p["info"]["records"]
+    off = (p["epscode"] == -1).all(axis=1)
+    assert off[55] and off.sum() < 0.5 * len(off), "only the neighbourhood of the degenerate cell is switched off"
+    tg = rt.TrackGenerator(model2, 8, 0.02)
+    rt.trace(tg)
+    ref = _oracle(orc, tg)
+    _same(hm.run(tg, walk=True), ref, "walk on")
+
+
+def test_record_limit_switches_walk_off(rt, pincell, monkeypatch):
+    """3·n_cells + 1 must fit the packed successor fields (2^27); mocked through the test knob."""
+    monkeypatch.setenv("RT_TEST_WALK_RECORD_LIMIT", "1000")
+    p = hm.prep(rt.Mesh(pincell))
+    assert p["info"]["walk_ok"] == 0 and p["info"]["records_walk"] == 0 and "too many cells" in p["note"]
+    monkeypatch.delenv("RT_TEST_WALK_RECORD_LIMIT")
+    assert hm.prep(rt.Mesh(pincell))["info"]["walk_ok"] == 1

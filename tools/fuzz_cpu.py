@@ -1,0 +1,90 @@
+"""Fuzz the walk step's certificates on the CPU: the device march's per-lane logic compiled for the host
+(tests/host_march.hip) with the walk step on and off, against the CPU checker, bit for bit, over seeded meshes
+of every shape class (tests/meshgen.py).  No GPU needed.
+usage: python tools/fuzz_cpu.py [first_seed] [count] [processes]   -> one line per mesh + a summary; exit 1 on mismatch"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def case(seed):
+    import raytracing_jl_amd as rt
+    import meshgen
+    rng = np.random.default_rng(seed * 104729 + 7)
+    kind = ["random", "cluster", "lattice", "sliver", "lattice_far", "sliver_fine"][seed % 6]
+    kw = dict(w=float(rng.choice([1.0, 0.3, 2.5, 7.0])), h=float(rng.choice([1.0, 0.4, 1.7])),
+              x0=float(rng.choice([0.0, -3.25, 11.0])), y0=float(rng.choice([0.0, 2.5, -0.75])))
+    if kind == "random":
+        model = meshgen.random_model(rt, seed, int(rng.integers(50, 2500)), nb=int(rng.choice([6, 12, 30])), **kw)
+    elif kind == "cluster":
+        model = meshgen.random_model(rt, seed, int(rng.integers(150, 2500)), nb=int(rng.choice([6, 12, 30])), cluster=True, **kw)
+    elif kind == "lattice":
+        n = int(rng.integers(6, 40))
+        model = meshgen.lattice_model(rt, seed, n, n, jitter=float(rng.choice([0.1, 0.25, 0.4])), **kw)
+    elif kind == "lattice_far":
+        n = int(rng.integers(6, 40))
+        kw.update(x0=float(rng.choice([100.0, -1000.0])), y0=float(rng.choice([50.0, 2000.0])))
+        model = meshgen.lattice_model(rt, seed, n, n, jitter=0.3, **kw)
+    elif kind == "sliver":
+        n = int(rng.integers(6, 30))
+        model = meshgen.sliver_model(rt, seed, n, n, gap=float(rng.choice([1e-2, 1e-3, 1e-4])), **kw)
+    else:
+        n = int(rng.integers(6, 30))
+        model = meshgen.sliver_model(rt, seed, n, n, gap=float(rng.choice([1e-5, 1e-6, 1e-7])), **kw)
+    n_azim = int(rng.choice([4, 8, 16, 32, 64, 256, 1024]))
+    delta = float(rng.choice([0.002, 0.004, 0.01])) * min(kw["w"], kw["h"]) * (4.0 if n_azim >= 256 else 1.0)
+    k = int(rng.choice([5, 5, 5, 2, 3, 8, 12, 1]))
+    return kind, model, n_azim, delta, k
+
+
+def run(seed):
+    import raytracing_jl_amd as rt
+    from oracle import oracle as orc
+    import hostmarch as hm
+    kind, model, n_azim, delta, k = case(seed)
+    tg = rt.TrackGenerator(model, n_azim, delta)
+    rt.trace(tg)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=False)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                        tiny_step=tg.tiny_step, k=k, iter_cap=4000000, n_threads=1)
+    res = {}
+    bad = []
+    for walk in (True, False):
+        r = hm.run(tg, k=k, walk=walk, n_threads=1)
+        ok = r["total"] == ref["total"] and np.array_equal(r["status"], ref["status"]) and np.array_equal(r["offsets"], ref["offsets"]) and \
+            np.array_equal(r["element"], ref["element"]) and all(np.array_equal(r[q], ref[q]) for q in ("px", "py", "qx", "qy", "ell"))
+        if not ok:
+            bad.append(walk)
+        res[walk] = r
+    s, info = res[True]["stats"], res[True]["info"]
+    line = ("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | records walkable %5d/%5d eps≤%.1e fragile %d degenerate %d | "
+            "walk emits %8d skips %6d generic emits %7d refused %6d%s" %
+            (seed, kind, model.num_cells, n_azim, k, tg.n_total_tracks, ref["total"], int(np.count_nonzero(ref["status"])),
+             int(info["records_walk"]), int(info["records"]), info["eps_max"], int(info["cells_fragile"]), int(info["cells_degenerate"]),
+             s["walk_emits"], s["walk_skips"], s["generic_emits"], s["refused"], ("  MISMATCH walk=%s" % bad) if bad else ""))
+    return seed, bool(bad), line, s["walk_emits"], ref["total"]
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+    procs = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    from oracle import oracle as orc
+    import hostmarch as hm
+    orc.build(); hm.build()
+    import multiprocessing as mp
+    t0 = time.time()
+    n_bad = 0; walk_total = 0; seg_total = 0
+    with mp.Pool(procs) as pool:
+        for seed, bad, line, we, tot in pool.imap_unordered(run, range(first, first + count)):
+            print(line, flush=True)
+            n_bad += bad; walk_total += we; seg_total += tot
+    print("done: %d meshes, %d mismatches, %d segments, %.1f %% of them by the walk step, %.0f s" %
+          (count, n_bad, seg_total, 100.0 * walk_total / max(seg_total, 1), time.time() - t0))
+    sys.exit(1 if n_bad else 0)
