@@ -91,10 +91,14 @@ def lib():
     L.rt_mesh_create.restype = _vp
     L.rt_mesh_create.argtypes = [C.c_int32, _dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp]
     L.rt_mesh_destroy.argtypes = [_vp]
-    L.rt_mesh_info.restype = C.c_int32
-    L.rt_mesh_info.argtypes = [_vp, _dp, C.c_int32, C.c_char_p, C.c_int32]
-    L.rt_last_stats.restype = C.c_int32
-    L.rt_last_stats.argtypes = [_vp, _lp, C.c_int32]
+    try:
+        L.rt_mesh_info.restype = C.c_int32
+        L.rt_mesh_info.argtypes = [_vp, _dp, C.c_int32, C.c_char_p, C.c_int32]
+        L.rt_last_stats.restype = C.c_int32
+        L.rt_last_stats.argtypes = [_vp, _lp, C.c_int32]
+    except AttributeError:
+        if not os.environ.get("RT_SEGMENTIZE_LIB"):  # development A/B against an older build (tools/ab.sh) only
+            raise
     L.rt_mesh_set_stream.restype = C.c_int32
     L.rt_mesh_set_stream.argtypes = [_vp, _vp]
     L.rt_mesh_get_stream.restype = _vp

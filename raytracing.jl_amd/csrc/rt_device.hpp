@@ -243,47 +243,12 @@ RT_HD __forceinline__ int32_t nearest_node(const DGeo &m, double qx, double qy) 
     return best_id == 0x7fffffff ? -1 : best_id;
 }
 
-// The node that follows (d2_prev, id_prev) in the (squared distance, id) order, other than `skip`; -1 when there is
-// none.  One exact ring search per call: the streaming form of knn for widths beyond the in-register list.
-RT_HD __noinline__ int32_t next_nearest_node(const DGeo &m, double qx, double qy, double d2_prev, int32_t id_prev,
-                                                  int32_t skip, double &d2_out) {
-    int ix, iy;
-    bucket_of(m, qx, qy, ix, iy);
-    double best = __builtin_huge_val();
-    int32_t best_id = 0x7fffffff;
-    const int rmax = m.gnx > m.gny ? m.gnx : m.gny;
-    for (int r = 0; r <= rmax; ++r) {
-        const int y0 = iy - r, y1 = iy + r;
-        for (int by = (y0 < 0 ? 0 : y0); by <= (y1 >= m.gny ? m.gny - 1 : y1); ++by) {
-            const int xl = ix - r < 0 ? 0 : ix - r, xr = ix + r >= m.gnx ? m.gnx - 1 : ix + r;
-            const bool full = (by == y0) || (by == y1);
-            for (int part = 0; part < (full ? 1 : 2); ++part) {
-                int b0, b1;
-                if (full) { b0 = by * m.gnx + xl; b1 = by * m.gnx + xr + 1; }
-                else {
-                    const int bx = part == 0 ? ix - r : ix + r;
-                    if (bx < 0 || bx >= m.gnx) continue;
-                    b0 = by * m.gnx + bx; b1 = b0 + 1;
-                }
-                for (int32_t s = m.gstart[b0]; s < m.gstart[b1]; ++s) {
-                    const int32_t id = m.gnode[s];
-                    if (id == skip) continue;
-                    const double dx = qx - m.x[id], dy = qy - m.y[id];
-                    const double d2 = dx * dx + dy * dy;
-                    if (node_before(d2_prev, id_prev, d2, id) && node_before(d2, id, best, best_id)) { best = d2; best_id = id; }
-                }
-            }
-        }
-        const double lb = ring_bound(m, qx, qy, ix, iy, r) - 1e-9 * m.gh;
-        if (lb == __builtin_huge_val()) break;
-        if (best_id != 0x7fffffff && lb > 0.0 && best < lb * lb) break;
-    }
-    d2_out = best;
-    return best_id == 0x7fffffff ? -1 : best_id;
-}
-
-// knn(kdtree, x, k, true, i -> i == skip): the k nearest nodes other than `skip`, ascending.
-RT_HD __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int k, int32_t skip, KBest &kb) {
+// knn(kdtree, x, k, true, i -> i == skip): the k nearest nodes other than `skip`, ascending.  AFTER: only nodes that
+// follow (d2_after, id_after) in the (squared distance, id) order — widths beyond the in-register list are served
+// in batches, the next kMaxK nodes after the last one of the previous batch.
+template <bool AFTER>
+RT_HD __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int k, int32_t skip, double d2_after,
+                                       int32_t id_after, KBest &kb) {
     kb.n = 0;
     kb.k = k > kMaxK ? kMaxK : k;  // (callers pass k <= kMaxK; wider searches stream, see find_element_fallback)
     if (kb.k <= 0) return;
@@ -307,7 +272,8 @@ RT_HD __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int 
                     const int32_t id = m.gnode[s];
                     if (id == skip) continue;
                     const double dx = qx - m.x[id], dy = qy - m.y[id];
-                    kbest_push(kb, dx * dx + dy * dy, id);
+                    const double d2 = dx * dx + dy * dy;
+                    if (!AFTER || node_before(d2_after, id_after, d2, id)) kbest_push(kb, d2, id);
                 }
             }
         }
@@ -329,24 +295,27 @@ RT_HD __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node,
 // followed, on failure, by find_element(mesh, xp, k) (src/track.jl:122,139).  The second
 // call repeats the first one's tests and then looks at nodes 3..k of the same sorted list,
 // so one sorted list of max(2,k) nodes serves both.
+// WIDEK (k > kMaxK; src/mesh.jl:123 takes any k): the same sorted node list, kMaxK nodes at a time.  A separate
+// instantiation, so that the march of the usual k keeps its register budget.
+template <bool WIDEK>
 RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double y, int k, int32_t nn_id) {
+    KBest kb;
     const int kk = k > 2 ? k : 2;
-    if (kk > kMaxK) {
-        // wide `k` (src/mesh.jl:123 takes any): the same sorted node list, produced one node at a time
+    if (WIDEK) {
         double d2p = -1.0;
         int32_t idp = -1;
-        for (int j = 0; j < kk; ++j) {
-            double d2;
-            const int32_t nd = next_nearest_node(m, x, y, d2p, idp, nn_id, d2);
-            if (nd < 0) break;
-            const int32_t c = first_cell_containing(m, nd, x, y);
-            if (c >= 0) return c;
-            d2p = d2; idp = nd;
+        for (int done = 0; done < kk; done += kMaxK) {
+            knearest_nodes<true>(m, x, y, kk - done < kMaxK ? kk - done : kMaxK, nn_id, d2p, idp, kb);
+            for (int j = 0; j < kb.n; ++j) {
+                const int32_t c = first_cell_containing(m, kb.id[j], x, y);
+                if (c >= 0) return c;
+            }
+            if (kb.n < kMaxK) break;  // no more nodes
+            d2p = kb.d2[kb.n - 1]; idp = kb.id[kb.n - 1];
         }
         return -1;
     }
-    KBest kb;
-    knearest_nodes(m, x, y, kk, nn_id, kb);
+    knearest_nodes<false>(m, x, y, kk, nn_id, -1.0, -1, kb);
     const int first = kb.n < 2 ? kb.n : 2;
     for (int j = 0; j < first; ++j) {
         const int32_t c = first_cell_containing(m, kb.id[j], x, y);
@@ -361,12 +330,13 @@ RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double
 }
 
 // find_element (src/mesh.jl:103-146), 0-based cell id or -1.
+template <bool WIDEK = false>
 RT_HD __forceinline__ int32_t find_element(const DGeo &m, double x, double y, int k) {
     const int32_t nn_id = nearest_node(m, x, y);
     if (nn_id < 0) return -1;
     const int32_t c = first_cell_containing(m, nn_id, x, y);
     if (c >= 0) return c;
-    return find_element_fallback(m, x, y, k, nn_id);
+    return find_element_fallback<WIDEK>(m, x, y, k, nn_id);
 }
 
 // ------------------------------------------------------- intersections -------------------
@@ -462,9 +432,10 @@ struct GenericOut {
     double px, py, qx, qy, ell;
     int32_t element, eq;
 };
+template <bool WIDEK>
 RT_HD __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
                                          double tA, double tB, double tC, GenericOut &o) {
-    const int32_t element = find_element(m, xpx, xpy, k);  // src/track.jl:122 and :138-139
+    const int32_t element = find_element<WIDEK>(m, xpx, xpy, k);  // src/track.jl:122 and :138-139
     o.element = element;
     if (element < 0) return 2;
     if (element == prev_element) return 1;  // :147-150
@@ -478,9 +449,10 @@ RT_HD __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k
 
 // Does the reference's iteration at xp end in a tiny step (`continue` at src/track.jl:147-150 or :156-159)?
 // False when it emits a segment or fails to locate / intersect.  Used by the cooperative creep of k_march.
+template <bool WIDEK>
 RT_HD __noinline__ bool generic_tiny_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element,
                                                double phi, double tA, double tB, double tC) {
-    const int32_t element = find_element(m, xpx, xpy, k);
+    const int32_t element = find_element<WIDEK>(m, xpx, xpy, k);
     if (element < 0) return false;
     if (element == prev_element) return true;
     double px, py, qx, qy;
@@ -567,33 +539,56 @@ RT_HD __forceinline__ bool rec_same(uint64_t hdr) { return (hdr >> 63) != 0; }
 // edge's general form), and `w` is advanced to the new cell.  On kWalkSkip the reference takes
 // its `prev_element == element` branch (src/track.jl:147-150).  kWalkGeneric: no decision.
 // `kk` = min(max(k, 2), 14): the node window of find_element(xp) followed by find_element(xp, k);
-// `fwd` = ϕ < π/2 (order_intersection_points, src/intersection.jl:151-159).
+// `phi` = ϕ, for order_intersection_points (src/intersection.jl:151-159).
 // Written straight-line (all certificates are folded into one predicate; a lane without a
 // prediction reads record 0 and is masked out) except for the rare exact shallow-crossing test:
 // on a 64-wide wave, selects are cheaper than divergent early exits.
-RT_HD __forceinline__ bool shallow_T_first(const Walk &w, double numT, double x2, double y2, int32_t Tn, double xpx,
-                                                double xpy, bool &tie) {
-    // T still passes the reference's barycentric test at xp iff all three λ, exactly as point_in_triangle
-    // evaluates them (src/mesh.jl:166-174; a, b, c are a cyclic rotation of the cell's nodes, which maps the
-    // three closed forms onto each other), lie in [0 - √eps, 1 + √eps]
-    const double lo = 0.0 - kRtolDefault, hi = 1.0 + kRtolDefault;
-    const double lc = numT / w.dT;
-    const double la = ((w.by - w.cy) * xpx + (w.cx - w.bx) * xpy + (w.bx * w.cy - w.cx * w.by)) / w.dT;
-    const double lb = ((w.cy - w.ay) * xpx + (w.ax - w.cx) * xpy + (w.cx * w.ay - w.ax * w.cy)) / w.dT;
-    tie = false;
-    if (!((lo <= lc && lc <= hi) && (lo <= la && la <= hi) && (lo <= lb && lb <= hi))) return false;
-    // scan order of find_element: nearest of {a, b, c, c'}; T is met before T' iff that is c,
-    // or it is a or b and T < T' (node -> cells lists ascend in cell id)
+// Is fl(num / d) inside [0 - √eps, 1 + √eps] (src/mesh.jl:171-174)?  The quotient is within one rounding of num/d, so
+// away from the two thresholds the answer follows from products and compares; next to a threshold (a band of relative
+// width 1e-12 below -√eps; anything above 1) the division itself decides — practically never, in a cold branch.
+// r = num·sign(d), ad = |d|: num/d = r/ad bit for bit.
+constexpr double kLamLoOut = -kRtolDefault * (1.0 + 1e-12);  // r < kLamLoOut·ad  =>  fl(r/ad) < -√eps
+constexpr double kLamLoIn = -kRtolDefault * (1.0 - 1e-12);   // kLamLoIn·ad <= r <= ad  =>  inside
+RT_HD __forceinline__ bool lambda_exact(double num, double d) {
+    const double l = num / d;
+    return (0.0 - kRtolDefault) <= l && l <= (1.0 + kRtolDefault);
+}
+// λ expected well inside (0, 1): inside for sure when 0 <= r <= ad
+RT_HD __forceinline__ bool lambda_inner_in_range(double num, double d, double ad) {
+    const double r = d > 0 ? num : -num;
+    bool in = r >= 0.0 && r <= ad && ad > 0.0;
+    if (__builtin_expect(!in, 0)) {
+        asm volatile("" ::: "memory");  // a real, cold branch
+        in = lambda_exact(num, d);
+    }
+    return in;
+}
+
+// The shallow crossing: T still passes the reference's barycentric test at xp iff all three λ, exactly as
+// point_in_triangle evaluates them (src/mesh.jl:166-174; a, b, c are a cyclic rotation of the cell's nodes, which maps
+// the three closed forms onto each other), lie in [0 - √eps, 1 + √eps]; rT / adT: the first one's numerator and
+// denominator, known not to be surely below -√eps.  Then the scan order of find_element: nearest of {a, b, c, c'}; T is
+// met before T' iff that is c, or it is a or b and T < T' (node -> cells lists ascend in cell id).
+RT_HD __forceinline__ bool shallow_T_first(const Walk &w, double numT, double rT, double adT, double x2, double y2, int32_t Tn,
+                                           double xpx, double xpy, bool &tie) {
+    bool pass = rT >= kLamLoIn * adT && rT <= adT && adT > 0.0;
+    if (__builtin_expect(!pass, 0)) {
+        asm volatile("" ::: "memory");  // a real, cold branch
+        pass = lambda_exact(numT, w.dT);
+    }
+    const double numA = (w.by - w.cy) * xpx + (w.cx - w.bx) * xpy + (w.bx * w.cy - w.cx * w.by);
+    const double numB = (w.cy - w.ay) * xpx + (w.ax - w.cx) * xpy + (w.cx * w.ay - w.ax * w.cy);
+    pass = pass && lambda_inner_in_range(numA, w.dT, adT) && lambda_inner_in_range(numB, w.dT, adT);
     const double da = (xpx - w.ax) * (xpx - w.ax) + (xpy - w.ay) * (xpy - w.ay);
     const double db = (xpx - w.bx) * (xpx - w.bx) + (xpy - w.by) * (xpy - w.by);
     const double dc = (xpx - w.cx) * (xpx - w.cx) + (xpy - w.cy) * (xpy - w.cy);
     const double dcp = (xpx - x2) * (xpx - x2) + (xpy - y2) * (xpy - y2);
     const double dab = da < db ? da : db;
-    tie = dc == dab || dcp == dab || dc == dcp;  // exactly equidistant nodes: generic step
-    return (dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn);
+    tie = pass && (dc == dab || dcp == dab || dc == dcp);  // exactly equidistant nodes: generic step
+    return pass && ((dc < dab && dc < dcp) || (dab < dc && dab < dcp && w.T < Tn));
 }
 
-RT_HD __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, bool fwd, double tA, double tB,
+RT_HD __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, int kk, double phi, double tA, double tB,
                                          double tC, double xpx, double xpy, double ppx, double ppy, double &qx,
                                          double &qy, double &ell) {
     const bool has = m.walk_ok && w.pred >= 0;
@@ -631,17 +626,17 @@ RT_HD __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, 
     ok = ok && ell >= m.l_min;
     // order_intersection_points (src/intersection.jl:151-159) compares the two x coordinates: the entry point stays
     // the entry point only if it is strictly on the expected side (near ϕ = π/2 rounding may decide otherwise)
-    ok = ok && (fwd ? ppx < qx : ppx > qx);
+    ok = ok && (phi < kHalfPi ? ppx < qx : ppx > qx);
     // --- shallow crossing: does T still pass the reference's barycentric test at xp?  λ of T for the
-    //     vertex opposite its exit edge, exactly as point_in_triangle evaluates it (src/mesh.jl:166-168);
-    //     the divisions are skipped when that quotient is clearly below -√eps
+    //     vertex opposite its exit edge (src/mesh.jl:166-168) is below -√eps for all but the flattest ≈3 % of
+    //     crossings; for those the other two λ and the scan order of find_element decide
     const double numT = (w.ay - w.by) * xpx + (w.bx - w.ax) * xpy + (w.ax * w.by - w.bx * w.ay);
-    const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
+    const double adT = fabs(w.dT), rT = w.dT > 0 ? numT : -numT;
     int res = ok ? kWalkEmit : kWalkGeneric;
-    if (ok && !clearly_out) {
-        asm volatile("" ::: "memory");  // a real branch: hoisted, the divisions run on every iteration for nothing
+    if (ok && !(rT < kLamLoOut * adT)) {
+        asm volatile("" ::: "memory");  // a real branch
         bool tie;
-        const bool t_first = shallow_T_first(w, numT, x2, y2, Tn, xpx, xpy, tie);
+        const bool t_first = shallow_T_first(w, numT, rT, adT, x2, y2, Tn, xpx, xpy, tie);
         res = tie ? kWalkGeneric : (t_first ? kWalkSkip : kWalkEmit);
     }
     // --- advance the state to T' (only when emitting)
@@ -677,10 +672,10 @@ RT_HD __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const 
     const double eps_aa = rec_eps(nr.hdr) * aa;
     if (!(c0 >= -0.25 * kRtolDefault * aa && c1 >= eps_aa && c2 >= eps_aa)) return false;
     const double numT = (w.ay - w.by) * xpx + (w.bx - w.ax) * xpy + (w.ax * w.by - w.bx * w.ay);
-    const bool clearly_out = (numT > 0) != (w.dT > 0) && fabs(numT) > 4.0 * kRtolDefault * fabs(w.dT);
-    if (clearly_out) return false;
+    const double adT = fabs(w.dT), rT = w.dT > 0 ? numT : -numT;
+    if (rT < kLamLoOut * adT) return false;
     bool tie;
-    const bool t_first = shallow_T_first(w, numT, x2, y2, (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u), xpx, xpy, tie);
+    const bool t_first = shallow_T_first(w, numT, rT, adT, x2, y2, (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u), xpx, xpy, tie);
     return !tie && t_first;
 }
 

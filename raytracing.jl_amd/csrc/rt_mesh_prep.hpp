@@ -219,11 +219,17 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
     P.kappa = area > 0 ? perim / (3.141592653589793 * area) : 0.0;
     if (wild.size() > 4096) { P.walk_ok = false; P.note = "too many degenerate cells for the walk certificates"; }
     {
-        // The track line must clear a cell's vertices by d_vertex: 100x the slack of point_in_segment (src/segment.jl:39-44,
-        // ≈0.75e-8·|edge| beyond an endpoint) and 100x the rounding error of the computed intersection point, which grows
-        // like 1/sin(track, edge) ≤ |edge| / (2 d_vertex): err ≈ 7.5e-16·|far corner|·|edge|/d_vertex.
+        // The track line must clear every vertex of the cell by d_vertex.  What depends on it:
+        //  * the edge the line misses is rejected by point_in_segment (src/segment.jl:39-44), which accepts hits up to
+        //    0.75e-8·|edge| beyond an endpoint — the miss is at least d_vertex beyond it, whatever the angle;
+        //  * the two crossed edges are not "parallel" to the track (isapprox(a, b), src/intersection.jl:128-131, fires
+        //    below sin ≈ 1.5e-8): endpoints on opposite sides at ≥ d_vertex give sin ≥ 2·d_vertex/|edge|;
+        //  * rounding of the computed intersection points (≈1.5e-15·|far corner| / sin) is 1e7 times below the distance of
+        //    a crossing from the edge's endpoints (≥ d_vertex / sin) — added here in absolute terms as well.
+        // 2e-7·l_max keeps a factor ≥ 13 over both tolerances (the walk step's refusals cost a full literal step each:
+        // 1e-6·l_max refused 5x as often and cost the march 4 % at the headline configuration).
         const double corner = std::hypot(cmax_x, cmax_y);
-        P.d_vertex = std::max(1e-6 * l_max, 3e-7 * std::sqrt(corner * l_max));
+        P.d_vertex = std::max(2e-7 * l_max, 1e-9 * corner);
         // chords shorter than this go to the generic step (the reference's isapprox(p, q) skip,
         // src/track.jl:156, triggers below ~1.5e-8 * |p|)
         P.l_min = std::max(1e-6 * l_max, 8.0 * kTol * corner);

@@ -148,6 +148,7 @@ struct DSplit {
     int32_t n_vwaves;
 };
 
+template <bool WIDEK>
 __global__ __launch_bounds__(64) void k_seed(DMesh m, DTracks t, DParams prm, DSplit sp) {
     const int32_t cv = blockIdx.x;
     const int32_t k = sp.vw_k[cv];
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) void k_seed(DMesh m, DTracks t, DParams prm, DS
     go.eq = -1;
     if (!inboundary(m, mx, my, prm.tiny_step)) {
         const DGeo g = load_geo(m.geo);
-        const int rc = generic_step(g, mx, my, prm.k, -1, t.phi[u], t.A[u], t.B[u], t.C[u], go);
+        const int rc = generic_step<WIDEK>(g, mx, my, prm.k, -1, t.phi[u], t.A[u], t.B[u], t.C[u], go);
         // Any genuine segment of the track near M will do: whether the march really produces it is
         // checked bit for bit by the piece that arrives there (k_march), not assumed here.
         if (rc == 0 && go.eq >= 0 && go.ell >= m.l_min) el = go.element;
@@ -265,7 +266,9 @@ __device__ __forceinline__ const RT_K DStage *march_stage_args() {
     return (const RT_K DStage *)(ka + offsetof(MarchArgsLayout, stg));
 }
 
-template <int MODE, int WAVES, bool SPLIT>
+// WIDEK: k > kMaxK (the knn fallback of find_element serves its node list in batches); a separate instantiation, so that
+// the march of the usual k keeps its register budget.
+template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false>
 __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         // the argument-segment view of `stg` must be the argument itself (guards MarchArgsLayout against drift:
         // a mismatch voids the attempt the way a pool overflow does, and the host reports it)
         const RT_K DStage *sk = march_stage_args();
-        if (sk->cursor != stg.cursor || sk->qx != stg.qx || sk->element != stg.element || sk->pool_chunks != stg.pool_chunks) {
+        if (sk->cursor != stg.cursor || sk->qx != stg.qx || sk->element != stg.element || sk->pool_chunks != stg.pool_chunks ||
+            *(unsigned long long *const RT_K *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, fail_info)) != fail_info) {
             if (threadIdx.x == 0) stg.cursor[1] = 2;
             return;
         }
@@ -352,7 +356,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
     // node window of find_element(xp) then find_element(xp, k) as the walk records count it (extras field: 0..14, 15 = never)
     const int kk = prm.k > 2 ? (prm.k < rt::kExtrasNever - 1 ? prm.k : rt::kExtrasNever - 1) : 2;
-    const bool fwd = phi < kHalfPi;  // order_intersection_points, src/intersection.jl:153
     double lqx = 0.0, lqy = 0.0;  // exit point of the last emitted segment
     // The walk step's mesh constants, held in VGPRs: as SGPRs they share a tuple of the argument load that the
     // register allocator spills as a whole and reloads (8 v_readlane) several times per iteration.
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         } else {
         // The reference locates first and tests the boundary second (:122-125); the locate
         // result is unused on both boundary branches, so the order is swapped here.
-        if (inboundary(m, xpx, xpy, prm.tiny_step)) {  // :125
+        if (__builtin_expect(inboundary(m, xpx, xpy, prm.tiny_step), 0)) {  // :125
             if (i == 0) {
                 xpx = xpx + sx; xpy = xpy + sy;
                 continue;  // :126-129
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         const unsigned long long tB_ = rt_tick(RT_TIMING == 2 ? nr.e2C : xpx);
         tacc0 += tB_ - tA_;
 #endif
-        res = walk_step(mh, wk, nr, kk, fwd, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+        res = walk_step(mh, wk, nr, kk, phi, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
 #ifdef RT_TIMING
         tC_ = rt_tick(ell + (double)res);
         tacc1 += tC_ - tB_;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         if (MODE != kFill && !SPLIT) atomicAdd(&fail_info[2 + res], 1ull);
 #endif
         if (res != kWalkGeneric) creep_run = 0;
-        if (res == kWalkSkip) {  // :147-150
+        if (__builtin_expect(res == kWalkSkip, 0)) {  // :147-150
             xpx = xpx + sx; xpy = xpy + sy;
             // creep on while the reference would keep locating T: each pass stands for one more march
             // iteration that ends in the same `continue`
@@ -444,9 +447,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
 #ifdef RT_TIMING
         if (__ballot(res == kWalkGeneric)) ++wgen;
 #endif
-        if (res == kWalkGeneric) {
+        if (__builtin_expect(res == kWalkGeneric, 0)) {
             const DGeo g = load_geo(m.geo);  // scalar loads, here only: the generic step's pointers and grid parameters
-            element = find_element(g, xpx, xpy, prm.k);               // :122 and :138-139
+            element = find_element<WIDEK>(g, xpx, xpy, prm.k);        // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
             // Creep: a track that leaves a cell at a very small angle next to a vertex takes hundreds of tiny
             // steps here (BWR-like config 4: 229 in a row through a 7e-8 sliver), each a full locate by one
@@ -470,8 +473,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
             if (MODE != kFill) {
                 // per-call statistic (rt_last_stats): records the generic step produced — the walk step made the rest
+                // (the control block's address is read from the argument segment here, not held across the loop)
                 const unsigned long long act = __ballot(1);
-                if (lane == __ffsll((long long)act) - 1) atomicAdd(&fail_info[15], (unsigned long long)__popcll(act));
+                if (lane == __ffsll((long long)act) - 1)
+                    atomicAdd(*(unsigned long long *const RT_K *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                                  offsetof(MarchArgsLayout, fail_info)) + 15,
+                              (unsigned long long)__popcll(act));
             }
             if (m.walk_ok && eq >= 0) walk_enter(m, g, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             if (out.fused_volumes) unsafeAtomicAdd((double *)&out.volumes[element], w * ell);  // src/trackgenerator.jl:382
         } else if (MODE == kStage) {
             const int r = i & (kChunkRows - 1);
-            if (r == 0) {
+            if (__builtin_expect(r == 0, 0)) {
                 // First row of a new chunk for this lane: wave-aggregated allocation among the
                 // lanes that are here.  chunk_lds[j] caches what the wave already owns.
                 const int j = i >> kChunkLog2;
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 const bool derived = res == kWalkEmit && !from_seed;
                 row_qx[r * 16] = qx; row_qy[r * 16] = qy;
                 row_el[r * 16] = derived ? element + 1 : -(element + 1);
-                if (!derived) {
+                if (__builtin_expect(!derived, 0)) {
                     const int64_t o = stage_slot(my_chunk, r, lane);
                     const RT_K DStage *sk = march_stage_args();
                     sk->px[o] = px; sk->py[o] = py;
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
                 for (int a = 0; a < 63; ++a)
                     if (a < lane) { cx = cx + l_sx; cy = cy + l_sy; }
                 const bool ok = !inboundary(m, cx, cy, prm.tiny_step) &&
-                                generic_tiny_step(g, cx, cy, prm.k, l_prev, l_phi, l_tA, l_tB, l_tC);
+                                generic_tiny_step<WIDEK>(g, cx, cy, prm.k, l_prev, l_phi, l_tA, l_tB, l_tC);
                 const unsigned long long okm = __ballot(ok);
                 int n_ok = okm == ~0ull ? 64 : __ffsll((long long)~okm) - 1;  // leading positions at which the reference steps on
                 const int allowed = cap - l_it;                              // it < cap, one count per step
@@ -1453,6 +1460,15 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         return RT_SUCCESS;
     };
 
+    const bool widek = k > rt::kMaxK;  // find_element's knn fallback beyond the in-register list: separate kernel instantiations
+    const int64_t *march_offsets = nullptr;
+    auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK>(unsigned blocks, size_t smem) -> int {
+        if (smem > 48 * 1024)
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK>), dim3(blocks), dim3(64 * WAVES), smem, s, m->d, t->d, prm, t->counts.p,
+                           t->status.p, march_offsets, out, stg, d_fail, sp);
+        return RT_SUCCESS;
+    };
     if (!m->single_pass) RT_HIP(hipEventRecord(t->ev[0], s));  // single pass: the call is timed from ev[1], after the 2-µs prologue
     if (!m->single_pass) RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
     if (m->single_pass) {
@@ -1472,7 +1488,8 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         //  +5 % on one that takes many rounds, C5 on one GPU)
         const int fuse_waves = (3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || n_waves > 3072) ? 4 : 6;
         const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
-        const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024;
+        // (a wide k marches with the one-wave kernels only: fewer instantiations of a rare case)
+        const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024 && !widek;
         fused_volumes_this_call = fuse;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
@@ -1498,45 +1515,23 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                                t->volumes.p, m->n_cells);
             RT_HIP(hipEventRecord(t->ev[1], s));
             if (n > 0 && split) {
-                hipLaunchKernelGGL(rt::k_seed, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
-                if (fuse && fuse_waves == 4) {
-                    if (fuse_smem > 48 * 1024)
-                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4, true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 4, true>), dim3((unsigned)((t->n_vwaves + 3) / 4)), dim3(256), fuse_smem, s,
-                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
-                } else if (fuse) {
-                    if (fuse_smem > 48 * 1024)
-                        RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 6, true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 6, true>), dim3((unsigned)((t->n_vwaves + 5) / 6)), dim3(384), fuse_smem, s,
-                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
-                } else {
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, true>), dim3((unsigned)t->n_vwaves), dim3(64),
-                                       rt::kMaxChunks * sizeof(int32_t), s, m->d, t->d, prm, t->counts.p, t->status.p,
-                                       (const int64_t *)nullptr, out, stg, d_fail, sp);
-                }
+                if (widek) hipLaunchKernelGGL(rt::k_seed<true>, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
+                else hipLaunchKernelGGL(rt::k_seed<false>, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
+                int rc;
+                if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, true, false>((unsigned)((t->n_vwaves + 3) / 4), fuse_smem);
+                else if (fuse) rc = march.template operator()<rt::kStage, 6, true, false>((unsigned)((t->n_vwaves + 5) / 6), fuse_smem);
+                else if (widek) rc = march.template operator()<rt::kStage, 1, true, true>((unsigned)t->n_vwaves, rt::kMaxChunks * sizeof(int32_t));
+                else rc = march.template operator()<rt::kStage, 1, true, false>((unsigned)t->n_vwaves, rt::kMaxChunks * sizeof(int32_t));
+                if (rc) return rc;
                 hipLaunchKernelGGL(rt::k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t->d, prm, sp, t->counts.p,
                                    t->status.p, d_fail);
             } else if (n > 0) {
-                if (fuse) {
-                    if (fuse_waves == 4) {
-                        if (fuse_smem > 48 * 1024)
-                            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 4, false>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
-                        hipLaunchKernelGGL((rt::k_march<rt::kStage, 4, false>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), fuse_smem, s,
-                                           m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
-                    } else {
-                        if (fuse_smem > 48 * 1024)
-                            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<rt::kStage, 6, false>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_smem));
-                        hipLaunchKernelGGL((rt::k_march<rt::kStage, 6, false>), dim3((unsigned)((n_waves + 5) / 6)), dim3(384), fuse_smem, s,
-                                           m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
-                    }
-                } else {
-                    hipLaunchKernelGGL((rt::k_march<rt::kStage, 1, false>), dim3(grid), dim3(64), rt::kMaxChunks * sizeof(int32_t), s,
-                                       m->d, t->d, prm, t->counts.p, t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
-                }
+                int rc;
+                if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, false, false>((unsigned)((n_waves + 3) / 4), fuse_smem);
+                else if (fuse) rc = march.template operator()<rt::kStage, 6, false, false>((unsigned)((n_waves + 5) / 6), fuse_smem);
+                else if (widek) rc = march.template operator()<rt::kStage, 1, false, true>(grid, rt::kMaxChunks * sizeof(int32_t));
+                else rc = march.template operator()<rt::kStage, 1, false, false>(grid, rt::kMaxChunks * sizeof(int32_t));
+                if (rc) return rc;
             }
             RT_HIP(hipEventRecord(t->ev[2], s));
             if (int rc = scan_counts(true, fuse)) return rc;
@@ -1574,9 +1569,10 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     } else {
         RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         RT_HIP(hipEventRecord(t->ev[1], s));
-        if (n > 0)
-            hipLaunchKernelGGL((rt::k_march<rt::kCount, 1, false>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
-                               t->status.p, (const int64_t *)nullptr, out, stg, d_fail, sp);
+        if (n > 0) {
+            if (int rc = widek ? march.template operator()<rt::kCount, 1, false, true>(grid, sizeof(int32_t))
+                               : march.template operator()<rt::kCount, 1, false, false>(grid, sizeof(int32_t))) return rc;
+        }
         RT_HIP(hipEventRecord(t->ev[2], s));
         if (int rc = scan_counts(false, false)) return rc;
         RT_HIP(hipEventRecord(t->ev[3], s));
@@ -1587,9 +1583,11 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
         memcpy(&total, h_res + 16, sizeof(total));
         if (int rc = reserve_out(total)) return rc;
         RT_HIP(hipEventRecord(t->ev[4], s));
-        if (n > 0)
-            hipLaunchKernelGGL((rt::k_march<rt::kFill, 1, false>), dim3(grid), dim3(64), sizeof(int32_t), s, m->d, t->d, prm, t->counts.p,
-                               t->status.p, (const int64_t *)t->offsets.p, out, stg, d_fail, sp);
+        if (n > 0) {
+            march_offsets = t->offsets.p;
+            if (int rc = widek ? march.template operator()<rt::kFill, 1, false, true>(grid, sizeof(int32_t))
+                               : march.template operator()<rt::kFill, 1, false, false>(grid, sizeof(int32_t))) return rc;
+        }
         RT_HIP(hipEventRecord(t->ev[5], s));
         if (int rc = launch_volumes()) return rc;
         RT_HIP(hipEventRecord(t->ev[6], s));

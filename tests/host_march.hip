@@ -33,6 +33,37 @@ struct Result {
 };
 Result g_res;
 
+// Why did walk_step refuse?  Re-evaluates its sub-certificates (development statistics only).
+// reasons: 0 record off / extras, 1 vertex clearance, 2 entry edge not crossed, 3 isolation margin (c1/c2), 4 entry side (c0),
+// 5 short chord, 6 order, 7 tie / other
+int refusal_reason(const rt::DMesh &m, const rt::Walk &w, const rt::NextRec &nr, int kk, double phi, double tA, double tB, double tC,
+                   double xpx, double xpy, double ppx, double ppy) {
+    using namespace rt;
+    if (rec_extras(nr.hdr) > kk) return 0;
+    const bool same = rec_same(nr.hdr);
+    const double x0 = same ? w.ax : w.bx, y0 = same ? w.ay : w.by, x1 = same ? w.bx : w.ax, y1 = same ? w.by : w.ay;
+    const double x2 = nr.x2, y2 = nr.y2;
+    const double s0 = tA * x0 + tB * y0 + tC, s1 = tA * x1 + tB * y1 + tC, s2 = tA * x2 + tB * y2 + tC;
+    if (!(fabs(s0) >= m.d_vertex && fabs(s1) >= m.d_vertex && fabs(s2) >= m.d_vertex)) return 1;
+    if ((s0 > 0) == (s1 > 0)) return 2;
+    const bool exit1 = (s1 > 0) != (s2 > 0);
+    const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    const double sg = area2 > 0 ? 1.0 : -1.0, aa = fabs(area2);
+    const double c0 = sg * ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0));
+    const double c1 = sg * ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1));
+    const double c2 = sg * ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2));
+    const double eps_aa = rec_eps(nr.hdr) * aa;
+    if (!(c1 >= eps_aa && c2 >= eps_aa)) return 3;
+    if (!(c0 >= -0.25 * kRtolDefault * aa)) return 4;
+    const double eA = exit1 ? nr.e1A : nr.e2A, eB = exit1 ? nr.e1B : nr.e2B, eC = exit1 ? nr.e1C : nr.e2C;
+    const double det = tB * eA - eB * tA;
+    const double qx = (tC * eB - eC * tB) / det, qy = (tA * eC - eA * tC) / det;
+    if (!(norm2(ppx - qx, ppy - qy) >= m.l_min)) return 5;
+    if (!(phi < kHalfPi ? ppx < qx : ppx > qx)) return 6;
+    return 7;
+}
+int64_t g_reasons[8];
+
 // counters: [0] walk emits, [1] walk skips (incl. creep passes), [2] generic emits, [3] generic iterations in total,
 // [4] generic iterations taken although a prediction existed (a certificate refused)
 void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, double phi, double cs, double sn, double tA,
@@ -50,7 +81,6 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
     wk.T = -1; wk.pred = -1;
     wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
     const int kk = k > 2 ? (k < kExtrasNever - 1 ? k : kExtrasNever - 1) : 2;
-    const bool fwd = phi < kHalfPi;
     double lqx = 0.0, lqy = 0.0;
     NextRec nr;
     while (st == 0 && inboundary(m, xpx, xpy, tiny)) {  // start band
@@ -66,7 +96,7 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
             break;
         }
         load_next(m, wk.pred, nr);
-        int res = walk_step(m, wk, nr, kk, fwd, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
+        int res = walk_step(m, wk, nr, kk, phi, tA, tB, tC, xpx, xpy, lqx, lqy, qx, qy, ell);
         if (res == kWalkSkip) {
             ++cnt[1];
             xpx = xpx + sx; xpy = xpy + sy;
@@ -79,8 +109,11 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
         px = lqx; py = lqy; element = wk.T;
         if (res == kWalkGeneric) {
             ++cnt[3];
-            if (m.walk_ok && wk.pred >= 0) ++cnt[4];
-            element = find_element(g, xpx, xpy, k);
+            if (m.walk_ok && wk.pred >= 0) {
+                ++cnt[4];
+                __atomic_fetch_add(&g_reasons[refusal_reason(m, wk, nr, kk, phi, tA, tB, tC, xpx, xpy, lqx, lqy)], 1, __ATOMIC_RELAXED);
+            }
+            element = k > kMaxK ? find_element<true>(g, xpx, xpy, k) : find_element<false>(g, xpx, xpy, k);
             if (element < 0) { st = 1; break; }
             if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }
             int eq;
@@ -163,6 +196,10 @@ int64_t hostmarch_run(const double *x, const double *y, int32_t n_nodes, const i
         for (int j = 0; j < 8; ++j) g_res.stats[j] += cnt[t][j];
     }
     return (int64_t)g_res.recs.size();
+}
+
+void hostmarch_reasons(int64_t *out, int32_t reset) {
+    for (int i = 0; i < 8; ++i) { out[i] = g_reasons[i]; if (reset) g_reasons[i] = 0; }
 }
 
 void hostmarch_fetch(int64_t *offsets, int32_t *status, double *px, double *py, double *qx, double *qy, double *ell,

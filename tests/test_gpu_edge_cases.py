@@ -30,11 +30,29 @@ def _same(tg, ref, check_volumes=True):
         assert np.allclose(tg.volumes, ref["volumes"], rtol=1e-10, atol=1e-300)
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 8])
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 8, 12, 40])
 def test_knn_width(rt, orc, traced, k):
     tg = traced(16, 0.02)
     rt.segmentize(tg, k=k, check=False)
     _same(tg, _oracle(orc, tg, k=k))
+
+
+@pytest.mark.parametrize("k", [2, 5, 12, 40])
+def test_knn_width_on_a_distorted_mesh(rt, orc, k):
+    """find_element(mesh, x, k) takes any k (src/mesh.jl:123); on this random Delaunay mesh the reference fails to
+    locate on many tracks with k = 2 and on fewer with a wider search — the device must follow for every k (beyond
+    the 8-entry in-register list the node list is streamed), with the walk step on and off."""
+    import meshgen
+
+    model = meshgen.random_model(rt, 18, 568)
+    tg = rt.TrackGenerator(model, 16, 0.01)
+    rt.trace(tg)
+    ref = _oracle(orc, tg, k=k)
+    for walk in (True, False):
+        rt.segmentize(tg, k=k, check=False, walk=walk)
+        _same(tg, ref)
+    print(f"k={k}: {int(np.count_nonzero(ref['status'] == 1))} of {tg.n_total_tracks} tracks fail to locate; "
+          f"regime {tg.device_mesh.info()}")
 
 
 @pytest.mark.parametrize("tiny", [1e-7, 1e-9])
@@ -195,6 +213,16 @@ def test_bad_arguments_are_refused_not_launched(rt, traced):
         dm.set_option("no_such_option", 1)
     L = _capi.lib()
     assert L.rt_segmentize(None, 1e-8, 5, 1e-8, None, 4) < 0 and b"bad arguments" in L.rt_last_error()
+    # k < 0: NearestNeighbors' knn throws; azim_idx must index delta_s (fill_volumes reads it on the device)
+    aq = tg.azimuthal_quadrature
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    with pytest.raises(_capi.RtError, match="k = -1"):
+        dt.segmentize(tg.tiny_step, -1, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    with pytest.raises(_capi.RtError, match="azim_idx reaches"):
+        dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s[:1], 1)
+    with pytest.raises(_capi.RtError, match="1-based"):
+        _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx - 1)
+    assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) > 0  # the handle is still good
     cells = np.asarray(tg.mesh.cell_nodes).copy()
     cells[0, 0] = tg.mesh.num_nodes + 5  # out-of-range node id
     bad = rt.Mesh.__new__(rt.Mesh)

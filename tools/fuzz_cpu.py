@@ -77,7 +77,11 @@ if __name__ == "__main__":
     procs = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     from oracle import oracle as orc
     import hostmarch as hm
-    orc.build(); hm.build()
+    orc.build()
+    import shutil, tempfile
+    private = os.path.join(tempfile.mkdtemp(prefix="fuzz_cpu_"), "libhostmarch.so")
+    shutil.copy(hm.build(), private)  # the workers load a private copy: rebuilding the tree does not disturb a long run
+    os.environ["HOSTMARCH_LIB"] = private
     import multiprocessing as mp
     t0 = time.time()
     n_bad = 0; walk_total = 0; seg_total = 0
