@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
-"""Benchmark of the HIP segmentize! path — BASELINE.json's metric on BASELINE.json's config.
+"""Benchmark of the HIP segmentize! path — BASELINE.json's metric on BASELINE.json's configurations.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one full ``segmentize!`` (``rt_segmentize``: device march of every track, CSR
-offsets, compact segment records, fused ``fill_volumes``) over a batch of tracks that is
-already resident in HBM.  N=1: the headline configuration, ``demo/pincell.msh`` at nφ=128,
-δ=1e-3 (130,456 tracks, 9.32 M segments).  N>1 (launched by ``torch.distributed.run``, one
-rank per GPU): weak scaling — the global problem is the same mesh at nφ=128, δ=1e-3/N (≈N×
-the tracks), ``tracks_by_uid`` is split into N contiguous uid ranges balanced by Σℓ, every
-rank marches its own range, and the only data-path exchange of the reference's algorithm
-(``fill_volumes``' cross-track sum) is one RCCL all-reduce of ``n_cells`` doubles inside the
-timed step.  Reassembling the global segment list on every rank (an RCCL all-gather of the
-segment arrays) is measured after the timed region and reported under ``"allgather"``.
+A "step" is one full ``segmentize!`` (``rt_segmentize`` through the C ABI: device march of every track, CSR
+offsets, compact segment records, fused ``fill_volumes``) over a batch of tracks that is already resident in HBM.
 
-The JSON line also carries ``roofline`` (dominant kernel, algorithmic bytes ÷ HIP-event
-duration against the 8 TB/s HBM peak) and, at N=1, ``cpu_baseline`` (the oracle — a C port
-of the reference's algorithm — timed on the host cores of the same box).
+N = 1 — the headline configuration (BASELINE.json configs[2], the one the 50 M segments/s target is quoted on):
+``demo/pincell.msh`` at nφ=128, δ=1e-3, 130,456 tracks, 9.32 M segments.  The line also carries, under
+``config5_single_gpu``, the scaling workload below run on this one GPU, so that an N=1 point of the same
+workload exists beside every N>1 line.
+
+N > 1 (launched by ``torch.distributed.run``, one rank per GPU) — BASELINE.json configs[4]: the BWR-like assembly
+mesh at nφ=128, δ=5e-4 (1,043,212 tracks, 114 M segments) as a FIXED global problem, i.e. strong scaling:
+``tracks_by_uid`` is cut into N contiguous uid ranges balanced by Σℓ, every rank marches its own range, and the only
+data-path exchange of the reference's algorithm (``fill_volumes``' cross-track sum) is one RCCL all-reduce of
+``n_cells`` doubles inside the timed step.  The RCCL all-gather-v that reassembles the global segment list on
+every rank (direct sends and receives into the final buffers, ``distributed.SegmentGather``) is measured after the
+timed region and always reported beside it (``allgather.ms``, ``segments_per_s_including_allgather``); rank 0 then
+runs the whole problem alone (``single_gpu_same_workload``) so that the speed-up is measured inside one run.
+
+The JSON line also carries ``roofline`` (dominant kernel: algorithmic bytes ÷ HIP-event duration against the
+8 TB/s HBM peak; ``pipeline``: the same for the whole step; ``traffic`` only when the committed PMC summary was
+taken from the very library that is running), ``latency`` (p50/p95 of single steps), ``e2e`` (the costs of the
+boundary around the step: mesh preparation, track upload, record download) and, at N=1, ``cpu_baseline`` (the
+oracle — a C port of the reference's algorithm — timed on the host cores of the same box).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,24 +46,76 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 # SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input (the march itself stages
 # only 20 B of it: q and the cell).  The compaction reads those 20 B from the staging pool, rebuilds p
 # and ℓ, and writes the 44-B record to its CSR position.
-KERNELS = {
-    "march": ("rt::k_march<2, 4, false>", 45.0),   # single-pass staged march, fill_volumes fused (LDS-private)
-    "compact": ("rt::k_compact3<false>", 64.0),
-    "scan": ("rt::k_scan_write", 0.0),  # three small kernels: CSR offsets of the counts; volumes ./= n_azim_2 rides along
+BYTES_PER_SEGMENT = {"march": 45.0, "compact": 64.0, "scan": 0.0}
+STEP_BYTES_PER_SEGMENT = 45.0  # the whole step, by the same definition (what one segmentize! must at least move)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+
+WORKLOADS = {
+    "c3": dict(mesh="pincell.msh", n_azim=128, delta=1e-3, name="BASELINE configs[2]: demo/pincell.msh, nφ=128, δ=1e-3"),
+    "c5": dict(mesh="bwr_like.msh", n_azim=128, delta=5e-4,
+               name="BASELINE configs[4]: BWR assembly (substitute mesh bwr_like.msh, tools/make_bwr_mesh.py), nφ=128, δ=5e-4"),
 }
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
 
 
-def hbm_traffic_per_launch(kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01): FETCH_SIZE and
-    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads and is
-    doubled (MI355X_MICROARCH.md §HBM).  None when no profile of this build is committed."""
+def lib_sha256():
+    from raytracing_jl_amd import _capi
+
+    return hashlib.sha256(open(_capi.LIB_PATH, "rb").read()).hexdigest()
+
+
+def pmc_traffic():
+    """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes — only if they were taken from the
+    library that is running now (sha256 of the .so recorded by tools/pmc_summary.py).  FETCH_SIZE and WRITE_SIZE are
+    in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads and is doubled
+    (MI355X_MICROARCH.md §HBM)."""
     try:
         d = json.load(open(PMC_SUMMARY))
-        k = d["kernels"][kernel_name]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
+        if d.get("lib_sha256") != lib_sha256():
+            return {}, "profiles/r02/pmc_summary.json was taken from another build of the library"
+        return ({k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in d["kernels"].items()
+                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r02/pmc_summary.json (same library, sha256 match)")
+    except Exception as e:
+        return {}, "no PMC summary: %r" % (e,)
+
+
+def kernel_names(stats):
+    w = stats["march_waves"]
+    return {"march": "rt::k_march<2, %d, %s, %s>" % (w, "true" if stats["split"] else "false", "true" if stats["wide_k"] else "false"),
+            "compact": "rt::k_compact3<%s>" % ("true" if stats["split"] else "false"), "scan": "rt::k_scan_write"}
+
+
+def make_tg(rt, wl):
+    mesh_file = rt.data_path(wl["mesh"])
+    model = rt.GmshDiscreteModel(mesh_file) if mesh_file.endswith(".msh") else rt.DiscreteModelFromFile(mesh_file)
+    tg = rt.TrackGenerator(model, wl["n_azim"], wl["delta"])
+    rt.trace(tg)
+    return tg
+
+
+def run_steps(rt, dt, tg, aq, n):
+    t0 = time.perf_counter()
+    for _ in range(n):
+        total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    return total, time.perf_counter() - t0
+
+
+def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=None):
+    """The given workload, unsharded, on one GPU: ms per step (host clock around K synchronous calls)."""
+    tg = tg if tg is not None else make_tg(rt, wl)
+    aq = tg.azimuthal_quadrature
+    dm = _capi.DeviceMesh(tg.mesh, device)
+    if stream_ptr:
+        dm.set_stream(stream_ptr)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    run_steps(rt, dt, tg, aq, warmup)
+    total, el = run_steps(rt, dt, tg, aq, steps)
+    tm = dt.timing()
+    out = {"workload": wl["name"], "tracks": int(tg.n_total_tracks), "segments": int(total), "steps": steps,
+           "ms_per_step": el / steps * 1e3, "value": total * steps / el, "unit": "segments/s",
+           "kernel_ms_last_step": {k: tm[k] for k in ("march", "scan", "compact", "total")}}
+    dt.close()
+    dm.close()
+    return out
 
 
 def two_in_flight(tg, aq, dmesh, dt, steps, segments_per_step):
@@ -94,7 +155,7 @@ def two_in_flight(tg, aq, dmesh, dt, steps, segments_per_step):
         return {"error": repr(e)}
 
 
-def cpu_baseline(tg, max_seconds=30.0):
+def cpu_baseline(tg):
     """Oracle (C port of the reference's algorithm, libm trig per advance_step as the
     reference does) on the host cores.  Checker code used as a reported baseline only."""
     from oracle import oracle as orc
@@ -139,14 +200,15 @@ def _main(real_stdout):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c5", "custom"],
+                    help="auto: c3 (headline) on one GPU, c5 (strong scaling) on several; custom: --mesh/--n-azim/--delta")
     ap.add_argument("--n-azim", type=int, default=128)
     ap.add_argument("--delta", type=float, default=1e-3)
     ap.add_argument("--mesh", default="pincell.msh")
+    ap.add_argument("--latency-steps", type=int, default=200, help="extra single steps for the p50/p95 latency (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the extra two-batches-in-flight measurement")
-    ap.add_argument("--allgather", action="store_true",
-                    help="N>1: also time the RCCL all-gather that reassembles the global segment list on every rank (after the timed region)")
-    ap.add_argument("--no-allgather", action="store_true", help="(default; kept for compatibility)")
+    ap.add_argument("--no-extras", action="store_true", help="skip e2e, latency, config5_single_gpu / single_gpu_same_workload")
     ap.add_argument("--force-dist", action="store_true", help="development: run the multi-GPU code path with a one-rank RCCL group")
     args = ap.parse_args()
 
@@ -174,22 +236,26 @@ def _main(real_stdout):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist_on = world > 1 or args.force_dist
 
-    # ---- workload (deterministic, no RNG): host-side trace! then upload the rank's uid range
-    mesh_file = rt.data_path(args.mesh)
-    model = rt.GmshDiscreteModel(mesh_file) if mesh_file.endswith(".msh") else rt.DiscreteModelFromFile(mesh_file)
-    delta = args.delta / world
-    tg = rt.TrackGenerator(model, args.n_azim, delta)
-    rt.trace(tg)
+    # ---- workload (deterministic, no RNG): host-side trace! of the GLOBAL problem, then upload the rank's uid range
+    wkey = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c5")
+    wl = WORKLOADS[wkey] if wkey in WORKLOADS else dict(mesh=args.mesh, n_azim=args.n_azim, delta=args.delta,
+                                                        name="%s, nφ=%d, δ=%g" % (args.mesh, args.n_azim, args.delta))
+    tg = make_tg(rt, wl)
     aq = tg.azimuthal_quadrature
+    t0 = time.perf_counter()
     dmesh = _capi.DeviceMesh(tg.mesh, local_rank)
+    mesh_create_ms = (time.perf_counter() - t0) * 1e3
     # one explicit stream for everything: the library's kernels, torch's own ops and the stream-level waits
     # of the pipelined all-reduce (torch's default stream has handle 0, which the library reads as "use
     # your own stream" — the waits would then order nothing)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     dmesh.set_stream(stream.cuda_stream)
+    t0 = time.perf_counter()
     dt, (lo, hi) = rtd.segmentize_shard(tg, rank, world, device=local_rank, dmesh=dmesh)
+    tracks_h2d_ms = (time.perf_counter() - t0) * 1e3
 
     # fill_volumes is the one reduction across tracks: every rank's partial `volumes` are summed by an RCCL
     # all-reduce per step, in place in the library's buffer.  It is pipelined by one step: the library
@@ -197,7 +263,6 @@ def _main(real_stdout):
     # hook of step i+1 (when step i+1's kernels are already queued) on a side stream — its launch and its
     # latency sit beside the next march instead of between two steps.  The last one is waited for inside the
     # timed region (`drain`).
-    dist_on = world > 1 or args.force_dist
     if dist_on:
         pipe = rtd.PipelinedVolumesAllReduce(device=dev)
         views = {}
@@ -241,6 +306,8 @@ def _main(real_stdout):
     elapsed = time.perf_counter() - t0
     n_failed, _, _ = dt.failed()  # tracks on which the reference itself would have thrown (never fatal here:
     #                               a rank that exits alone would deadlock the others)
+    stats = dt.stats()
+    info = dmesh.info()
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(local_total), float(n_failed)], dtype=torch.float64, device=dev)
@@ -251,40 +318,94 @@ def _main(real_stdout):
     global_segments = float(tot[0].item())
     failed_tracks = int(tot[1].item())
 
-    # ---- optional: reassemble the global segment list on every rank (RCCL all-gather)
+    # ---- N > 1: reassemble the global segment list on every rank (RCCL all-gather-v), always reported
     allgather = None
-    if world > 1 and args.allgather:
+    if world > 1 or args.force_dist:
         p = dt.device_pointers()
         off = torch.as_tensor(rtd.DevArray(p["offsets"], dt.n + 1, "<i8", dt), device=dev)
         local = {"counts": off[1:] - off[:-1]}
         for name in ("px", "py", "qx", "qy", "ell"):
             local[name] = torch.as_tensor(rtd.DevArray(p[name], local_total, "<f8", dt), device=dev)
         local["element"] = torch.as_tensor(rtd.DevArray(p["element"], local_total, "<i4", dt), device=dev)
-        rtd.allgather_segments(local)  # warm-up
+        try:
+            gather = rtd.SegmentGather()
+            gather(local)  # warm-up (allocates the final buffers, opens the peer connections)
+            sync()
+            reps = 3
+            g0 = time.perf_counter()
+            for _ in range(reps):
+                g = gather(local)
+            sync()
+            g_ms = (time.perf_counter() - g0) / reps * 1e3
+            gt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            assert int(g["offsets"][-1].item()) == int(global_segments)
+            g_ms = float(gt.item())
+            allgather = {"ms": g_ms, "bytes_received_per_rank": 44.0 * (global_segments - local_total),
+                         "GBs_received_per_rank": 44.0 * (global_segments - local_total) / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0,
+                         "segments_per_s_including_allgather": global_segments / (t_max / args.steps + g_ms / 1e3),
+                         "method": "batched RCCL send/recv pairs straight into the final buffers (all-gather-v, no padding)"}
+            del g, gather
+        except Exception as e:  # the headline line must survive a failure of the extra
+            allgather = {"error": repr(e)}
+
+    # ---- extras measured outside the timed region (rank 0)
+    latency = e2e = same_workload = config5 = None
+    if rank == 0 and not args.no_extras and not dist_on:
+        # single-step latency distribution
+        lat = []
+        for _ in range(max(args.latency_steps, 0)):
+            a = time.perf_counter()
+            dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+            lat.append((time.perf_counter() - a) * 1e3)
+        if lat:
+            q = np.percentile(lat, [50, 95, 99])
+            latency = {"steps": len(lat), "ms_p50": float(q[0]), "ms_p95": float(q[1]), "ms_p99": float(q[2]), "ms_min": float(min(lat)),
+                       "ms_max": float(max(lat)), "note": "host clock around single synchronous rt_segmentize calls, after the timed region"}
+        # the boundary's real costs around one step (host buffers in, host buffers out)
+        a = time.perf_counter()
+        dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        seg_ms = (time.perf_counter() - a) * 1e3
+        dt.fetch_segments_pinned()  # first use pins the buffers (one-time)
+        a = time.perf_counter()
+        dt.fetch_segments_pinned()
+        fetch_ms = (time.perf_counter() - a) * 1e3
+        a = time.perf_counter()
+        dt.fetch_offsets()
+        off_ms = (time.perf_counter() - a) * 1e3
+        e2e = {"mesh_create_ms": mesh_create_ms, "mesh_prep_host_ms": info["prep_ms"], "tracks_h2d_ms": tracks_h2d_ms,
+               "segmentize_ms": seg_ms, "fetch_pinned_ms": fetch_ms, "fetch_offsets_status_ms": off_ms,
+               "fetch_GBs": 44.0 * local_total / (fetch_ms * 1e-3) / 1e9 if fetch_ms > 0 else 0.0,
+               "note": "one call as the shim sees it: rt_mesh_create (once per mesh), rt_tracks_create (H2D of the track arrays), "
+                       "rt_segmentize, rt_fetch_segments_pinned (D2H of the 44-B records over PCIe) — never part of `value`"}
+    if not args.no_extras and world > 1:
+        # the same global problem on rank 0's GPU alone, in the same run: the N=1 point of this strong-scaling line
         sync()
-        reps = 3
-        g0 = time.perf_counter()
-        for _ in range(reps):
-            g = rtd.allgather_segments(local)
+        if rank == 0:
+            same_workload = single_gpu_run(rt, _capi, wl, local_rank, max(3, args.steps // 4), 2, stream.cuda_stream, tg=tg)
         sync()
-        g_ms = (time.perf_counter() - g0) / reps * 1e3
-        gt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        assert int(g["offsets"][-1].item()) == int(global_segments)
-        allgather = {"ms": float(gt.item()), "bytes_per_rank_received": 44.0 * global_segments,
-                     "segments_per_s_including_allgather": global_segments / (t_max / args.steps + float(gt.item()) / 1e3)}
-        del g
+    if rank == 0 and not args.no_extras and world == 1 and not dist_on and wkey == "c3":
+        try:
+            config5 = single_gpu_run(rt, _capi, WORKLOADS["c5"], local_rank, 5, 2, stream.cuda_stream)
+        except Exception as e:  # pragma: no cover
+            config5 = {"error": repr(e)}
 
     if rank == 0:
         ms_per_step = t_max / args.steps * 1e3
+        names = kernel_names(stats)
+        traffic, traffic_src = pmc_traffic()
         per_kernel = []
-        for key, (kname, bps) in KERNELS.items():
+        for key in ("march", "compact", "scan"):
             ms = kern[key] / args.steps
-            per_kernel.append({"kernel": kname, "ms_avg": ms, "bytes_per_segment": bps,
+            bps = BYTES_PER_SEGMENT[key]
+            per_kernel.append({"kernel": names[key], "ms_avg": ms, "bytes_per_segment": bps,
                                "achieved_GBs": bps * local_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                               "traffic": hbm_traffic_per_launch(kname)})
+                               "traffic": traffic.get(names[key]) if wkey == "c3" and world == 1 else None})
         dom_k = max(per_kernel, key=lambda k: k["ms_avg"])
         achieved = dom_k["achieved_GBs"]
+        step_GBs = STEP_BYTES_PER_SEGMENT * global_segments / (ms_per_step * 1e-3) / 1e9
+        tr_all = [k["traffic"] for k in per_kernel]
         out = {
             "metric": "segments/sec (whole node)",
             "value": global_segments * args.steps / t_max,
@@ -294,32 +415,48 @@ def _main(real_stdout):
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (deterministic tracks from trace! on the reference's demo/pincell.msh; no RNG)",
+            "data": "synthetic (deterministic tracks from trace! on the mesh; no RNG)",
             "config": {
-                "workload": "%s, nφ=%d, δ=%g (global), all tracks of tracks_by_uid; segmentize! = march + CSR offsets "
-                            "+ compact segment records + fill_volumes" % (args.mesh, args.n_azim, delta),
+                "workload": "%s; all tracks of tracks_by_uid; segmentize! = march + CSR offsets + compact segment records + "
+                            "fill_volumes%s" % (wl["name"], "; FIXED global problem split over %d GPUs (strong scaling)" % world if world > 1 else ""),
                 "tracks_global": int(tg.n_total_tracks), "segments_global": int(global_segments),
                 "tracks_rank0": int(hi - lo), "segments_rank0": int(local_total),
-                "sharding": "contiguous uid ranges balanced by Σℓ; all-reduce(sum) of volumes" if world > 1 else "none",
+                "sharding": "contiguous uid ranges balanced by Σℓ; all-reduce(sum) of volumes inside the step" if world > 1 else "none",
                 "tiny_step": tg.tiny_step, "k": 5, "rtol": rt.RTOL_DEFAULT, "failed_tracks": failed_tracks,
+                "regime": {"walk_enabled": info["walk_enabled"], "records_walkable": info["records_walk"], "records": info["records"],
+                           "walk_records_rank0": stats["walk_records"], "generic_records_rank0": stats["generic_records"]},
+                "library_sha256": lib_sha256(),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom_k["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": dom_k["traffic"],
+                "traffic": dom_k["traffic"], "traffic_source": traffic_src,
                 "bytes_per_segment": dom_k["bytes_per_segment"], "segments_per_launch": int(local_total),
                 "kernel_ms_avg": dom_k["ms_avg"],
+                "pipeline": {"achieved": step_GBs, "frac": step_GBs / (HBM_PEAK_GBS * world), "unit": "GB/s",
+                             "bytes_per_segment": STEP_BYTES_PER_SEGMENT, "ms_per_step": ms_per_step,
+                             "traffic_over_algorithmic": (sum(tr_all) / (STEP_BYTES_PER_SEGMENT * local_total)) if all(t is not None for t in tr_all) else None,
+                             "note": "whole step: algorithmic bytes (45 B/segment) ÷ ms_per_step against the peak of the GPUs in use"},
                 "note": "dominant kernel by HIP-event duration; algorithmic bytes = bytes_per_segment x segments per launch "
                         "(DESIGN.md §4).  The march is FP64 traversal bound by its per-track dependent chain, not by HBM",
             },
             "kernels": per_kernel,
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},
         }
+        if latency is not None:
+            out["latency"] = latency
+        if e2e is not None:
+            out["e2e"] = e2e
         if allgather is not None:
             out["allgather"] = allgather
+        if same_workload is not None:
+            out["single_gpu_same_workload"] = same_workload
+            out["speedup_vs_single_gpu"] = same_workload["ms_per_step"] / ms_per_step
+        if config5 is not None:
+            out["config5_single_gpu"] = config5
         if world == 1 and not dist_on and not args.no_concurrent:
             out["two_batches_in_flight"] = two_in_flight(tg, aq, dmesh, dt, args.steps, local_total)
         if world == 1 and not args.no_cpu_baseline:

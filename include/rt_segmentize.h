@@ -177,8 +177,53 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
 
 /* Counters of the last rt_segmentize on this handle: stats[0] segment records, stats[1] records produced by the
  * literal step (the walk step produced the rest; track pieces' seeds in split mode count as neither), stats[2]
- * staging chunks used, stats[3] staging chunks allocated.  n = capacity of stats (>= 4). */
+ * staging chunks used, stats[3] staging chunks allocated; if n allows: stats[4] waves per workgroup of the march kernel
+ * the call launched, stats[5] 1 if it marched track pieces (split mode), stats[6] 1 for the wide-k instantiation.
+ * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
+
+/* ---------------------------------------------------------------------------------------
+ * Several GPUs behind one call.  segmentize! marches tracks_by_uid one after the other and every track writes
+ * only its own segments (src/trackgenerator.jl:362-364): the path shards without a data-path exchange.  The mesh
+ * is replicated on every device of device_ids[n_devices] (a device may be named more than once), tracks_by_uid is
+ * cut into contiguous uid ranges of ≈ equal Σℓ, one per entry of device_ids, and every range runs the
+ * single-device path from its own host thread.  Arguments as for rt_mesh_create + rt_tracks_create.
+ * --------------------------------------------------------------------------------------- */
+typedef struct rt_multi rt_multi;
+rt_multi *rt_multi_create(const int32_t *device_ids, int32_t n_devices, const double *x, const double *y,
+                          int32_t n_nodes, const int32_t *cell_nodes, int32_t n_cells,
+                          const int32_t *node_cells_ptrs, const int32_t *node_cells_data, const double *bb,
+                          int64_t n_tracks, const double *px, const double *py, const double *phi,
+                          const double *cos_phi, const double *sin_phi, const double *A, const double *B,
+                          const double *C, const double *ell, const int32_t *azim_idx);
+void rt_multi_destroy(rt_multi *multi);
+/* rt_set_option on every replica of the mesh. */
+int32_t rt_multi_set_option(rt_multi *multi, const char *name, int64_t value);
+/* segmentize!(t; k, rtol) over all shards at once (arguments as rt_segmentize).  Returns the global number of
+ * segments or a negative RT_ERR_* code. */
+int64_t rt_multi_segmentize(rt_multi *multi, double tiny_step, int32_t k, double rtol, const double *delta_s,
+                            int32_t n_azim_2);
+/* The partition: shard i owns 0-based uids [uid_begin[i], uid_begin[i+1]) and, after rt_multi_segmentize, the global
+ * segment positions [seg_begin[i], seg_begin[i+1]); both arrays hold n_devices + 1 entries (either may be NULL).
+ * Returns n_devices. */
+int32_t rt_multi_shards(rt_multi *multi, int64_t *uid_begin, int64_t *seg_begin);
+/* Shard i's own handle (owned by `multi`): rt_device_pointers / rt_last_timing / rt_last_stats per device. */
+rt_tracks *rt_multi_shard(rt_multi *multi, int32_t i);
+/* As rt_failed_tracks, with the GLOBAL 1-based uid of the first failing track. */
+int32_t rt_multi_failed_tracks(rt_multi *multi, int64_t *n_failed, int64_t *first_uid, int32_t *first_status);
+/* The global results in caller-allocated host buffers, exactly what rt_fetch_* of an unsharded run would hold:
+ * seg_offsets[n_tracks+1], status[n_tracks], the six segment arrays [total] (every device copies its shard over its
+ * own PCIe link, concurrently), volumes[n_cells] = the sum of the shards' volumes (fill_volumes is the only
+ * reduction across tracks, src/trackgenerator.jl:371-386).  Any pointer may be NULL to skip it. */
+int32_t rt_multi_fetch_offsets(rt_multi *multi, int64_t *seg_offsets, int32_t *status);
+int32_t rt_multi_fetch_segments(rt_multi *multi, double *px, double *py, double *qx, double *qy, double *ell,
+                                int32_t *element);
+int32_t rt_multi_fetch_volumes(rt_multi *multi, double *volumes);
+/* Reassemble the global segment list ON every shard's device with peer-to-peer copies (shard j travels to device i
+ * over the xGMI link of that pair; all pairs at once).  ptrs_dev[n_devices*6] (may be NULL) receives, per shard i, the
+ * device pointers of the global px, py, qx, qy, ell (f64) and element (i32) arrays on device_ids[i], valid until the
+ * next rt_multi_allgather / rt_multi_destroy; *ms (may be NULL) the wall time of the copies. */
+int32_t rt_multi_allgather(rt_multi *multi, void **ptrs_dev, double *ms);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side rows around the hot path: they run on the CPU, like in the

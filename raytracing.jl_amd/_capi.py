@@ -20,6 +20,8 @@ SYMBOLS = (
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option",
+    "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
+    "rt_multi_failed_tracks", "rt_multi_fetch_offsets", "rt_multi_fetch_segments", "rt_multi_fetch_volumes", "rt_multi_allgather",
     "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
 )
 
@@ -126,6 +128,31 @@ def lib():
     L.rt_last_timing.argtypes = [_vp, _dp, C.c_int32]
     L.rt_set_option.restype = C.c_int32
     L.rt_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
+    try:
+        L.rt_multi_create.restype = _vp
+        L.rt_multi_create.argtypes = [_ip, C.c_int32, _dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp, C.c_int64] + [_dp] * 9 + [_ip]
+        L.rt_multi_destroy.argtypes = [_vp]
+        L.rt_multi_set_option.restype = C.c_int32
+        L.rt_multi_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
+        L.rt_multi_segmentize.restype = C.c_int64
+        L.rt_multi_segmentize.argtypes = [_vp, C.c_double, C.c_int32, C.c_double, _dp, C.c_int32]
+        L.rt_multi_shards.restype = C.c_int32
+        L.rt_multi_shards.argtypes = [_vp, _lp, _lp]
+        L.rt_multi_shard.restype = _vp
+        L.rt_multi_shard.argtypes = [_vp, C.c_int32]
+        L.rt_multi_failed_tracks.restype = C.c_int32
+        L.rt_multi_failed_tracks.argtypes = [_vp, _lp, _lp, _ip]
+        L.rt_multi_fetch_offsets.restype = C.c_int32
+        L.rt_multi_fetch_offsets.argtypes = [_vp, _lp, _ip]
+        L.rt_multi_fetch_segments.restype = C.c_int32
+        L.rt_multi_fetch_segments.argtypes = [_vp, _dp, _dp, _dp, _dp, _dp, _ip]
+        L.rt_multi_fetch_volumes.restype = C.c_int32
+        L.rt_multi_fetch_volumes.argtypes = [_vp, _dp]
+        L.rt_multi_allgather.restype = C.c_int32
+        L.rt_multi_allgather.argtypes = [_vp, C.POINTER(_vp), _dp]
+    except AttributeError:
+        if not os.environ.get("RT_SEGMENTIZE_LIB"):
+            raise
     _bp = C.POINTER(C.c_int8)
     L.rt_trace_counts.restype = C.c_int64
     L.rt_trace_counts.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_double, _lp, _lp]
@@ -307,10 +334,10 @@ class DeviceTracks:
 
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
-        v = (C.c_int64 * 4)()
-        _check(lib().rt_last_stats(self._h, v, 4))
+        v = (C.c_int64 * 8)()
+        _check(lib().rt_last_stats(self._h, v, 8))
         return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
-                    chunks_used=int(v[2]), chunks_allocated=int(v[3]))
+                    chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]))
 
     def timing(self):
         ms = getattr(self, "_ms_buf", None)
@@ -324,6 +351,82 @@ class DeviceTracks:
     def close(self):
         if getattr(self, "_h", None):
             lib().rt_tracks_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiDevice:
+    """``rt_multi`` handle: ``tracks_by_uid`` sharded over several devices behind one call (``device_ids`` may
+    name a device more than once)."""
+
+    def __init__(self, mesh, device_ids, px, py, phi, cos_phi, sin_phi, A, B, Cc, ell, azim_idx):
+        L = lib()
+        ids, idp = _i32(device_ids)
+        x, xp = _f64(mesh.x); y, yp = _f64(mesh.y)
+        cn, cnp = _i32(np.asarray(mesh.cell_nodes).reshape(-1))
+        ptr, ptrp = _i32(mesh.node_cells_ptrs); dat, datp = _i32(mesh.node_cells_data)
+        bb, bbp = _f64(mesh.bb)
+        arrs = [_f64(a) for a in (px, py, phi, cos_phi, sin_phi, A, B, Cc, ell)]
+        az, azp = _i32(azim_idx)
+        self.n_devices, self.n_tracks, self.n_cells = len(ids), len(arrs[0][0]), len(cn) // 3
+        self._h = L.rt_multi_create(idp, len(ids), xp, yp, len(x), cnp, self.n_cells, ptrp, datp, bbp, self.n_tracks,
+                                    *[p for _, p in arrs], azp)
+        if not self._h:
+            raise RtError(f"rt_multi_create failed: {last_error()}")
+        self.total = None
+
+    def set_option(self, name: str, value: int):
+        _check(lib().rt_multi_set_option(self._h, name.encode(), int(value)))
+
+    def segmentize(self, tiny_step: float, k: int, rtol: float, delta_s, n_azim_2: int) -> int:
+        ds, dsp = _f64(delta_s)
+        self.total = int(_check(lib().rt_multi_segmentize(self._h, tiny_step, k, rtol, dsp, n_azim_2)))
+        return self.total
+
+    def shards(self):
+        ub, sb = np.zeros(self.n_devices + 1, np.int64), np.zeros(self.n_devices + 1, np.int64)
+        _check(lib().rt_multi_shards(self._h, ub.ctypes.data_as(_lp), sb.ctypes.data_as(_lp) if self.total is not None else None))
+        return ub, sb
+
+    def failed(self):
+        n, u, st = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        _check(lib().rt_multi_failed_tracks(self._h, C.byref(n), C.byref(u), C.byref(st)))
+        return n.value, u.value, st.value
+
+    def fetch_offsets(self):
+        off = np.zeros(self.n_tracks + 1, np.int64)
+        st = np.zeros(max(self.n_tracks, 1), np.int32)
+        _check(lib().rt_multi_fetch_offsets(self._h, off.ctypes.data_as(_lp), st.ctypes.data_as(_ip)))
+        return off, st[: self.n_tracks]
+
+    def fetch_segments(self):
+        n = self.total
+        out = {k: np.empty(n, np.float64) for k in ("px", "py", "qx", "qy", "ell")}
+        out["element"] = np.empty(n, np.int32)
+        _check(lib().rt_multi_fetch_segments(self._h, *[out[k].ctypes.data_as(_dp) for k in ("px", "py", "qx", "qy", "ell")],
+                                             out["element"].ctypes.data_as(_ip)))
+        return out
+
+    def fetch_volumes(self):
+        v = np.zeros(self.n_cells, np.float64)
+        _check(lib().rt_multi_fetch_volumes(self._h, v.ctypes.data_as(_dp)))
+        return v
+
+    def allgather(self):
+        """Reassemble the global arrays on every shard's device (peer copies).  Returns (ms, ptrs[n_devices][6])."""
+        ptrs = (_vp * (6 * self.n_devices))()
+        ms = C.c_double(0.0)
+        _check(lib().rt_multi_allgather(self._h, ptrs, C.byref(ms)))
+        return ms.value, [[ptrs[6 * i + a] or 0 for a in range(6)] for i in range(self.n_devices)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_multi_destroy(self._h)
             self._h = None
 
     def __del__(self):

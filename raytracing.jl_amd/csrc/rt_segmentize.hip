@@ -985,6 +985,7 @@ struct rt_tracks {
     double sum_ell = 0.0;
     int32_t azim_min = 1, azim_max = 0;  // range of azim_idx (checked against n_azim_2 by rt_segmentize)
     int64_t n_generic_records = 0;       // rt_last_stats
+    int32_t last_march_waves = 0, last_split = 0, last_widek = 0;  // which instantiation of the march the last call launched
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     void *pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rt_fetch_segments_pinned
     size_t pin_cap = 0;                                                     // records
@@ -1463,6 +1464,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     const bool widek = k > rt::kMaxK;  // find_element's knn fallback beyond the in-register list: separate kernel instantiations
     const int64_t *march_offsets = nullptr;
     auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK>(unsigned blocks, size_t smem) -> int {
+        t->last_march_waves = WAVES; t->last_split = SPLIT ? 1 : 0; t->last_widek = WIDEK ? 1 : 0;
         if (smem > 48 * 1024)
             RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK>), dim3(blocks), dim3(64 * WAVES), smem, s, m->d, t->d, prm, t->counts.p,
@@ -1753,6 +1755,9 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     stats[1] = t->n_generic_records;
     stats[2] = t->chunks_needed_last;
     stats[3] = t->pool_chunks;
+    if (n > 4) stats[4] = t->last_march_waves;
+    if (n > 5) stats[5] = t->last_split;
+    if (n > 6) stats[6] = t->last_widek;
     return RT_SUCCESS;
 }
 

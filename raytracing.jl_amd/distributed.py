@@ -19,7 +19,7 @@ from typing import Callable, Dict, List, Tuple
 import numpy as np
 
 __all__ = ["shard_ranges", "shard_arrays", "segmentize_shard", "allreduce_volumes",
-           "allgather_segments", "DevArray", "TRACK_FIELDS", "PipelinedVolumesAllReduce"]
+           "allgather_segments", "SegmentGather", "DevArray", "TRACK_FIELDS", "PipelinedVolumesAllReduce"]
 
 TRACK_FIELDS = ("px", "py", "phi", "cos_phi", "sin_phi", "A", "B", "C", "ell", "azim_idx")
 
@@ -77,57 +77,85 @@ def allreduce_volumes(volumes, group=None):
     return volumes
 
 
-def allgather_segments(local: dict, group=None) -> dict:
+class SegmentGather:
+    """All-gather-v of the ranks' segment arrays straight into the final buffers.
+
+    Ranks own contiguous uid ranges in rank order, so the global list is the concatenation of the shards in rank
+    order: every rank sends each of its six arrays to every peer and receives each peer's into the slice of the
+    final buffer where that shard belongs — one batched group of point-to-point operations
+    (``batch_isend_irecv``: RCCL send/recv pairs, all issued inside one group), no padding, no staging, no
+    concatenation.  xGMI is point to point, so the 7 transfers a rank sends travel over 7 different links at
+    once, which a ring all-gather of 8 unequal blocks would not use.  The final buffers are allocated once and
+    reused while they are large enough.  Works over ``gloo`` as well (CPU tests)."""
+
+    NAMES = ("px", "py", "qx", "qy", "ell", "element")
+
+    def __init__(self, group=None):
+        self.group = group
+        self.buf = {}
+        self.cap = 0
+
+    def __call__(self, local: dict) -> dict:
+        import torch
+        import torch.distributed as dist
+
+        on = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size(self.group) if on else 1
+        rank = dist.get_rank(self.group) if on else 0
+        dev = local["ell"].device
+        n_seg, n_trk = int(local["ell"].numel()), int(local["counts"].numel())
+        if world == 1:
+            counts = local["counts"]
+            out = {k: local[k] for k in self.NAMES}
+        else:
+            sizes = torch.tensor([n_seg, n_trk], dtype=torch.int64, device=dev)
+            all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+            dist.all_gather(all_sizes, sizes, group=self.group)
+            all_sizes = torch.stack(all_sizes).cpu().numpy()
+            seg_begin = np.concatenate(([0], np.cumsum(all_sizes[:, 0])))
+            trk_begin = np.concatenate(([0], np.cumsum(all_sizes[:, 1])))
+            total, n_tracks = int(seg_begin[-1]), int(trk_begin[-1])
+            if total > self.cap or self.buf.get("dev") != dev:
+                cap = total + total // 16 + 64
+                self.buf = {k: torch.empty(cap, dtype=torch.int32 if k == "element" else torch.float64, device=dev) for k in self.NAMES}
+                self.buf["dev"] = dev
+                self.cap = cap
+            out = {k: self.buf[k][:total] for k in self.NAMES}
+            counts = torch.empty(n_tracks, dtype=torch.int64, device=dev)
+            ops = []
+            for k in self.NAMES + ("counts",):
+                dst = counts if k == "counts" else out[k]
+                begin = trk_begin if k == "counts" else seg_begin
+                dst[int(begin[rank]): int(begin[rank + 1])].copy_(local[k])  # the rank's own shard: a local copy
+                for p in range(world):
+                    if p == rank:
+                        continue
+                    if local[k].numel():
+                        ops.append(dist.P2POp(dist.isend, local[k], self._peer(p), self.group))
+                    if begin[p + 1] > begin[p]:
+                        ops.append(dist.P2POp(dist.irecv, dst[int(begin[p]): int(begin[p + 1])], self._peer(p), self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        offsets = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=offsets[1:])
+        out = dict(out)
+        out["offsets"] = offsets
+        return out
+
+    def _peer(self, p):
+        import torch.distributed as dist
+
+        return p if self.group is None else dist.get_global_rank(self.group, p)
+
+
+def allgather_segments(local: dict, group=None, gather: "SegmentGather | None" = None) -> dict:
     """Reassemble the global segment list on every rank.
 
     ``local``: torch tensors of this rank's shard — ``counts`` (int64, per local track),
-    ``px, py, qx, qy, ell`` (float64) and ``element`` (int32), all on one device.  Ranks own
-    contiguous uid ranges in rank order, so concatenating shards in rank order is uid
-    order.  Two padded collectives move the payload (one f64 block of 5 rows, one i32 row);
-    RCCL has no all-gather-v.  Returns ``offsets`` (int64, n_tracks+1) and the six arrays.
-    """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    dev = local["ell"].device
-    n_seg = int(local["ell"].numel())
-    n_trk = int(local["counts"].numel())
-    if world == 1:
-        counts = local["counts"]
-        out = {k: local[k] for k in ("px", "py", "qx", "qy", "ell", "element")}
-    else:
-        sizes = torch.tensor([n_seg, n_trk], dtype=torch.int64, device=dev)
-        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes, group=group)
-        all_sizes = torch.stack(all_sizes).cpu().numpy()
-        max_seg, max_trk = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-        f = torch.zeros((5, max(max_seg, 1)), dtype=torch.float64, device=dev)
-        for i, name in enumerate(("px", "py", "qx", "qy", "ell")):
-            f[i, :n_seg] = local[name]
-        e = torch.zeros(max(max_seg, 1), dtype=torch.int32, device=dev)
-        e[:n_seg] = local["element"]
-        c = torch.zeros(max(max_trk, 1), dtype=torch.int64, device=dev)
-        c[:n_trk] = local["counts"]
-        # outputs in the concatenated form (world*rows, ...), which both RCCL and gloo accept
-        gf = torch.empty((world * 5, f.shape[1]), dtype=f.dtype, device=dev)
-        ge = torch.empty(world * e.numel(), dtype=e.dtype, device=dev)
-        gc = torch.empty(world * c.numel(), dtype=c.dtype, device=dev)
-        dist.all_gather_into_tensor(gf, f, group=group)
-        dist.all_gather_into_tensor(ge, e, group=group)
-        dist.all_gather_into_tensor(gc, c, group=group)
-        gf = gf.view(world, 5, -1)
-        ge = ge.view(world, -1)
-        gc = gc.view(world, -1)
-        out = {}
-        for i, name in enumerate(("px", "py", "qx", "qy", "ell")):
-            out[name] = torch.cat([gf[r, i, : int(all_sizes[r, 0])] for r in range(world)])
-        out["element"] = torch.cat([ge[r, : int(all_sizes[r, 0])] for r in range(world)])
-        counts = torch.cat([gc[r, : int(all_sizes[r, 1])] for r in range(world)])
-    offsets = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=offsets[1:])
-    out["offsets"] = offsets
-    return out
+    ``px, py, qx, qy, ell`` (float64) and ``element`` (int32), all on one device.  Returns ``offsets``
+    (int64, n_tracks+1) and the six arrays (views of ``gather``'s buffers, see ``SegmentGather``)."""
+    return (gather or SegmentGather(group))(local)
 
 
 class PipelinedVolumesAllReduce:

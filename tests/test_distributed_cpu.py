@@ -60,13 +60,16 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_shard_and_gather():
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_shard_and_gather(world):
+    """Sharding by Σℓ, all-reduce of volumes and the all-gather-v of the segment arrays (direct sends and receives into
+    the final buffers, distributed.SegmentGather) against the unsharded answer."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

@@ -19,6 +19,9 @@ for k in sorted(res, key=lambda k: -res[k].get("SQ_WAVE_CYCLES", 0)):
     for c, v in sorted(res[k].items()):
         print("   %-28s %.6g" % (c, v))
 if len(sys.argv) > 2:
-    json.dump({"source": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracing.jl_amd", "csrc", "librt_segmentize.so")
+    json.dump({"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+               "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
                          "(tools/pmc_passes.sh); mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
                "kernels": res}, open(sys.argv[2], "w"), indent=1)
