@@ -4,8 +4,10 @@
 # RayTracing.jl defines; NeutronTransport.jl consumes the result unchanged.
 #
 # NOT EXECUTED in the build container or on the GPU box (no Julia there); it mirrors, call
-# for call, the tested Python/ctypes binding in raytracing.jl_amd/_capi.py.  Field names of
-# Gridap's `Table` (`data`, `ptrs`) are as of Gridap 0.19.
+# for call, the tested Python/ctypes binding in raytracing.jl_amd/_capi.py, and tests/c_abi_smoke.c makes
+# the same call sequence with the same argument types from plain C on the GPU box (dlopen by path,
+# 1-based CSR ptrs, pinned fetch, "%d" substitution).  Field names of Gridap's `Table` (`data`, `ptrs`)
+# are as of Gridap 0.19.
 module RayTracingAMD
 
 using RayTracing
@@ -16,33 +18,102 @@ const LIB = get(ENV, "RT_SEGMENTIZE_LIB", "librt_segmentize.so")
 
 lasterror() = unsafe_string(ccall((:rt_last_error, LIB), Cstring, ()))
 
+# ---- the device-resident mesh is kept across calls: rt_mesh_create flattens the mesh, builds the nearest-node grid
+#      and the walk records with their certificates (≈12 ms of host work for the pincell mesh, plus the upload) —
+#      per mesh, not per segmentize!.  Keyed by the Mesh object (the reference's `Mesh` is an immutable struct, so it
+#      cannot carry a finalizer) and the device; released by `release_mesh!(mesh)` or at exit.
+const MESH_HANDLES = IdDict{Any,Dict{Int,Ptr{Cvoid}}}()
+const MESH_LOCK = ReentrantLock()
+
+function mesh_handle(mesh, device::Int)
+    lock(MESH_LOCK) do
+        per = get!(() -> Dict{Int,Ptr{Cvoid}}(), MESH_HANDLES, mesh)
+        get!(per, device) do
+            coords = get_node_coordinates(get_grid(mesh.model))
+            x = Float64[c[1] for c in coords]
+            y = Float64[c[2] for c in coords]
+            cell_nodes = Vector{Int32}(mesh.cell_nodes.data)            # 3 per cell, 1-based
+            nc_ptrs = Vector{Int32}(mesh.node_cells.ptrs)               # 1-based CSR offsets (accepted as is)
+            nc_data = Vector{Int32}(mesh.node_cells.data)
+            bb = Float64[mesh.bb_min[1], mesh.bb_min[2], mesh.bb_max[1], mesh.bb_max[2]]
+            hm = ccall((:rt_mesh_create, LIB), Ptr{Cvoid},
+                       (Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}),
+                       device, x, y, Int32(length(x)), cell_nodes, Int32(length(cell_nodes) ÷ 3), nc_ptrs, nc_data, bb)
+            hm == C_NULL && error("rt_mesh_create: " * lasterror())
+            hm
+        end
+    end
+end
+
+function release_mesh!(mesh)
+    lock(MESH_LOCK) do
+        per = pop!(MESH_HANDLES, mesh, nothing)
+        per === nothing && return
+        for hm in values(per)
+            ccall((:rt_mesh_destroy, LIB), Cvoid, (Ptr{Cvoid},), hm)
+        end
+    end
+    return nothing
+end
+
+__init__() = atexit(() -> foreach(release_mesh!, collect(keys(MESH_HANDLES))))
+
 """
-    segmentize_amd!(t::TrackGenerator{Float64}; k=5, rtol=Base.rtoldefault(Float64), device=0)
+    SegmentsView <: AbstractVector{Segment{Float64}}
+
+A track's segments read straight from the SoA arrays the library fetched (page-locked, owned by the kept track-set
+handle `keep`): `view[i]` builds `Segment(p, q, ℓ, τ, element)` on demand, so a consumer that only iterates
+(NeutronTransport.jl's sweep reads `ℓ`, `element` and fills `τ`) pays no per-segment allocation up front.  `τ` vectors
+are created on first access and then kept, one per segment, as in the reference (src/segment.jl:14,28).
+Opt in with `segmentize_amd!(t; materialize=false)`; the default rebuilds real `Vector{Segment}`s.
+"""
+struct SegmentsView <: AbstractVector{Segment{Float64}}
+    px::Vector{Float64}; py::Vector{Float64}; qx::Vector{Float64}; qy::Vector{Float64}
+    ℓ::Vector{Float64}; element::Vector{Int32}
+    first::Int; len::Int
+    τ::Dict{Int,Vector{Float64}}
+    keep::Any
+end
+Base.size(v::SegmentsView) = (v.len,)
+Base.IndexStyle(::Type{SegmentsView}) = IndexLinear()
+function Base.getindex(v::SegmentsView, i::Int)
+    @boundscheck checkbounds(v, i)
+    s = v.first + i - 1
+    τ = get!(() -> Float64[], v.τ, i)
+    return Segment(Point2D(v.px[s], v.py[s]), Point2D(v.qx[s], v.qy[s]), v.ℓ[s], τ, v.element[s])
+end
+
+# keeps the last track-set handle of a generator alive while SegmentsViews of it exist
+mutable struct TrackSetHandle
+    h::Ptr{Cvoid}
+    function TrackSetHandle(h)
+        x = new(h)
+        finalizer(x) do y
+            y.h != C_NULL && ccall((:rt_tracks_destroy, LIB), Cvoid, (Ptr{Cvoid},), y.h)
+            y.h = C_NULL
+        end
+        x
+    end
+end
+
+"""
+    segmentize_amd!(t::TrackGenerator{Float64}; k=5, rtol=Base.rtoldefault(Float64), device=0, materialize=true)
 
 Same contract as `RayTracing.segmentize!` (src/trackgenerator.jl:357-369): requires `trace!`,
 refills every `track.segments` in march order, overwrites `t.volumes`, returns `t`, and
 throws the reference's `ErrorException`s for point-location failure and Σℓ mismatch.
+`materialize=false` returns `(t, views)` instead, `views[uid]::SegmentsView` over the fetched SoA arrays, and leaves
+`track.segments` untouched (no per-segment allocation; see `SegmentsView`).
 """
 function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.rtoldefault(Float64),
-                         device::Int=0)
+                         device::Int=0, materialize::Bool=true)
     tracks = t.tracks_by_uid
     !isassigned(tracks, 1) && error("Segmentation is intended after tracing. Please, " *
                                     "call `trace!` first!")
-    mesh = t.mesh
-    # ---- flatten the mesh (src/mesh.jl:10-31) to the SoA arrays rt_mesh_create takes
-    coords = get_node_coordinates(get_grid(mesh.model))
-    x = Float64[c[1] for c in coords]
-    y = Float64[c[2] for c in coords]
-    cell_nodes = Vector{Int32}(mesh.cell_nodes.data)            # 3 per cell, 1-based
-    nc_ptrs = Vector{Int32}(mesh.node_cells.ptrs)               # 1-based CSR offsets (accepted as is)
-    nc_data = Vector{Int32}(mesh.node_cells.data)
-    bb = Float64[mesh.bb_min[1], mesh.bb_min[2], mesh.bb_max[1], mesh.bb_max[2]]
-    n_nodes, n_cells = Int32(length(x)), Int32(length(cell_nodes) ÷ 3)
-    hm = ccall((:rt_mesh_create, LIB), Ptr{Cvoid},
-               (Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}),
-               device, x, y, n_nodes, cell_nodes, n_cells, nc_ptrs, nc_data, bb)
-    hm == C_NULL && error("rt_mesh_create: " * lasterror())
+    # ---- the mesh handle (src/mesh.jl:10-31 flattened to the SoA arrays rt_mesh_create takes) is cached per mesh
+    hm = mesh_handle(t.mesh, device)
     ht = C_NULL
+    views = nothing
     try
         # ---- per-track inputs in uid order (src/track.jl:42-54); cos/sin by the host libm,
         #      exactly the values advance_step (src/point.jl:43) would use
@@ -83,20 +154,30 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
         spx = unsafe_wrap(Array, Ptr{Float64}(hp[1]), total); spy = unsafe_wrap(Array, Ptr{Float64}(hp[2]), total)
         sqx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total)
         sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total); sel = unsafe_wrap(Array, Ptr{Int32}(hp[6]), total)
-        Threads.@threads for u in 1:n
-            segs = tracks[u].segments
-            empty!(segs)
-            sizehint!(segs, offs[u+1] - offs[u])
-            for s in (offs[u]+1):offs[u+1]
-                push!(segs, Segment(Point2D(spx[s], spy[s]), Point2D(sqx[s], sqy[s]), sℓ[s], Float64[], sel[s]))
+        if materialize
+            # eager rebuild: real Vector{Segment}s, the reference's layout (src/segment.jl:23-33); one `τ` per segment
+            Threads.@threads for u in 1:n
+                segs = tracks[u].segments
+                cnt = Int(offs[u+1] - offs[u])
+                resize!(segs, cnt)                       # one growth per track instead of a push! per segment
+                base = Int(offs[u])
+                @inbounds for i in 1:cnt
+                    s = base + i
+                    segs[i] = Segment(Point2D(spx[s], spy[s]), Point2D(sqx[s], sqy[s]), sℓ[s], Float64[], sel[s])
+                end
             end
+        else
+            keep = TrackSetHandle(ht)   # the pinned arrays live as long as a view does
+            ht = C_NULL
+            views = [SegmentsView(spx, spy, sqx, sqy, sℓ, sel, Int(offs[u]) + 1, Int(offs[u+1] - offs[u]),
+                                  Dict{Int,Vector{Float64}}(), keep) for u in 1:n]
+            ccall((:rt_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), keep.h, t.volumes)
         end
-        ccall((:rt_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ht, t.volumes)
+        materialize && ccall((:rt_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ht, t.volumes)
     finally
         ht != C_NULL && ccall((:rt_tracks_destroy, LIB), Cvoid, (Ptr{Cvoid},), ht)
-        ccall((:rt_mesh_destroy, LIB), Cvoid, (Ptr{Cvoid},), hm)
     end
-    return t
+    return materialize ? t : (t, views)
 end
 
 # Opt-in replacement of the reference entry point:  RayTracingAMD.install!()

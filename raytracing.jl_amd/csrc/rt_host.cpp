@@ -72,6 +72,14 @@ int32_t rt_trace(const double *bb, int32_t n_azim, const int64_t *ntx, const int
                  double *A, double *B, double *C, int8_t *bc_fwd, int8_t *bc_bwd, int8_t *dir_fwd, int8_t *dir_bwd,
                  int64_t *next_fwd, int64_t *next_bwd) {
     if (!bb || !ntx || !nty || !bcs || n_azim <= 0 || n_azim % 4) { set_error("rt_trace: bad arguments"); return RT_ERR_INVALID; }
+    if (!phis || !delta_s || !omega || !azim_idx || !track_idx || !px || !py || !qx || !qy || !phi || !cos_phi || !sin_phi || !ell ||
+        !A || !B || !C || !bc_fwd || !bc_bwd || !dir_fwd || !dir_bwd || !next_fwd || !next_bwd) {
+        set_error("rt_trace: null output array");
+        return RT_ERR_INVALID;
+    }
+    for (int i = 0; i < n_azim / 2; ++i)
+        if (ntx[i] <= 0 || nty[i] <= 0) { set_error("rt_trace: track counts must be positive (angle %d)", i + 1); return RT_ERR_INVALID; }
+    try {
     const int n2 = n_azim / 2, n4 = n_azim / 4;
     const double Dx = bb[2] - bb[0], Dy = bb[3] - bb[1];
     std::vector<double> dxs(n2), dys(n2), tans(n2), coss(n2), sins(n2);
@@ -154,6 +162,10 @@ int32_t rt_trace(const double *bb, int32_t n_azim, const int64_t *ntx, const int
         }
     }
     return rc;
+    } catch (const std::exception &e) {  // no C++ exception may cross the C ABI (a Julia ccall / ctypes caller would abort)
+        set_error("rt_trace: %s", e.what());
+        return RT_ERR_INVALID;
+    }
 }
 
 // ------------------------------------------------------------------ mesh ingest -----------
@@ -257,11 +269,26 @@ static bool finish_msh(rt_msh *M, std::string &why) {
 
 extern "C" {
 
+static rt_msh *msh_load_impl(const char *path);
+
 rt_msh *rt_msh_load(const char *path) {
     if (!path) { set_error("rt_msh_load: null path"); return nullptr; }
-    std::ifstream f(path);
+    try {
+        return msh_load_impl(path);
+    } catch (const std::exception &e) {  // bad_alloc / length_error from a hostile header must not cross the C ABI
+        set_error("rt_msh_load(%s): %s", path, e.what());
+        return nullptr;
+    }
+}
+
+static rt_msh *msh_load_impl(const char *path) {
+    std::ifstream f(path, std::ios::binary);
     if (!f) { set_error("rt_msh_load: cannot open %s", path); return nullptr; }
-    rt_msh *M = new rt_msh();
+    f.seekg(0, std::ios::end);
+    const long file_size = (long)f.tellg();  // every node / element takes at least two bytes of the file: bounds the counts
+    f.seekg(0, std::ios::beg);
+    struct Guard { rt_msh *p; ~Guard() { delete p; } } guard{new rt_msh()};
+    rt_msh *M = guard.p;
     {   // a file that starts with '{' is a Gridap JSON model
         int ch;
         while ((ch = f.peek()) != EOF && isspace(ch)) f.get();
@@ -271,15 +298,15 @@ rt_msh *rt_msh_load(const char *path) {
             std::string why;
             if (!load_gridap_json(buf.str(), M, why) || !finish_msh(M, why)) {
                 set_error("rt_msh_load(%s): %s", path, why.c_str());
-                delete M;
                 return nullptr;
             }
+            guard.p = nullptr;
             return M;
         }
     }
     std::string line;
     bool fmt_ok = false;
-    auto fail = [&](const char *why) -> rt_msh * { set_error("rt_msh_load(%s): %s", path, why); delete M; return nullptr; };
+    auto fail = [&](const char *why) -> rt_msh * { set_error("rt_msh_load(%s): %s", path, why); return nullptr; };
     while (std::getline(f, line)) {
         if (line.rfind("$MeshFormat", 0) == 0) {
             std::getline(f, line);
@@ -288,11 +315,13 @@ rt_msh *rt_msh_load(const char *path) {
         } else if (line.rfind("$Nodes", 0) == 0) {
             long nb, nn, mn, mx;
             f >> nb >> nn >> mn >> mx;
+            if (!f || nb < 0 || nn <= 0 || nn > file_size / 2 || nb > nn) return fail("bad $Nodes header");
             M->x.assign(nn, 0.0); M->y.assign(nn, 0.0);
             std::vector<char> seen(nn, 0);
             for (long b = 0; b < nb; ++b) {
                 long dim, tag, par, cnt;
                 f >> dim >> tag >> par >> cnt;
+                if (!f || cnt < 0 || cnt > nn) return fail("bad $Nodes block header");
                 std::vector<long> tags(cnt);
                 for (long k = 0; k < cnt; ++k) f >> tags[k];
                 for (long k = 0; k < cnt; ++k) {
@@ -307,9 +336,11 @@ rt_msh *rt_msh_load(const char *path) {
         } else if (line.rfind("$Elements", 0) == 0) {
             long nb, ne, mn, mx;
             f >> nb >> ne >> mn >> mx;
+            if (!f || nb < 0 || ne < 0 || ne > file_size / 2 || nb > ne) return fail("bad $Elements header");
             for (long b = 0; b < nb; ++b) {
                 long dim, tag, type, cnt;
                 f >> dim >> tag >> type >> cnt;
+                if (!f || cnt < 0 || cnt > ne) return fail("bad $Elements block header");
                 std::getline(f, line);
                 for (long k = 0; k < cnt; ++k) {
                     std::getline(f, line);
@@ -330,6 +361,7 @@ rt_msh *rt_msh_load(const char *path) {
         std::string why;
         if (!finish_msh(M, why)) return fail(why.c_str());
     }
+    guard.p = nullptr;
     return M;
 }
 

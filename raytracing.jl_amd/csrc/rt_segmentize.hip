@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
         for (int kk2 = 0; kk2 < P; ++kk2) all += sp.p_count[(int64_t)(base + kk2) * 64 + lane];
         if (all != total) atomicAdd(&fail_info[7], (unsigned long long)(all - total));
     }
+    // MAX_ITER counts the segments of a whole track (src/track.jl:104,119): the reference stops after 10000 of them and
+    // then fails its Σℓ check.  Pieces count on their own, so a track that reaches the limit is flagged and the host
+    // marches the batch again without splitting (practically never: est > MAX_ITER/2 already marches whole).
+    if (total >= kMaxIter) atomicAdd(&fail_info[21], 1ull);  // (word 21 of the control block)
     counts[u] = total;
     status[u] = st;
     if (st != RT_TRACK_OK) {
@@ -966,7 +970,7 @@ struct rt_tracks {
     DevBuf<int32_t> counts, status, element;
     DevBuf<int64_t> offsets, tile_sums;
     // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag,
-    // 20 ticket of the scan's "last block" step
+    // 20 ticket of the scan's "last block" step, 21 tracks that reached MAX_ITER segments in split mode
     DevBuf<unsigned long long> ctl;
 #ifdef RT_TIMING
     DevBuf<unsigned long long> dbg;
@@ -985,6 +989,7 @@ struct rt_tracks {
     double sum_ell = 0.0;
     int32_t azim_min = 1, azim_max = 0;  // range of azim_idx (checked against n_azim_2 by rt_segmentize)
     int64_t n_generic_records = 0;       // rt_last_stats
+    bool force_unsplit = false;  // a track reached MAX_ITER segments in split mode: this track set marches whole from now on
     int32_t last_march_waves = 0, last_split = 0, last_widek = 0;  // which instantiation of the march the last call launched
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     void *pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rt_fetch_segments_pinned
@@ -1148,7 +1153,45 @@ int32_t rt_device_count(void) {
     return n;
 }
 
+static rt_mesh *mesh_create_impl(int32_t device, const double *x, const double *y, int32_t n_nodes, const int32_t *cell_nodes,
+                                 int32_t n_cells, const int32_t *node_cells_ptrs, const int32_t *node_cells_data, const double *bb);
+static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const double *px, const double *py, const double *phi,
+                                     const double *cos_phi, const double *sin_phi, const double *A, const double *B, const double *C,
+                                     const double *ell, const int32_t *azim_idx);
+static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s, int32_t n_azim_2);
+
+// No C++ exception may cross the C ABI (a Julia ccall or a ctypes caller would end in std::terminate): the entry points
+// that allocate host memory catch what the standard library throws and report it through rt_last_error.
 rt_mesh *rt_mesh_create(int32_t device, const double *x, const double *y, int32_t n_nodes,
+                        const int32_t *cell_nodes, int32_t n_cells, const int32_t *node_cells_ptrs,
+                        const int32_t *node_cells_data, const double *bb) {
+    try {
+        return mesh_create_impl(device, x, y, n_nodes, cell_nodes, n_cells, node_cells_ptrs, node_cells_data, bb);
+    } catch (const std::exception &e) {
+        set_error("rt_mesh_create: %s", e.what());
+        return nullptr;
+    }
+}
+rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, const double *py, const double *phi,
+                            const double *cos_phi, const double *sin_phi, const double *A, const double *B, const double *C,
+                            const double *ell, const int32_t *azim_idx) {
+    try {
+        return tracks_create_impl(mesh, n_tracks, px, py, phi, cos_phi, sin_phi, A, B, C, ell, azim_idx);
+    } catch (const std::exception &e) {
+        set_error("rt_tracks_create: %s", e.what());
+        return nullptr;
+    }
+}
+int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s, int32_t n_azim_2) {
+    try {
+        return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
+    } catch (const std::exception &e) {
+        set_error("rt_segmentize: %s", e.what());
+        return RT_ERR_INVALID;
+    }
+}
+
+static rt_mesh *mesh_create_impl(int32_t device, const double *x, const double *y, int32_t n_nodes,
                         const int32_t *cell_nodes, int32_t n_cells, const int32_t *node_cells_ptrs,
                         const int32_t *node_cells_data, const double *bb) {
     if (!x || !y || !cell_nodes || !node_cells_ptrs || !node_cells_data || !bb || n_nodes <= 0 || n_cells <= 0) {
@@ -1166,17 +1209,14 @@ rt_mesh *rt_mesh_create(int32_t device, const double *x, const double *y, int32_
     }
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return nullptr; }
     rt_mesh *m = new rt_mesh();
+    struct Guard { rt_mesh *p; ~Guard() { if (p) free_mesh(p); } } guard{m};  // released on success
     m->device = device;
     if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipStreamCreate failed");
-        delete m;
         return nullptr;
     }
     m->stream = m->own_stream;
-    if (build_mesh(m, x, y, n_nodes, cell_nodes, n_cells, node_cells_ptrs, node_cells_data, bb) != RT_SUCCESS) {
-        free_mesh(m);
-        return nullptr;
-    }
+    if (build_mesh(m, x, y, n_nodes, cell_nodes, n_cells, node_cells_ptrs, node_cells_data, bb) != RT_SUCCESS) return nullptr;
     // development knob: RT_OPTIONS="name=value,name=value" applies rt_set_option at creation
     if (const char *env = getenv("RT_OPTIONS")) {
         std::string e(env);
@@ -1190,6 +1230,7 @@ rt_mesh *rt_mesh_create(int32_t device, const double *x, const double *y, int32_
             pos = end + 1;
         }
     }
+    guard.p = nullptr;
     return m;
 }
 
@@ -1231,7 +1272,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     return RT_ERR_INVALID;
 }
 
-rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, const double *py,
+static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const double *px, const double *py,
                             const double *phi, const double *cos_phi, const double *sin_phi, const double *A,
                             const double *B, const double *C, const double *ell, const int32_t *azim_idx) {
     if (!mesh || n_tracks < 0 || n_tracks > 0x7fffffff ||
@@ -1241,6 +1282,7 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     }
     if (hipSetDevice(mesh->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     rt_tracks *t = new rt_tracks();
+    struct Guard { rt_tracks *p; ~Guard() { if (p) free_tracks(p); } } guard{t};  // released on success
     t->mesh = mesh;
     t->n = n_tracks;
     hipStream_t s = mesh->stream;
@@ -1270,7 +1312,6 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
         t->azim_max = *std::max_element(azim_idx, azim_idx + n);
         if (t->azim_min < 1) {  // δs[azim_idx] is read on the device (fill_volumes, src/trackgenerator.jl:379-382)
             set_error("rt_tracks_create: azim_idx must be 1-based (smallest value %d)", t->azim_min);
-            delete t;
             return nullptr;
         }
     }
@@ -1324,7 +1365,6 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
     if (!ok) {
         if (g_last_error.empty()) set_error("rt_tracks_create: upload failed");
-        free_tracks(t);
         return nullptr;
     }
     rt::DTracks &d = t->d;
@@ -1333,6 +1373,7 @@ rt_tracks *rt_tracks_create(rt_mesh *mesh, int64_t n_tracks, const double *px, c
     d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
     d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
     d.n = n_tracks;
+    guard.p = nullptr;
     return t;
 }
 
@@ -1342,7 +1383,7 @@ void rt_tracks_destroy(rt_tracks *tracks) {
     free_tracks(tracks);
 }
 
-int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s,
+static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s,
                       int32_t n_azim_2) {
     if (!t || !delta_s || n_azim_2 <= 0) { set_error("rt_segmentize: bad arguments"); return RT_ERR_INVALID; }
     if (k < 0) {  // knn(kdtree, x, k, ...) rejects a negative k (src/mesh.jl:123); any k >= 0 is honoured
@@ -1395,7 +1436,7 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
     out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
     rt::DStage stg{};
     rt::DSplit sp{};
-    const bool split = m->single_pass && t->n_vwaves > 0;
+    const bool split = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit;
     if (split) {
         sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
         sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
@@ -1563,6 +1604,10 @@ int64_t rt_segmentize(rt_tracks *t, double tiny_step, int32_t k, double rtol, co
                 RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
                 if (int rc = launch_volumes()) return rc;
                 RT_HIP(hipStreamSynchronize(s));
+            }
+            if (!cur[1] && split && h_res[21] != 0) {
+                t->force_unsplit = true;
+                return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
             }
             if (!cur[1]) break;
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }

@@ -1,0 +1,128 @@
+/*
+ * c_abi_smoke.c — a non-Python caller of the C ABI (include/rt_segmentize.h), in plain C.
+ *
+ * Makes the call sequence of the Julia shim (julia/RayTracingAMD.jl: segmentize_amd!) with the shim's argument
+ * types: dlopen of the library by path (what Julia's `ccall((:sym, LIB), ...)` does), 1-based CSR `ptrs` as
+ * Gridap's Table holds them, rt_mesh_create -> rt_tracks_create -> rt_segmentize -> rt_failed_tracks (+ the
+ * "%d" -> uid substitution into rt_status_message's text) -> rt_fetch_offsets -> rt_fetch_segments_pinned ->
+ * rt_fetch_volumes -> destroy.  Inputs come from the library's own host rows (rt_msh_load, rt_trace_counts,
+ * rt_trace), so no Julia or Python is involved.  Prints one JSON line with order-sensitive checksums of every
+ * result array; tests/test_gpu_c_abi.py compares them with the checker's arrays.
+ *
+ * Build: gcc -O1 -std=c11 -o c_abi_smoke c_abi_smoke.c -ldl     (no link against the library: it is dlopen'ed)
+ * Run:   c_abi_smoke <librt_segmentize.so> <mesh.msh> <n_azim> <delta> [fail_uid]
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <inttypes.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rt_segmentize.h" /* types, constants and the prototypes the pointers below must match */
+
+#define LOAD(name)                                                          \
+    __typeof__(&name) p_##name = (__typeof__(&name))dlsym(lib, #name);      \
+    if (!p_##name) { fprintf(stderr, "missing symbol %s\n", #name); return 2; }
+
+static uint64_t sum_bits64(const void *a, int64_t n) {  /* Σ (i+1)·bits_i mod 2^64: order-sensitive, cheap to mirror in numpy */
+    const uint64_t *w = (const uint64_t *)a;
+    uint64_t s = 0;
+    for (int64_t i = 0; i < n; ++i) s += (uint64_t)(i + 1) * w[i];
+    return s;
+}
+static uint64_t sum_bits32(const int32_t *a, int64_t n) {
+    uint64_t s = 0;
+    for (int64_t i = 0; i < n; ++i) s += (uint64_t)(i + 1) * (uint64_t)(uint32_t)a[i];
+    return s;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 5) { fprintf(stderr, "usage: %s lib mesh.msh n_azim delta [fail_uid]\n", argv[0]); return 2; }
+    const int32_t n_azim = atoi(argv[3]);
+    const double delta = atof(argv[4]);
+    const int64_t fail_uid = argc > 5 ? atoll(argv[5]) : 0; /* 1-based: spoil this track's length so that its Σℓ check fails */
+    void *lib = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    LOAD(rt_abi_version) LOAD(rt_last_error) LOAD(rt_status_message) LOAD(rt_device_count)
+    LOAD(rt_mesh_create) LOAD(rt_mesh_destroy) LOAD(rt_mesh_info) LOAD(rt_tracks_create) LOAD(rt_tracks_destroy)
+    LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_volumes)
+    LOAD(rt_msh_load) LOAD(rt_msh_sizes) LOAD(rt_msh_fetch) LOAD(rt_msh_free) LOAD(rt_trace_counts) LOAD(rt_trace)
+    if (p_rt_abi_version() != RT_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
+    if (p_rt_device_count() < 1) { fprintf(stderr, "no GPU\n"); return 3; }
+
+    /* ---- Mesh(model): the arrays the shim flattens out of Gridap (src/mesh.jl:10-31) */
+    rt_msh *msh = p_rt_msh_load(argv[2]);
+    if (!msh) { fprintf(stderr, "rt_msh_load: %s\n", p_rt_last_error()); return 1; }
+    int32_t n_nodes = 0, n_cells = 0, nnz = 0;
+    p_rt_msh_sizes(msh, &n_nodes, &n_cells, &nnz);
+    double *x = malloc(sizeof(double) * n_nodes), *y = malloc(sizeof(double) * n_nodes), bb[4];
+    int32_t *cell_nodes = malloc(sizeof(int32_t) * 3 * (size_t)n_cells);
+    int32_t *nc_ptrs = malloc(sizeof(int32_t) * ((size_t)n_nodes + 1)), *nc_data = malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+    if (p_rt_msh_fetch(msh, x, y, cell_nodes, nc_ptrs, nc_data, bb)) { fprintf(stderr, "rt_msh_fetch: %s\n", p_rt_last_error()); return 1; }
+    p_rt_msh_free(msh);
+    for (int32_t i = 0; i <= n_nodes; ++i) nc_ptrs[i] += 1; /* Gridap's Table.ptrs is 1-based; the shim passes it as is */
+
+    /* ---- TrackGenerator ctor + trace! (host rows of the library) */
+    const int32_t n2 = n_azim / 2;
+    int64_t *ntx = malloc(sizeof(int64_t) * n2), *nty = malloc(sizeof(int64_t) * n2);
+    const int64_t n = p_rt_trace_counts(bb[2] - bb[0], bb[3] - bb[1], n_azim, delta, ntx, nty);
+    if (n < 0) { fprintf(stderr, "rt_trace_counts: %s\n", p_rt_last_error()); return 1; }
+    const int32_t bcs[4] = {1, 1, 1, 1}; /* all Reflective, as test/runtests.jl:8 */
+    double *phis = malloc(sizeof(double) * n2), *delta_s = malloc(sizeof(double) * n2), *omega = malloc(sizeof(double) * n2);
+    int32_t *azim = malloc(sizeof(int32_t) * n), *tidx = malloc(sizeof(int32_t) * n);
+    double *D[11];
+    for (int a = 0; a < 11; ++a) D[a] = malloc(sizeof(double) * (n > 0 ? n : 1));
+    double *px = D[0], *py = D[1], *qx_t = D[2], *qy_t = D[3], *phi = D[4], *cs = D[5], *sn = D[6], *ell = D[7], *A = D[8], *B = D[9], *C = D[10];
+    int8_t *b8[4];
+    for (int a = 0; a < 4; ++a) b8[a] = malloc((size_t)(n > 0 ? n : 1));
+    int64_t *nf = malloc(sizeof(int64_t) * n), *nb = malloc(sizeof(int64_t) * n);
+    if (p_rt_trace(bb, n_azim, ntx, nty, bcs, phis, delta_s, omega, azim, tidx, px, py, qx_t, qy_t, phi, cs, sn, ell, A, B, C, b8[0],
+                   b8[1], b8[2], b8[3], nf, nb)) { fprintf(stderr, "rt_trace: %s\n", p_rt_last_error()); return 1; }
+    if (fail_uid >= 1 && fail_uid <= n) ell[fail_uid - 1] *= 1.0 + 1e-6;
+
+    /* ---- the shim's sequence */
+    rt_mesh *hm = p_rt_mesh_create(0, x, y, n_nodes, cell_nodes, n_cells, nc_ptrs, nc_data, bb);
+    if (!hm) { fprintf(stderr, "rt_mesh_create: %s\n", p_rt_last_error()); return 1; }
+    double info[RT_MESH_INFO_COUNT];
+    char note[128];
+    p_rt_mesh_info(hm, info, RT_MESH_INFO_COUNT, note, sizeof note);
+    rt_tracks *ht = p_rt_tracks_create(hm, n, px, py, phi, cs, sn, A, B, C, ell, azim);
+    if (!ht) { fprintf(stderr, "rt_tracks_create: %s\n", p_rt_last_error()); return 1; }
+    const double rtol = 1.4901161193847656e-8; /* Base.rtoldefault(Float64) */
+    const int64_t total = p_rt_segmentize(ht, 1e-8, 5, rtol, delta_s, n2);
+    if (total < 0) { fprintf(stderr, "rt_segmentize: %s\n", p_rt_last_error()); return 1; }
+    int64_t n_failed = 0, first_uid = 0;
+    int32_t first_status = 0;
+    p_rt_failed_tracks(ht, &n_failed, &first_uid, &first_status);
+    char message[512] = "";
+    if (n_failed > 0) { /* error(replace(msg, "%d" => string(uid))) */
+        const char *msg = p_rt_status_message(first_status);
+        const char *at = strstr(msg, "%d");
+        if (at) snprintf(message, sizeof message, "%.*s%" PRId64 "%s", (int)(at - msg), msg, first_uid, at + 2);
+        else snprintf(message, sizeof message, "%s", msg);
+    }
+    int64_t *offs = malloc(sizeof(int64_t) * ((size_t)n + 1));
+    int32_t *status = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    if (p_rt_fetch_offsets(ht, offs, status)) { fprintf(stderr, "rt_fetch_offsets: %s\n", p_rt_last_error()); return 1; }
+    void *hp[6];
+    if (p_rt_fetch_segments_pinned(ht, hp)) { fprintf(stderr, "rt_fetch_segments_pinned: %s\n", p_rt_last_error()); return 1; }
+    double *volumes = malloc(sizeof(double) * n_cells);
+    if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
+    double vsum = 0.0;
+    for (int32_t c = 0; c < n_cells; ++c) vsum += volumes[c];
+    /* per-track rebuild as the shim does it: walk the CSR ranges once (here: just check they tile the arrays) */
+    int64_t walked = 0;
+    for (int64_t u = 0; u < n; ++u) walked += offs[u + 1] - offs[u];
+    printf("{\"n_tracks\": %" PRId64 ", \"total\": %" PRId64 ", \"walked\": %" PRId64 ", \"n_failed\": %" PRId64
+           ", \"first_uid\": %" PRId64 ", \"first_status\": %d, \"message\": \"%s\", \"walk_enabled\": %d, "
+           "\"sum_offsets\": %" PRIu64 ", \"sum_status\": %" PRIu64 ", \"px\": %" PRIu64 ", \"py\": %" PRIu64 ", \"qx\": %" PRIu64
+           ", \"qy\": %" PRIu64 ", \"ell\": %" PRIu64 ", \"element\": %" PRIu64 ", \"volumes_sum\": %.17g, \"tracks_px\": %" PRIu64 "}\n",
+           n, total, walked, n_failed, first_uid, first_status, message, (int)info[RT_MESH_INFO_WALK_ENABLED],
+           sum_bits64(offs, n + 1), sum_bits32(status, n), sum_bits64(hp[0], total), sum_bits64(hp[1], total), sum_bits64(hp[2], total),
+           sum_bits64(hp[3], total), sum_bits64(hp[4], total), sum_bits32((const int32_t *)hp[5], total), vsum, sum_bits64(px, n));
+    p_rt_tracks_destroy(ht);
+    p_rt_mesh_destroy(hm);
+    return 0;
+}

@@ -1,0 +1,73 @@
+"""tests/c_abi_smoke.c: a plain-C caller of the C ABI that makes the Julia shim's call sequence (dlopen by path,
+1-based CSR ptrs, pinned fetch, "%d" substitution into the status message).  Without a GPU the harness must build and
+the library must refuse to compute; on the GPU box its result checksums must equal the checker's, bit for bit."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "c_abi_smoke.c")
+EXE = os.path.join(ROOT, "tests", "build", "c_abi_smoke")
+LIB = os.path.join(ROOT, "raytracing.jl_amd", "csrc", "librt_segmentize.so")
+
+
+def _build():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror", "-o", EXE, SRC, "-ldl"])
+    return EXE
+
+
+def _bits64(a):
+    w = np.ascontiguousarray(a).view(np.uint64)
+    return int((np.arange(1, len(w) + 1, dtype=np.uint64) * w).sum(dtype=np.uint64))
+
+
+def _bits32(a):
+    w = np.ascontiguousarray(a, np.int32).view(np.uint32).astype(np.uint64)
+    return int((np.arange(1, len(w) + 1, dtype=np.uint64) * w).sum(dtype=np.uint64))
+
+
+def test_harness_builds_and_library_refuses_without_gpu(rt):
+    exe = _build()
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), "8", "0.02"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no GPU" in r.stderr  # rt_device_count() == 0: nothing is computed on the host
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_azim,delta", [(8, 0.02), (32, 5e-3)])
+def test_c_caller_matches_checker(rt, orc, n_azim, delta):
+    exe = _build()
+    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), str(n_azim), str(delta)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    model = rt.GmshDiscreteModel(rt.data_path("pincell.msh"))
+    tg = rt.TrackGenerator(model, n_azim, delta)
+    rt.trace(tg)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi, n_threads=0)
+    aq = tg.azimuthal_quadrature
+    vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
+    assert got["n_tracks"] == tg.n_total_tracks and got["tracks_px"] == _bits64(tg.px)  # same inputs
+    assert got["total"] == ref["total"] == got["walked"] and got["n_failed"] == 0 and got["walk_enabled"] == 1
+    assert got["sum_offsets"] == _bits64(ref["offsets"]) and got["sum_status"] == 0
+    for k in ("px", "py", "qx", "qy", "ell"):
+        assert got[k] == _bits64(ref[k]), k
+    assert got["element"] == _bits32(ref["element"])
+    assert abs(got["volumes_sum"] - vol.sum()) < 1e-10
+
+
+@pytest.mark.gpu
+def test_c_caller_reports_the_reference_error_text(rt):
+    exe = _build()
+    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), "8", "0.02", "17"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    assert got["n_failed"] == 1 and got["first_uid"] == 17 and got["first_status"] == 2
+    assert got["message"].startswith("Track with `uid` 17 has a length that do not match")

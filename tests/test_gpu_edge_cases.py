@@ -254,3 +254,30 @@ def test_pinned_fetch_equals_plain_fetch(rt, traced):
     c = dt.fetch_segments_pinned()  # buffers are reused
     for k in a:
         assert np.array_equal(a[k], c[k]), k
+
+
+def test_max_iter_counts_whole_tracks_even_when_marched_in_pieces(rt, orc):
+    """MAX_ITER = 10000 segments per track (src/track.jl:104,119): the reference stops there and its Σℓ check then
+    fails.  A band of 48000 needle cells crossed lengthwise by the shallowest tracks gives such tracks, while the
+    mesh-wide estimate (few cells elsewhere) says a track has a few hundred segments — so the batch is marched in
+    pieces, each far below the limit.  The device must still report what the reference reports."""
+    from scipy.spatial import Delaunay
+
+    n_band, h = 24000, 0.016
+    xs = np.linspace(0.0, 1.0, n_band + 1)
+    pts = [(x, 0.500) for x in xs[1:-1]] + [(x, 0.500 + h) for x in xs[1:-1]]
+    g = np.linspace(0.0, 1.0, 11)
+    pts += [(x, y) for x in g for y in g if not (0.45 < y < 0.56)] + [(0.0, 0.5), (1.0, 0.5), (0.0, 0.5 + h), (1.0, 0.5 + h)]
+    xy = np.asarray(pts)
+    cells = np.sort(Delaunay(xy).simplices.astype(np.int32) + 1, axis=1)
+    a, b, c = xy[cells[:, 0] - 1], xy[cells[:, 1] - 1], xy[cells[:, 2] - 1]
+    area2 = np.abs((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1]))
+    model = rt.DiscreteModel(xy, cells[area2 > 1e-14])
+    tg = rt.TrackGenerator(model, 256, 0.05)
+    rt.trace(tg)
+    ref = _oracle(orc, tg)
+    counts = np.diff(ref["offsets"])
+    assert counts.max() == 10000 and np.any((ref["status"] == 2) & (counts == 10000)), (counts.max(), np.bincount(ref["status"]))
+    rt.segmentize(tg, check=False)  # default options: this small batch is split into pieces
+    assert tg.device_tracks.stats()["split"] == 0, "the call must have fallen back to whole tracks"
+    _same(tg, ref, check_volumes=False)
