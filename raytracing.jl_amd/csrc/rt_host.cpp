@@ -202,7 +202,7 @@ static size_t json_match(const std::string &s, size_t open) {  // index of the b
     return std::string::npos;
 }
 template <typename T, typename Conv>
-static bool json_numbers(const std::string &s, const char *after_key, std::vector<T> &out, Conv conv) {
+static bool json_numbers(const std::string &, const char *after_key, std::vector<T> &out, Conv conv) {
     const char *p = after_key;
     while (*p && *p != '[') { if (*p != ':' && !isspace((unsigned char)*p)) return false; ++p; }
     if (*p != '[') return false;

@@ -157,3 +157,17 @@ def test_record_limit_switches_walk_off(rt, pincell, monkeypatch):
     assert p["info"]["walk_ok"] == 0 and p["info"]["records_walk"] == 0 and "too many cells" in p["note"]
     monkeypatch.delenv("RT_TEST_WALK_RECORD_LIMIT")
     assert hm.prep(rt.Mesh(pincell))["info"]["walk_ok"] == 1
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """csrc/rt_host.cpp, csrc/rt_mesh_prep.hpp, the device geometry header on the host and the checker under
+    AddressSanitizer + UBSan over fixtures, seeded fuzz meshes (degenerate cell, non-manifold edge included) and
+    malformed mesh files (tests/sanitize/run.sh; the 200-mesh log is kept as profiles/r02/host_sanitizers.log)."""
+    import subprocess
+
+    log = tmp_path / "san.log"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["bash", os.path.join(root, "tests", "sanitize", "run.sh"), "15", str(log)], stdout=subprocess.DEVNULL)
+    text = log.read_text()
+    assert text.count("exit code: 0") == 2 and "ERROR" not in text and "runtime error" not in text, text[-2000:]
+    assert "12 refused" in text and "walk on == walk off == checker: yes" in text
