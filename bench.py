@@ -79,9 +79,12 @@ def pmc_traffic():
 
 
 def kernel_names(stats):
+    """Names of the kernels behind the three timed phases.  split = 2 (hybrid): the whole-track kernel named here runs
+    beside the split kernel that marches the longest waves in pieces; the phase time covers both."""
     w = stats["march_waves"]
-    return {"march": "rt::k_march<2, %d, %s, %s>" % (w, "true" if stats["split"] else "false", "true" if stats["wide_k"] else "false"),
-            "compact": "rt::k_compact3<%s>" % ("true" if stats["split"] else "false"), "scan": "rt::k_scan_write"}
+    sp = stats["split"] == 1
+    return {"march": "rt::k_march<2, %d, %s, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false"),
+            "compact": "rt::k_compact3<%s>" % ("true" if sp else "false"), "scan": "rt::k_scan_write"}
 
 
 def make_tg(rt, wl):
@@ -426,6 +429,7 @@ def _main(real_stdout):
                 "tracks_rank0": int(hi - lo), "segments_rank0": int(local_total),
                 "sharding": "contiguous uid ranges balanced by Σℓ; all-reduce(sum) of volumes inside the step" if world > 1 else "none",
                 "tiny_step": tg.tiny_step, "k": 5, "rtol": rt.RTOL_DEFAULT, "failed_tracks": failed_tracks,
+                "march_plan": {0: "whole tracks", 1: "every track in pieces", 2: "hybrid: the longest waves in pieces beside the whole-track march"}[stats["split"]],
                 "regime": {"walk_enabled": info["walk_enabled"], "records_walkable": info["records_walk"], "records": info["records"],
                            "walk_records_rank0": stats["walk_records"], "generic_records_rank0": stats["generic_records"]},
                 "library_sha256": lib_sha256(),

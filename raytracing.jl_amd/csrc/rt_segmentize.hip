@@ -188,25 +188,27 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
     if (u >= t.n) return;
     const int32_t w = (int32_t)(u >> 6), lane = (int32_t)(u & 63);
     const int32_t P = sp.w_P[w], base = sp.w_base[w];
+    if (P == 0) return;  // hybrid mode: this wave of tracks was marched whole by the non-split kernel
     for (int k = 0; k < P; ++k) sp.p_valid[(int64_t)(base + k) * 64 + lane] = 0;
     int32_t total = 0, st = RT_TRACK_OK;
     double sum = 0.0;
     int k = 0;
 #ifdef RT_STATS
-    {
-        unsigned long long alive = 1, cnt_all = 0;
+    {   // development statistics of the split plan: control-block words 22.. (tracks, live seeds, pieces, records marched)
+        unsigned long long alive = 0, cnt_all = 0;
         for (int kk2 = 0; kk2 < P; ++kk2) {
             if (kk2 > 0 && sp.s_el[(int64_t)(base + kk2) * 64 + lane] >= 0) ++alive;
             cnt_all += (unsigned long long)sp.p_count[(int64_t)(base + kk2) * 64 + lane];
         }
-        atomicAdd(&fail_info[3], alive);
-        atomicAdd(&fail_info[4], (unsigned long long)P);
-        atomicAdd(&fail_info[5], cnt_all);
+        atomicAdd(&fail_info[22], 1ull);
+        atomicAdd(&fail_info[23], alive);
+        atomicAdd(&fail_info[24], (unsigned long long)(P - 1));
+        atomicAdd(&fail_info[25], cnt_all);
     }
 #endif
     for (int guard = 0; guard < P; ++guard) {
 #ifdef RT_STATS
-        atomicAdd(&fail_info[2], 1ull);
+        atomicAdd(&fail_info[26], 1ull);  // pieces kept
 #endif
         const int64_t pi = (int64_t)(base + k) * 64 + lane;
         const int32_t c = sp.p_count[pi], fl = sp.p_flags[pi];
@@ -273,10 +275,15 @@ __device__ __forceinline__ const RT_K DStage *march_stage_args() {
 // WIDEK: k > kMaxK (the knn fallback of find_element serves its node list in batches); a separate instantiation, so that
 // the march of the usual k keeps its register budget.
 template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false>
-__global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
+__global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 3 : 1) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
                                                       unsigned long long *__restrict__ fail_info, DSplit sp) {
+    // The split plan's tables are used at the start and the end of a piece and when a record of the target's cell comes
+    // up — never in the steady march: they are read from the argument segment where they are used (as `stg` is), so
+    // that their 17 pointers do not occupy scalar registers across the loop.
+    const RT_K DSplit *spk = (const RT_K DSplit *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, sp));
+    (void)sp;
     constexpr bool FUSE = WAVES > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
@@ -304,11 +311,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     int32_t pk = 0, pP = 1, pw = 0;  // SPLIT: piece index, pieces per track, wave of tracks
     if (SPLIT) {
         const int64_t vidx = (int64_t)blockIdx.x * WAVES + wib;  // position in the dispatch order
-        if (vidx < sp.n_vwaves) {
-            wave_id = sp.vorder[vidx];
-            pw = sp.vw_wave[wave_id];
-            pk = sp.vw_k[wave_id];
-            pP = sp.w_P[pw];
+        if (vidx < spk->n_vwaves) {
+            wave_id = spk->vorder[vidx];
+            pw = spk->vw_wave[wave_id];
+            pk = spk->vw_k[wave_id];
+            pP = spk->w_P[pw];
             slot = (int64_t)pw * 64 + lane;
         } else {
             slot = t.n;  // padding wave of the last workgroup
@@ -316,24 +323,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     }
     if (slot < t.n) {
     const int32_t u = SPLIT ? (int32_t)slot : t.perm[slot];
-    const int64_t pi = wave_id * 64 + lane;  // SPLIT: this lane's piece
-    // SPLIT: the seed this piece starts from (k >= 1) and the next live seed, at which it stops
+    // SPLIT: the seed this piece starts from (k >= 1) and the next live seed, at which it stops.  Only the target's cell
+    // and piece index live in registers across the march; its p and q are read when a record of that cell comes up.
     bool seed_pending = false, piece_dead = false, matched = false;
-    int32_t tgt_el = -1, tgt_k = 0;
-    double tgt_px = 0, tgt_py = 0, tgt_qx = 0, tgt_qy = 0;
+    int32_t tgt_el = -1, tgt_pj = 0;  // tgt_pj: index of the target piece's seed (canonical virtual wave * 64 + lane)
     if (SPLIT) {
+        const int64_t pi = wave_id * 64 + lane;
         if (pk > 0) {
-            if (sp.s_el[pi] < 0) piece_dead = true;
+            if (spk->s_el[pi] < 0) piece_dead = true;
             else seed_pending = true;
         }
         for (int kk2 = pk + 1; kk2 < pP; ++kk2) {
-            const int64_t pj = (int64_t)(sp.w_base[pw] + kk2) * 64 + lane;
-            const int32_t e = sp.s_el[pj];
-            if (e >= 0) {
-                tgt_el = e; tgt_k = kk2;
-                tgt_px = sp.s_px[pj]; tgt_py = sp.s_py[pj]; tgt_qx = sp.s_qx[pj]; tgt_qy = sp.s_qy[pj];
-                break;
-            }
+            const int64_t pj = (int64_t)(spk->w_base[pw] + kk2) * 64 + lane;
+            const int32_t e = spk->s_el[pj];
+            if (e >= 0) { tgt_el = e; tgt_pj = (int32_t)pj; break; }
         }
     }
     const double tA = t.A[u], tB = t.B[u], tC = t.C[u];
@@ -398,9 +401,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
         int res = kWalkEmit;
         if (from_seed) {
             // first segment of a seeded piece: the seed itself (k_seed), then march on from its exit point
-            element = sp.s_el[pi];
-            px = sp.s_px[pi]; py = sp.s_py[pi]; qx = sp.s_qx[pi]; qy = sp.s_qy[pi]; ell = sp.s_ell[pi];
-            const int seq = sp.s_eq[pi];
+            const int64_t pi = wave_id * 64 + lane;
+            element = spk->s_el[pi];
+            px = spk->s_px[pi]; py = spk->s_py[pi]; qx = spk->s_qx[pi]; qy = spk->s_qy[pi]; ell = spk->s_ell[pi];
+            const int seq = spk->s_eq[pi];
             if (m.walk_ok && seq >= 0) walk_enter(m, load_geo(m.geo), wk, element, seq);
             else { wk.T = element; wk.pred = -1; }
             seed_pending = false;
@@ -488,10 +492,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
             else { wk.T = element; wk.pred = -1; }
         }
         }
-        if (SPLIT && !from_seed && tgt_el >= 0 && element == tgt_el && qx == tgt_qx && qy == tgt_qy && px == tgt_px &&
-            py == tgt_py) {
-            matched = true;  // the next piece starts with exactly this segment: stop here
-            break;
+        if (SPLIT && !from_seed && element == tgt_el) {  // (tgt_el = -1: no target)
+            asm volatile("" ::: "memory");  // a real, rare branch: a record of the target's cell
+            if (qx == spk->s_qx[tgt_pj] && qy == spk->s_qy[tgt_pj] && px == spk->s_px[tgt_pj] && py == spk->s_py[tgt_pj]) {
+                matched = true;  // the next piece starts with exactly this segment: stop here
+                break;
+            }
         }
         if (MODE == kFill) {
             const int64_t o = base + i;
@@ -613,9 +619,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(DMesh m, DTracks t, DParam
     }
 #endif
     if (SPLIT) {
-        sp.p_count[pi] = i;
-        sp.p_flags[pi] = (matched ? 1 : 0) | (st << 8) | (tgt_k << 16);
-        sp.p_sum[pi] = sum_ell;
+        const int64_t pi = wave_id * 64 + lane;
+        const int32_t tgt_k = tgt_el >= 0 ? tgt_pj / 64 - spk->w_base[pw] : 0;  // piece index of the target within its wave
+        spk->p_count[pi] = i;
+        spk->p_flags[pi] = (matched ? 1 : 0) | (st << 8) | (tgt_k << 16);
+        spk->p_sum[pi] = sum_ell;
     } else if (MODE != kFill) {
         // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol)
         if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
@@ -946,6 +954,9 @@ struct rt_mesh {
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
     int split = -1;         // track splitting (see DSplit), read by rt_tracks_create: -1 auto (only batches that leave the chip
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
+    int hybrid = 0;        // 1: batches that fill the chip march only their longest waves in pieces, beside the whole-track march of the rest
+                           // (measured slower at every threshold on MI355X — the full batch is within 1.6x of its throughput floor — DESIGN.md §4)
+    int hybrid_pct = 55;   // ... those whose expected segment count exceeds this percentage of the batch's longest
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int test_volumes_fallback = 0;  // tests only: take the split mode's volumes recomputation path unconditionally
@@ -962,7 +973,7 @@ struct rt_tracks {
     rt_mesh *mesh = nullptr;
     int64_t n = 0;
     DevBuf<double> px, py, phi, cs, sn, A, B, C, ell;
-    DevBuf<int32_t> azim, perm;
+    DevBuf<int32_t> azim, perm, perm_whole;  // perm: march order of all tracks; perm_whole: of those the hybrid plan marches whole
     rt::DTracks d{};
     // results
     bool segmentized = false;
@@ -984,6 +995,10 @@ struct rt_tracks {
     int64_t pool_chunks = 0, chunks_needed_last = 0;
     // split mode (pieces of tracks)
     int32_t n_vwaves = 0;
+    bool hybrid = false;   // the split plan covers only the longest waves; perm[0 .. n_whole) lists the tracks marched whole
+    int64_t n_whole = 0;
+    hipStream_t aux_stream = nullptr;  // hybrid: the pieces march beside the whole tracks
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<int32_t> vorder, vw_wave, vw_k, w_base, w_P, s_el, s_eq, p_count, p_flags, p_valid, p_rel;
     DevBuf<double> s_px, s_py, s_qx, s_qy, s_ell, p_sum;
     double sum_ell = 0.0;
@@ -1104,7 +1119,7 @@ void pin_release_to_cache(rt_tracks *t);  // defined with rt_fetch_segments_pinn
 
 void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
-    t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release();
+    t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->perm_whole.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
     t->tile_sums.release(); t->ctl.release();
 #ifdef RT_TIMING
@@ -1121,6 +1136,9 @@ void free_tracks(rt_tracks *t) {
     t->s_px.release(); t->s_py.release(); t->s_qx.release(); t->s_qy.release(); t->s_ell.release(); t->p_sum.release();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->aux_stream) (void)hipStreamDestroy(t->aux_stream);
     delete t;
 }
 
@@ -1261,6 +1279,8 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
+    if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
@@ -1316,7 +1336,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         }
     }
     // split plan: pieces per wave of 64 consecutive uids, canonical numbering, dispatch order
-    std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P;
+    std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P, h_perm_whole;
     // Splitting pays when the batch has too few waves to fill the chip (the march is then bound by its
     // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420).  On a batch whose waves are all resident
     // anyway the split variant of the march plus its seed and resolve kernels costs more than shorter
@@ -1345,6 +1365,44 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         std::iota(h_vorder.begin(), h_vorder.end(), 0);
         std::stable_sort(h_vorder.begin(), h_vorder.end(), [&](int32_t a, int32_t b) { return piece_len[a] > piece_len[b]; });
         t->n_vwaves = nv;
+    } else if (mesh->split < 0 && mesh->hybrid && mesh->sort_mode == 2 && !auto_split && n > 0) {
+        // Hybrid plan for batches that fill the chip.  The march lasts as long as its longest track's chain while the
+        // mean track is half as long: only the waves whose expected segment count exceeds hybrid_pct of the longest are
+        // cut into pieces (marched by the split kernel on a second stream); all others keep the lean whole-track kernel.
+        const size_t nw = nw_all;
+        std::vector<double> west(nw, 0.0);
+        double est_max = 0.0;
+        for (size_t w = 0; w < nw; ++w) {
+            double lmax = 0.0;
+            for (size_t l = 0; l < 64 && w * 64 + l < n; ++l) lmax = std::max(lmax, ell[w * 64 + l]);
+            west[w] = lmax * mesh->kappa;
+            est_max = std::max(est_max, west[w]);
+        }
+        const double T = std::max(24.0, 0.01 * mesh->hybrid_pct * est_max);
+        h_w_base.assign(nw, 0); h_w_P.assign(nw, 0);
+        std::vector<double> piece_len;
+        int32_t nv = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            if (!(west[w] > T) || west[w] > 0.5 * rt::kMaxIter) continue;  // (MAX_ITER counts whole tracks, src/track.jl:104)
+            const int32_t P = std::min(4, (int32_t)std::ceil(west[w] / T));
+            if (P < 2) continue;
+            h_w_base[w] = nv; h_w_P[w] = P;
+            for (int32_t k = 0; k < P; ++k) { h_vw_wave.push_back((int32_t)w); h_vw_k.push_back(k); piece_len.push_back(west[w] / P); }
+            nv += P;
+        }
+        if (nv > 0) {
+            h_vorder.resize(nv);
+            std::iota(h_vorder.begin(), h_vorder.end(), 0);
+            std::stable_sort(h_vorder.begin(), h_vorder.end(), [&](int32_t a, int32_t b) { return piece_len[a] > piece_len[b]; });
+            t->n_vwaves = nv;
+            t->hybrid = true;
+            // the whole-track march's order: the remaining waves, longest first (the order `perm` already has)
+            for (size_t i = 0; i < n; ++i)
+                if (h_w_P[(size_t)perm[i] / 64] == 0) h_perm_whole.push_back(perm[i]);
+            t->n_whole = (int64_t)h_perm_whole.size();
+        } else {
+            h_w_base.clear(); h_w_P.clear();
+        }
     }
     bool ok = upload(t->px, px, n, s) == 0 && upload(t->py, py, n, s) == 0 && upload(t->phi, phi, n, s) == 0 &&
               upload(t->cs, cos_phi, n, s) == 0 && upload(t->sn, sin_phi, n, s) == 0 && upload(t->A, A, n, s) == 0 &&
@@ -1362,6 +1420,10 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     }
     for (auto &e : t->ev)
         if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
+    if (ok && t->hybrid)
+        ok = upload(t->perm_whole, h_perm_whole.data(), h_perm_whole.size(), s) == 0 && hipStreamCreateWithFlags(&t->aux_stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
     if (!ok) {
         if (g_last_error.empty()) set_error("rt_tracks_create: upload failed");
@@ -1436,7 +1498,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
     rt::DStage stg{};
     rt::DSplit sp{};
-    const bool split = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit;
+    // Track pieces (DSplit): every wave of a batch too small to fill the chip, or — hybrid plan — only the longest waves
+    // of a full batch, beside the whole-track march of the rest.  The hybrid plan needs the fused-volumes kernels of the
+    // usual k; a call that cannot use it (or any plan, once a track reached MAX_ITER segments) marches every track whole.
+    const bool widek_ = k > rt::kMaxK;
+    const size_t hist_bytes_ = (size_t)m->n_cells * sizeof(double);
+    const int fuse_waves_ = (3 * (hist_bytes_ + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || (n + 63) / 64 > 3072) ? 4 : 6;
+    const bool fuse_ = m->volumes_mode == 2 && m->fuse_volumes && 2 * (hist_bytes_ + fuse_waves_ * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 && !widek_;
+    const bool plan_ok = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit;
+    const bool hybrid = plan_ok && t->hybrid && fuse_;
+    const bool split = plan_ok && (!t->hybrid || hybrid);  // pieces are marched in this call
     if (split) {
         sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
         sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
@@ -1504,35 +1575,41 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
     const bool widek = k > rt::kMaxK;  // find_element's knn fallback beyond the in-register list: separate kernel instantiations
     const int64_t *march_offsets = nullptr;
+    hipStream_t march_stream = s;          // (the hybrid path launches its pieces on the auxiliary stream)
+    const rt::DTracks *march_tracks = &t->d;
+    const rt::DStage *march_stage = &stg;
     auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK>(unsigned blocks, size_t smem) -> int {
-        t->last_march_waves = WAVES; t->last_split = SPLIT ? 1 : 0; t->last_widek = WIDEK ? 1 : 0;
+        t->last_march_waves = WAVES; t->last_split = std::max(t->last_split, SPLIT ? 1 : 0); t->last_widek = WIDEK ? 1 : 0;
         if (smem > 48 * 1024)
             RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK>), dim3(blocks), dim3(64 * WAVES), smem, s, m->d, t->d, prm, t->counts.p,
-                           t->status.p, march_offsets, out, stg, d_fail, sp);
+        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK>), dim3(blocks), dim3(64 * WAVES), smem, march_stream, m->d, *march_tracks, prm,
+                           t->counts.p, t->status.p, march_offsets, out, *march_stage, d_fail, sp);
         return RT_SUCCESS;
     };
+    t->last_split = 0;
     if (!m->single_pass) RT_HIP(hipEventRecord(t->ev[0], s));  // single pass: the call is timed from ev[1], after the 2-µs prologue
     if (!m->single_pass) RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
     if (m->single_pass) {
         // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
         //      (or from what the previous call needed) and grown + re-run on overflow
-        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, split ? t->n_vwaves : n_waves) * rt::kMaxChunks));
+        // fill_volumes fused into the march when an LDS copy of `volumes` (+ 4 chunk tables) leaves room
+        // for two workgroups per CU; larger meshes use the separate k_volumes pass.
+        // The march fits three waves per SIMD (12 per CU): four-wave workgroups when three copies of the
+        // LDS histogram fit in the CU's 160 KB, six-wave workgroups (two copies) for larger meshes
+        // (six-wave workgroups measured -10 % march time on a batch that is resident at once, BWR-like C4, and
+        //  +5 % on one that takes many rounds, C5 on one GPU).  A wide k marches with the one-wave kernels only:
+        // fewer instantiations of a rare case.
+        const size_t hist_bytes = hist_bytes_;
+        const int fuse_waves = fuse_waves_;
+        const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
+        const bool fuse = fuse_;
+        const bool split_all = split && !hybrid;  // every wave in pieces (small batches, or "split" > 0)
+        const int64_t n_whole_waves = hybrid ? (t->n_whole + 63) / 64 : n_waves;
+        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, split_all ? t->n_vwaves : n_whole_waves + (hybrid ? t->n_vwaves : 0)) * rt::kMaxChunks));
         int64_t want = t->chunks_needed_last > 0
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
-                           : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * (split ? t->n_vwaves : n_waves) + 64;
+                           : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * ((split ? t->n_vwaves : 0) + (split_all ? 0 : n_whole_waves)) + 64;
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
-        // fill_volumes fused into the march when an LDS copy of `volumes` (+ 4 chunk tables) leaves room
-        // for two workgroups per CU; larger meshes use the separate k_volumes pass
-        // The 132-VGPR march fits three waves per SIMD (12 per CU): four-wave workgroups when three copies of the
-        // LDS histogram fit in the CU's 160 KB, six-wave workgroups (two copies) for larger meshes.
-        const size_t hist_bytes = (size_t)m->n_cells * sizeof(double);
-        // (six-wave workgroups measured -10 % march time on a batch that is resident at once, BWR-like C4, and
-        //  +5 % on one that takes many rounds, C5 on one GPU)
-        const int fuse_waves = (3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || n_waves > 3072) ? 4 : 6;
-        const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
-        // (a wide k marches with the one-wave kernels only: fewer instantiations of a rare case)
-        const bool fuse = m->volumes_mode == 2 && m->fuse_volumes && 2 * fuse_smem <= 158 * 1024 && !widek;
         fused_volumes_this_call = fuse;
         for (int attempt = 0;; ++attempt) {
             if (want > t->pool_chunks) {
@@ -1557,34 +1634,52 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, 32) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
                                t->volumes.p, m->n_cells);
             RT_HIP(hipEventRecord(t->ev[1], s));
+            // hybrid: the pieces (split kernel) use the chunk tables behind those of the whole-track waves
+            rt::DStage stg_pieces = stg;
+            if (hybrid) stg_pieces.ctab = stg.ctab + n_whole_waves * rt::kMaxChunks;
+            rt::DTracks d_whole = t->d;
+            if (hybrid) { d_whole.perm = as_global(t->perm_whole.p); d_whole.n = t->n_whole; }
             if (n > 0 && split) {
-                if (widek) hipLaunchKernelGGL(rt::k_seed<true>, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
-                else hipLaunchKernelGGL(rt::k_seed<false>, dim3((unsigned)t->n_vwaves), dim3(64), 0, s, m->d, t->d, prm, sp);
+                hipStream_t ps = s;  // the stream the pieces march on
+                if (hybrid) {
+                    ps = t->aux_stream;
+                    RT_HIP(hipEventRecord(t->ev_fork, s));
+                    RT_HIP(hipStreamWaitEvent(ps, t->ev_fork, 0));
+                }
+                if (widek) hipLaunchKernelGGL(rt::k_seed<true>, dim3((unsigned)t->n_vwaves), dim3(64), 0, ps, m->d, t->d, prm, sp);
+                else hipLaunchKernelGGL(rt::k_seed<false>, dim3((unsigned)t->n_vwaves), dim3(64), 0, ps, m->d, t->d, prm, sp);
                 int rc;
+                march_stream = ps; march_stage = &stg_pieces; march_tracks = &t->d;
                 if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, true, false>((unsigned)((t->n_vwaves + 3) / 4), fuse_smem);
                 else if (fuse) rc = march.template operator()<rt::kStage, 6, true, false>((unsigned)((t->n_vwaves + 5) / 6), fuse_smem);
                 else if (widek) rc = march.template operator()<rt::kStage, 1, true, true>((unsigned)t->n_vwaves, rt::kMaxChunks * sizeof(int32_t));
                 else rc = march.template operator()<rt::kStage, 1, true, false>((unsigned)t->n_vwaves, rt::kMaxChunks * sizeof(int32_t));
+                march_stream = s; march_stage = &stg;
                 if (rc) return rc;
-                hipLaunchKernelGGL(rt::k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t->d, prm, sp, t->counts.p,
+                hipLaunchKernelGGL(rt::k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ps, t->d, prm, sp, t->counts.p,
                                    t->status.p, d_fail);
-            } else if (n > 0) {
+                if (hybrid) RT_HIP(hipEventRecord(t->ev_join, ps));
+            }
+            if (n > 0 && !split_all) {  // whole tracks: all of them, or those the hybrid plan leaves whole
                 int rc;
-                if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, false, false>((unsigned)((n_waves + 3) / 4), fuse_smem);
-                else if (fuse) rc = march.template operator()<rt::kStage, 6, false, false>((unsigned)((n_waves + 5) / 6), fuse_smem);
-                else if (widek) rc = march.template operator()<rt::kStage, 1, false, true>(grid, rt::kMaxChunks * sizeof(int32_t));
-                else rc = march.template operator()<rt::kStage, 1, false, false>(grid, rt::kMaxChunks * sizeof(int32_t));
+                march_tracks = &d_whole;
+                if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, false, false>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
+                else if (fuse) rc = march.template operator()<rt::kStage, 6, false, false>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
+                else if (widek) rc = march.template operator()<rt::kStage, 1, false, true>((unsigned)n_whole_waves, rt::kMaxChunks * sizeof(int32_t));
+                else rc = march.template operator()<rt::kStage, 1, false, false>((unsigned)n_whole_waves, rt::kMaxChunks * sizeof(int32_t));
+                march_tracks = &t->d;
                 if (rc) return rc;
+                if (hybrid) RT_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
             }
             RT_HIP(hipEventRecord(t->ev[2], s));
             if (int rc = scan_counts(true, fuse)) return rc;
             RT_HIP(hipEventRecord(t->ev[3], s));  // every event record costs ≈4 µs of stream time: none is recorded twice
+            if (n > 0 && !split_all && n_whole_waves > 0)
+                hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_whole_waves), dim3(256), 0, s, d_whole,
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
             if (n > 0 && split)
                 hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
-            else if (n > 0)
-                hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_waves), dim3(256), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp);
             RT_HIP(hipEventRecord(t->ev[5], s));
             if (int rc = launch_volumes()) return rc;
             volumes_pass = !(fuse && n > 0);
@@ -1658,9 +1753,13 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             (double)fi[8] / fi[12], (double)fi[9] / fi[12], (double)fi[10] / fi[12], (double)fi[11] / fi[12], (double)fi[12] / fi[14], (double)fi[13] / fi[14]);
 #endif
 #ifdef RT_STATS
+    if (split)
+        fprintf(stderr, "[rt stats] split plan: %llu tracks, %llu of %llu seeds alive, %llu pieces kept, %llu records marched by pieces, %llu dropped\n",
+                h_res[22], h_res[23], h_res[24], h_res[26], h_res[25], fi[7]);
     fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
             fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
 #endif
+    if (hybrid) t->last_split = 2;
     t->total = total;
     t->n_generic_records = (int64_t)fi[15];
     t->n_failed = (int64_t)fi[0];
@@ -1801,7 +1900,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     stats[2] = t->chunks_needed_last;
     stats[3] = t->pool_chunks;
     if (n > 4) stats[4] = t->last_march_waves;
-    if (n > 5) stats[5] = t->last_split;
+    if (n > 5) stats[5] = t->last_split;  // 0 whole tracks, 1 pieces, 2 hybrid (pieces for the longest waves only)
     if (n > 6) stats[6] = t->last_widek;
     return RT_SUCCESS;
 }

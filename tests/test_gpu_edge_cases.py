@@ -281,3 +281,31 @@ def test_max_iter_counts_whole_tracks_even_when_marched_in_pieces(rt, orc):
     rt.segmentize(tg, check=False)  # default options: this small batch is split into pieces
     assert tg.device_tracks.stats()["split"] == 0, "the call must have fallen back to whole tracks"
     _same(tg, ref, check_volumes=False)
+
+
+@pytest.mark.parametrize("pct", [55, 80])
+def test_hybrid_plan_gives_identical_results(rt, traced, oracle_run, pct):
+    """"hybrid" = 1: on a batch that fills the chip only the longest waves are marched in pieces (split kernel, second
+    stream) beside the whole-track march of the rest.  An option kept for experiments; same records."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(128, 1e-3)
+    ref = oracle_run(tg)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("hybrid", 1)
+    dm.set_option("hybrid_pct", pct)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    for _ in range(2):
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    assert dt.stats()["split"] == 2
+    off, st = dt.fetch_offsets()
+    s = dt.fetch_segments()
+    assert np.array_equal(off, ref["offsets"]) and st.max() == 0
+    assert np.array_equal(s["element"], ref["element"])
+    for k in FIELDS:
+        assert np.array_equal(s[k], ref[k]), k
+    assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
+    # a wide k cannot use the plan: the same handle then marches every track whole
+    assert dt.segmentize(tg.tiny_step, 12, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    assert dt.stats()["split"] == 0 and np.array_equal(dt.fetch_segments()["element"], ref["element"])

@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 kernel trace of a few rt_segmentize calls (default options): per-kernel start / end of the last call, to see overlap.
+# usage (GPU box): bash tools/trace_one_call.sh <out_subdir> [gpu_modes args]
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/gpu_modes.py "$@" > $OUT/trace.log 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+f = sorted(glob.glob(sys.argv[1] + "/trace/*/*kernel_trace.csv"))[-1]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# last call = from the last k_prologue on
+idx = max(i for i, r in enumerate(rows) if "k_prologue" in r["Kernel_Name"])
+t0 = int(rows[idx]["Start_Timestamp"])
+for r in rows[idx:]:
+    print("%-60s start %8.1f us  end %8.1f us  (%.1f us)  queue %s" % (r["Kernel_Name"][:60], (int(r["Start_Timestamp"]) - t0) / 1e3,
+          (int(r["End_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?")))
+PY
