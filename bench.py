@@ -115,7 +115,8 @@ def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=Non
     tm = dt.timing()
     out = {"workload": wl["name"], "tracks": int(tg.n_total_tracks), "segments": int(total), "steps": steps,
            "ms_per_step": el / steps * 1e3, "value": total * steps / el, "unit": "segments/s",
-           "kernel_ms_last_step": {k: tm[k] for k in ("march", "scan", "compact", "total")}}
+           "kernel_ms_last_step": {k: tm[k] for k in ("march", "scan", "compact", "total")},
+           "device_GB_held_by_the_handle": dt.stats()["device_bytes"] / 1e9}
     dt.close()
     dm.close()
     return out
@@ -432,6 +433,7 @@ def _main(real_stdout):
                 "march_plan": {0: "whole tracks", 1: "every track in pieces", 2: "hybrid: the longest waves in pieces beside the whole-track march"}[stats["split"]],
                 "regime": {"walk_enabled": info["walk_enabled"], "records_walkable": info["records_walk"], "records": info["records"],
                            "walk_records_rank0": stats["walk_records"], "generic_records_rank0": stats["generic_records"]},
+                "device_GB_held_by_rank0_handle": stats["device_bytes"] / 1e9,
                 "library_sha256": lib_sha256(),
             },
             "roofline": {

@@ -178,7 +178,8 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
 /* Counters of the last rt_segmentize on this handle: stats[0] segment records, stats[1] records produced by the
  * literal step (the walk step produced the rest; track pieces' seeds in split mode count as neither), stats[2]
  * staging chunks used, stats[3] staging chunks allocated; if n allows: stats[4] waves per workgroup of the march kernel
- * the call launched, stats[5] 1 if it marched track pieces (split mode), stats[6] 1 for the wide-k instantiation.
+ * the call launched, stats[5] 1 if it marched track pieces (split mode; 2: only the longest waves), stats[6] 1 for the wide-k instantiation,
+ * stats[7] bytes of device memory this handle holds (inputs, staging pools, tables, results).
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 

@@ -337,7 +337,7 @@ class DeviceTracks:
         v = (C.c_int64 * 8)()
         _check(lib().rt_last_stats(self._h, v, 8))
         return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
-                    chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]))
+                    chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]), device_bytes=int(v[7]))
 
     def timing(self):
         ms = getattr(self, "_ms_buf", None)

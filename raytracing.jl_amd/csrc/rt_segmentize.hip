@@ -85,6 +85,8 @@ struct DOut {
     RT_G double *volumes;  // accumulated δs·ℓ per cell (un-normalised)
     const RT_G double *delta_s;
     int32_t fused_volumes;  // 1: accumulate δs·ℓ with global f64 atomics inside the fill march
+    int64_t cap;            // records the six arrays can hold: the single-pass compaction does not write beyond (the host
+                            // sizes them from an estimate, sees the true total afterwards, and compacts again if it was short)
 };
 
 // Staging of the single-pass march: a pool of chunks, each kChunkRows rows of 64 lanes, per
@@ -275,7 +277,7 @@ __device__ __forceinline__ const RT_K DStage *march_stage_args() {
 // WIDEK: k > kMaxK (the knn fallback of find_element serves its node list in batches); a separate instantiation, so that
 // the march of the usual k keeps its register budget.
 template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false>
-__global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 3 : 1) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
+__global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 3 : 0) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
                                                       unsigned long long *__restrict__ fail_info, DSplit sp) {
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
             const int32_t ct = __shfl(cnt, tt, 64);
             const int64_t ot = __shfl(off, tt, 64);
             const int row = r0 + rowL;
-            ro[g] = row < ct ? ot + row : -1;
+            ro[g] = (row < ct && ot + row < out.cap) ? ot + row : -1;
             rqx[g] = tx[tt * kC3Pitch + 1 + rowL]; rqy[g] = ty[tt * kC3Pitch + 1 + rowL];
             rpx[g] = tx[tt * kC3Pitch + rowL]; rpy[g] = ty[tt * kC3Pitch + rowL];
         }
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(1024) void k_volumes(const int64_t *__restrict__ of
                                                   const int32_t *__restrict__ element,
                                                   const double *__restrict__ ell, double *__restrict__ volumes,
                                                   int32_t n_cells, int32_t tpb, int32_t use_lds,
-                                                  const int32_t *__restrict__ overflow) {
+                                                  const int32_t *__restrict__ overflow, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (overflow && *overflow) return;  // staging pool overflowed: this attempt's records are void
     double *hist = reinterpret_cast<double *>(smem);
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(1024) void k_volumes(const int64_t *__restrict__ of
     const int64_t u1 = u0 + tpb < n_tracks ? u0 + tpb : n_tracks;
     if (u0 >= u1) return;
     const int nt = (int)(u1 - u0);
-    const int64_t s0 = offsets[u0], s1 = offsets[u1];
+    const int64_t s0 = offsets[u0], s1 = offsets[u1] < cap ? offsets[u1] : cap;  // (records beyond the arrays' capacity: the host compacts again)
     if (use_lds)
         for (int c = threadIdx.x; c < n_cells; c += blockDim.x) hist[c] = 0.0;
     for (int j = threadIdx.x; j <= nt; j += blockDim.x) rel[j] = (int32_t)(offsets[u0 + j] - s0);
@@ -959,6 +961,7 @@ struct rt_mesh {
     int hybrid_pct = 55;   // ... those whose expected segment count exceeds this percentage of the batch's longest
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
+    int64_t test_out_records = 0;   // tests only: capacity of the output arrays on a handle's first call (forces the re-compaction path)
     int test_volumes_fallback = 0;  // tests only: take the split mode's volumes recomputation path unconditionally
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
@@ -992,7 +995,7 @@ struct rt_tracks {
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy;
     DevBuf<int32_t> gelement, ctab, cowner;
-    int64_t pool_chunks = 0, chunks_needed_last = 0;
+    int64_t pool_chunks = 0, chunks_needed_last = 0, total_last = 0;
     // split mode (pieces of tracks)
     int32_t n_vwaves = 0;
     bool hybrid = false;   // the split plan covers only the longest waves; perm[0 .. n_whole) lists the tracks marched whole
@@ -1282,6 +1285,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
     if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
+    if (!strcmp(name, "test_out_records")) { mesh->test_out_records = value; return RT_SUCCESS; }
     if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
@@ -1545,6 +1549,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         RT_HIP(t->sqy.reserve(cap)); RT_HIP(t->sell.reserve(cap)); RT_HIP(t->element.reserve(cap));
         out.px = as_global(t->spx.p); out.py = as_global(t->spy.p); out.qx = as_global(t->sqx.p);
         out.qy = as_global(t->sqy.p); out.ell = as_global(t->sell.p); out.element = as_global(t->element.p);
+        out.cap = (int64_t)std::min({t->spx.cap, t->spy.cap, t->sqx.cap, t->sqy.cap, t->sell.cap, t->element.cap});
         return RT_SUCCESS;
     };
     // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
@@ -1565,7 +1570,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             hipLaunchKernelGGL(rt::k_volumes, dim3((unsigned)nb), dim3(1024), shmem, s, (const int64_t *)t->offsets.p, n,
                                (const int32_t *)t->azim.p, (const double *)t->delta_s.p, (const int32_t *)t->element.p,
                                (const double *)t->sell.p, t->volumes.p, m->n_cells, tpb, use_lds,
-                               m->single_pass ? (const int32_t *)(d_cursor + 1) : (const int32_t *)nullptr);
+                               m->single_pass ? (const int32_t *)(d_cursor + 1) : (const int32_t *)nullptr, out.cap);
         }
         if (!(fused_volumes_this_call && n > 0))  // the fused path scales inside k_scan_write
             hipLaunchKernelGGL(rt::k_scale_volumes, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, s, t->volumes.p,
@@ -1619,9 +1624,14 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 RT_HIP(t->cowner.reserve((size_t)want));
                 t->pool_chunks = want;
             }
-            // the compact records can never outnumber the pool's slots: sizing the outputs by the
-            // pool lets march -> scan -> compaction -> volumes run back to back without a host sync
-            if (int rc = reserve_out(t->pool_chunks * rt::kChunkRows * 64)) return rc;
+            // The six output arrays are sized from the Cauchy–Crofton estimate of the record count (or from what the
+            // previous call produced), not from the pool's slots: march -> scan -> compaction still run back to back
+            // without a host sync — the compaction simply does not write beyond the capacity, and in the rare call
+            // whose total exceeds it the host grows the arrays and compacts again (the staged rows are still there).
+            const int64_t est_records = t->total_last > 0 ? t->total_last + t->total_last / 32 + 4096
+                                                          : (int64_t)(1.08 * m->kappa * t->sum_ell) + 2 * n + 4096;
+            if (int rc = reserve_out(std::min<int64_t>(m->test_out_records > 0 && t->total_last == 0 ? m->test_out_records : est_records,
+                                                       t->pool_chunks * rt::kChunkRows * 64))) return rc;
             stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
             stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
@@ -1692,6 +1702,21 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
+            if (!cur[1] && total > out.cap) {
+                // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
+                if (int rc = reserve_out(total + total / 32 + 4096)) return rc;
+                if (n > 0 && !split_all && n_whole_waves > 0)
+                    hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_whole_waves), dim3(256), 0, s, d_whole,
+                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
+                if (n > 0 && split)
+                    hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
+                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp);
+                if (!fused_volumes_this_call && m->volumes_mode == 2) {  // the separate volumes pass read truncated records
+                    RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+                    if (int rc = launch_volumes()) return rc;
+                }
+                RT_HIP(hipStreamSynchronize(s));
+            }
             if (!cur[1] && split && fuse && (fi[7] != 0 || m->test_volumes_fallback)) {
                 // some piece marched past the seed it should have stopped at: its surplus records were dropped by
                 // k_resolve but had already been added to the fused volumes — recompute them from the kept records
@@ -1761,6 +1786,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 #endif
     if (hybrid) t->last_split = 2;
     t->total = total;
+    t->total_last = total;
     t->n_generic_records = (int64_t)fi[15];
     t->n_failed = (int64_t)fi[0];
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
@@ -1902,6 +1928,15 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 4) stats[4] = t->last_march_waves;
     if (n > 5) stats[5] = t->last_split;  // 0 whole tracks, 1 pieces, 2 hybrid (pieces for the longest waves only)
     if (n > 6) stats[6] = t->last_widek;
+    if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
+        auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
+        stats[7] = b(t->px) + b(t->py) + b(t->phi) + b(t->cs) + b(t->sn) + b(t->A) + b(t->B) + b(t->C) + b(t->ell) + b(t->azim) + b(t->perm) +
+                   b(t->perm_whole) + b(t->counts) + b(t->status) + b(t->element) + b(t->offsets) + b(t->tile_sums) + b(t->ctl) + b(t->spx) +
+                   b(t->spy) + b(t->sqx) + b(t->sqy) + b(t->sell) + b(t->volumes) + b(t->volumes_prev) + b(t->delta_s) + b(t->gpx) + b(t->gpy) +
+                   b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +
+                   b(t->w_base) + b(t->w_P) + b(t->s_el) + b(t->s_eq) + b(t->p_count) + b(t->p_flags) + b(t->p_valid) + b(t->p_rel) + b(t->s_px) +
+                   b(t->s_py) + b(t->s_qx) + b(t->s_qy) + b(t->s_ell) + b(t->p_sum);
+    }
     return RT_SUCCESS;
 }
 

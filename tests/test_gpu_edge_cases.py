@@ -309,3 +309,26 @@ def test_hybrid_plan_gives_identical_results(rt, traced, oracle_run, pct):
     # a wide k cannot use the plan: the same handle then marches every track whole
     assert dt.segmentize(tg.tiny_step, 12, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
     assert dt.stats()["split"] == 0 and np.array_equal(dt.fetch_segments()["element"], ref["element"])
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(fuse_volumes=0), dict(split=24)])
+def test_short_output_estimate_is_recovered(rt, traced, oracle_run, opts):
+    """The six output arrays are sized from an estimate of the record count; a call that produces more must grow them
+    and compact again without marching again (forced here through the test knob)."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("test_out_records", 1000)
+    for k, v in opts.items():
+        dm.set_option(k, v)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    for _ in range(2):
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+        s = dt.fetch_segments()
+        assert np.array_equal(dt.fetch_offsets()[0], ref["offsets"]) and np.array_equal(s["element"], ref["element"])
+        for k in FIELDS:
+            assert np.array_equal(s[k], ref[k]), k
+        assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
