@@ -601,18 +601,24 @@ RT_HD __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, 
     const double e1A = nr.e1A, e1B = nr.e1B, e1C = nr.e1C, e2A = nr.e2A, e2B = nr.e2B, e2C = nr.e2C;
     bool ok = has && rec_extras(nr.hdr) <= kk;
     // --- certificate 1: the track line clears every vertex of T' by d_vertex and crosses the entry edge
-    const double s0 = tA * x0 + tB * y0 + tC, s1 = tA * x1 + tB * y1 + tC, s2 = tA * x2 + tB * y2 + tC;
+    //     (certificates may use any arithmetic — only what reaches an output follows the reference's operation order —
+    //      so these use fused multiply-adds: half the instructions)
+    const double s0 = __builtin_fma(tA, x0, __builtin_fma(tB, y0, tC)), s1 = __builtin_fma(tA, x1, __builtin_fma(tB, y1, tC)),
+                 s2 = __builtin_fma(tA, x2, __builtin_fma(tB, y2, tC));
     ok = ok && fabs(s0) >= m.d_vertex && fabs(s1) >= m.d_vertex && fabs(s2) >= m.d_vertex;
     const bool p0 = s0 > 0, p1 = s1 > 0, p2 = s2 > 0;
     ok = ok && (p0 != p1);
     const bool exit1 = p1 != p2;  // the line leaves through rotated edge 1 = (v1,v2), else edge 2 = (v2,v0)
     // --- certificate 2: xp is inside T', at least the record's eps (barycentric) from edges 1 and 2
-    const double area2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-    const double sg = area2 > 0 ? 1.0 : -1.0;
+    const double ex = x1 - x0, ey = y1 - y0, fx = x2 - x0, fy = y2 - y0, gx = xpx - x0, gy = xpy - y0;
+    const double area2 = __builtin_fma(ex, fy, -(fx * ey));
     const double aa = fabs(area2);
-    const double c0 = sg * ((x1 - x0) * (xpy - y0) - (y1 - y0) * (xpx - x0));  // ~ distance from the entry edge
-    const double c1 = sg * ((x2 - x1) * (xpy - y1) - (y2 - y1) * (xpx - x1));
-    const double c2 = sg * ((x0 - x2) * (xpy - y2) - (y0 - y2) * (xpx - x2));
+    // signed areas of (entry edge, xp), (edge 1, xp), (edge 2, xp), in units of the cell's signed double area
+    const double d0 = __builtin_fma(ex, gy, -(ey * gx));          // ~ distance from the entry edge
+    const double d2 = __builtin_fma(gx, fy, -(gy * fx));          // from edge 2 = (v2, v0)
+    const double d1 = area2 - d0 - d2;                            // from edge 1 = (v1, v2): the three sum to area2
+    const bool pos = area2 > 0;
+    const double c0 = pos ? d0 : -d0, c1 = pos ? d1 : -d1, c2 = pos ? d2 : -d2;
     const double eps_aa = rec_eps(nr.hdr) * aa;
     ok = ok && c0 >= -0.25 * kRtolDefault * aa && c1 >= eps_aa && c2 >= eps_aa;
     // --- exit point: intersection(track.ABC, ABC) — src/intersection.jl:127-138

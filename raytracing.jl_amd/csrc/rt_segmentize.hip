@@ -661,12 +661,15 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
 constexpr int kC3Pitch = kChunkRows + 4;  // doubles per track in a tile: slot 0 = carry, slots 1..32 = rows
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__restrict__ counts,
-                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out, DSplit sp) {
+                                                  const int64_t *__restrict__ offsets, DStage stg, DOut out, DSplit sp,
+                                                  const int32_t *__restrict__ corder) {
     static_assert(kChunkRows == 32, "k_compact3 moves 32-row chunks");
     __shared__ double tiles_x[4][16 * kC3Pitch];  // 36.9 KB per workgroup: four workgroups per CU
     __shared__ double tiles_y[4][16 * kC3Pitch];
     if (stg.cursor[1] != 0) return;  // pool overflow: this attempt is void
-    const int64_t w = blockIdx.x >> 2;  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
+    // corder (large batches): workgroups take the march waves in the order of their output addresses — a batch that takes
+    // several rounds of workgroups anyway then writes the 44-B records front to back instead of scattered over gigabytes
+    const int64_t w = corder ? corder[blockIdx.x >> 2] : (blockIdx.x >> 2);  // SPLIT: canonical virtual wave (one piece of 64 consecutive tracks)
     const int q = blockIdx.x & 3;       // quarter: tracks 16 q .. 16 q + 15 of the wave
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr+4, ...
@@ -976,6 +979,7 @@ struct rt_tracks {
     rt_mesh *mesh = nullptr;
     int64_t n = 0;
     DevBuf<double> px, py, phi, cs, sn, A, B, C, ell;
+    DevBuf<int32_t> corder;  // march waves sorted by the uid of their first track (the compaction order of large batches)
     DevBuf<int32_t> azim, perm, perm_whole;  // perm: march order of all tracks; perm_whole: of those the hybrid plan marches whole
     rt::DTracks d{};
     // results
@@ -1019,6 +1023,8 @@ struct rt_tracks {
 };
 
 namespace {
+
+inline size_t nw_all_early(size_t n) { return (n + 63) / 64; }
 
 // Wait for a stream the way a latency-bound caller wants it: hipStreamSynchronize may sleep on an interrupt and
 // wake well after the last kernel ended.  Poll for the first milliseconds, then sleep.
@@ -1122,7 +1128,7 @@ void pin_release_to_cache(rt_tracks *t);  // defined with rt_fetch_segments_pinn
 
 void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
-    t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->perm_whole.release();
+    t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->perm_whole.release(); t->corder.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
     t->tile_sums.release(); t->ctl.release();
 #ifdef RT_TIMING
@@ -1330,6 +1336,13 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         for (size_t w = 0; w < nw; ++w)
             for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
     }
+    std::vector<int32_t> h_corder;
+    if (nw_all_early(n) > 4096) {  // batches of many rounds: compaction in output order (measured -8 % at 16 k waves, +1.5 % at 2 k)
+        const size_t nw = (n + 63) / 64;
+        h_corder.resize(nw);
+        std::iota(h_corder.begin(), h_corder.end(), 0);
+        std::stable_sort(h_corder.begin(), h_corder.end(), [&](int32_t a, int32_t b) { return perm[(size_t)a * 64] < perm[(size_t)b * 64]; });
+    }
     for (size_t i = 0; i < n; ++i) t->sum_ell += ell[i];
     if (n > 0) {
         t->azim_min = *std::min_element(azim_idx, azim_idx + n);
@@ -1411,7 +1424,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     bool ok = upload(t->px, px, n, s) == 0 && upload(t->py, py, n, s) == 0 && upload(t->phi, phi, n, s) == 0 &&
               upload(t->cs, cos_phi, n, s) == 0 && upload(t->sn, sin_phi, n, s) == 0 && upload(t->A, A, n, s) == 0 &&
               upload(t->B, B, n, s) == 0 && upload(t->C, C, n, s) == 0 && upload(t->ell, ell, n, s) == 0 &&
-              upload(t->azim, azim_idx, n, s) == 0 && upload(t->perm, perm.data(), n, s) == 0;
+              upload(t->azim, azim_idx, n, s) == 0 && upload(t->perm, perm.data(), n, s) == 0 &&
+              (h_corder.empty() || upload(t->corder, h_corder.data(), h_corder.size(), s) == 0);
     if (ok && t->n_vwaves > 0) {
         const size_t np = (size_t)t->n_vwaves * 64;
         ok = upload(t->vorder, h_vorder.data(), h_vorder.size(), s) == 0 && upload(t->vw_wave, h_vw_wave.data(), h_vw_wave.size(), s) == 0 &&
@@ -1523,6 +1537,8 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         sp.n_vwaves = t->n_vwaves;
     }
     const unsigned grid = (unsigned)n_waves;
+    // compaction order of the whole-track waves (only when every track marches whole with the full march order)
+    const int32_t *corder = (t->corder.p && m->single_pass && !t->n_vwaves) ? (const int32_t *)t->corder.p : (const int32_t *)nullptr;
     int64_t total = 0;
     unsigned long long fi[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float f = 0;
@@ -1686,10 +1702,10 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             RT_HIP(hipEventRecord(t->ev[3], s));  // every event record costs ≈4 µs of stream time: none is recorded twice
             if (n > 0 && !split_all && n_whole_waves > 0)
                 hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_whole_waves), dim3(256), 0, s, d_whole,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp, corder);
             if (n > 0 && split)
                 hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
-                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp);
+                                   (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp, (const int32_t *)nullptr);
             RT_HIP(hipEventRecord(t->ev[5], s));
             if (int rc = launch_volumes()) return rc;
             volumes_pass = !(fuse && n > 0);
@@ -1707,10 +1723,10 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 if (int rc = reserve_out(total + total / 32 + 4096)) return rc;
                 if (n > 0 && !split_all && n_whole_waves > 0)
                     hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_whole_waves), dim3(256), 0, s, d_whole,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp);
+                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp, corder);
                 if (n > 0 && split)
                     hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp);
+                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp, (const int32_t *)nullptr);
                 if (!fused_volumes_this_call && m->volumes_mode == 2) {  // the separate volumes pass read truncated records
                     RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
                     if (int rc = launch_volumes()) return rc;
