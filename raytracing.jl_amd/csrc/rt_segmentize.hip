@@ -276,7 +276,10 @@ __device__ __forceinline__ const RT_K DStage *march_stage_args() {
 
 // WIDEK: k > kMaxK (the knn fallback of find_element serves its node list in batches); a separate instantiation, so that
 // the march of the usual k keeps its register budget.
-template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false>
+// LDSREC (experiment, option "lds_records"): the workgroup first copies ALL walk records of the mesh into LDS and the
+// lanes fetch their next record from there instead of from L2 — only meshes of a few hundred cells fit (80 B per record,
+// three per cell); see DESIGN.md §4 for what it measures.
+template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false, bool LDSREC = false>
 __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 3 : 0) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
@@ -306,8 +309,16 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
         for (int c = lane; c < kMaxChunks; c += 64) chunk_lds[c] = -1;
         if (FUSE)
             for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) hist[c] = 0.0;
+        if (LDSREC) {
+            typedef __attribute__((address_space(3))) double lds_f64w;
+            lds_f64w *dst = (lds_f64w *)(march_smem + (((size_t)m.n_cells * sizeof(double) + (size_t)WAVES * kMaxChunks * sizeof(int32_t) + 15) & ~(size_t)15));
+            const RT_G double *src = (const RT_G double *)m.wrec;  // (the header word travels as a bit pattern)
+            for (int c = threadIdx.x; c < 3 * m.n_cells * 10; c += 64 * WAVES) dst[c] = src[c];
+        }
         __syncthreads();
     }
+    typedef __attribute__((address_space(3))) const WalkRec lds_rec_t;
+    lds_rec_t *lrec = (lds_rec_t *)(march_smem + (((size_t)m.n_cells * sizeof(double) + (size_t)WAVES * kMaxChunks * sizeof(int32_t) + 15) & ~(size_t)15));
     int64_t wave_id = (int64_t)blockIdx.x * WAVES + wib;  // indexes the wave's chunk table (ctab)
     int64_t slot = wave_id * 64 + lane;
     int32_t pk = 0, pP = 1, pw = 0;  // SPLIT: piece index, pieces per track, wave of tracks
@@ -420,7 +431,13 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
             }
             break;  // :130-132
         }
-        load_next(mh, wk.pred, nr);
+        if (LDSREC) {
+            lds_rec_t *R = lrec + (wk.pred >= 0 ? wk.pred : 0);
+            nr.hdr = R->hdr; nr.dT = R->dT; nr.x2 = R->x2; nr.y2 = R->y2;
+            nr.e1A = R->e1A; nr.e1B = R->e1B; nr.e1C = R->e1C; nr.e2A = R->e2A; nr.e2B = R->e2B; nr.e2C = R->e2C;
+        } else {
+            load_next(mh, wk.pred, nr);
+        }
 #ifdef RT_TIMING
         const unsigned long long tB_ = rt_tick(RT_TIMING == 2 ? nr.e2C : xpx);
         tacc0 += tB_ - tA_;
@@ -961,6 +978,7 @@ struct rt_mesh {
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
     int hybrid = 0;        // 1: batches that fill the chip march only their longest waves in pieces, beside the whole-track march of the rest
                            // (measured slower at every threshold on MI355X — the full batch is within 1.6x of its throughput floor — DESIGN.md §4)
+    int lds_records = 0;   // experiment: 1 = eight-wave workgroups with all walk records in LDS (meshes that fit), 2 = the same shape from L2
     int hybrid_pct = 55;   // ... those whose expected segment count exceeds this percentage of the batch's longest
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
@@ -1288,6 +1306,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
     if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
@@ -1599,11 +1618,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     hipStream_t march_stream = s;          // (the hybrid path launches its pieces on the auxiliary stream)
     const rt::DTracks *march_tracks = &t->d;
     const rt::DStage *march_stage = &stg;
-    auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK>(unsigned blocks, size_t smem) -> int {
+    auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK, bool LDSREC = false>(unsigned blocks, size_t smem) -> int {
         t->last_march_waves = WAVES; t->last_split = std::max(t->last_split, SPLIT ? 1 : 0); t->last_widek = WIDEK ? 1 : 0;
         if (smem > 48 * 1024)
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK>), dim3(blocks), dim3(64 * WAVES), smem, march_stream, m->d, *march_tracks, prm,
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC>), dim3(blocks), dim3(64 * WAVES), smem, march_stream, m->d, *march_tracks, prm,
                            t->counts.p, t->status.p, march_offsets, out, *march_stage, d_fail, sp);
         return RT_SUCCESS;
     };
@@ -1689,7 +1708,14 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             if (n > 0 && !split_all) {  // whole tracks: all of them, or those the hybrid plan leaves whole
                 int rc;
                 march_tracks = &d_whole;
-                if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, false, false>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
+                // experiment: eight-wave workgroups (one per CU) with all walk records in LDS (1), or from L2 as usual (2: its control)
+                const size_t lds_base = ((hist_bytes + 8 * rt::kMaxChunks * sizeof(int32_t) + 15) & ~(size_t)15);
+                const size_t lds_smem = lds_base + (size_t)3 * m->n_cells * sizeof(rt::WalkRec);
+                if (fuse && m->lds_records == 1 && !hybrid && lds_smem <= 160 * 1024)
+                    rc = march.template operator()<rt::kStage, 8, false, false, true>((unsigned)((n_whole_waves + 7) / 8), lds_smem);
+                else if (fuse && m->lds_records == 2 && !hybrid && lds_smem <= 160 * 1024)
+                    rc = march.template operator()<rt::kStage, 8, false, false, false>((unsigned)((n_whole_waves + 7) / 8), lds_smem);
+                else if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, false, false>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
                 else if (fuse) rc = march.template operator()<rt::kStage, 6, false, false>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
                 else if (widek) rc = march.template operator()<rt::kStage, 1, false, true>((unsigned)n_whole_waves, rt::kMaxChunks * sizeof(int32_t));
                 else rc = march.template operator()<rt::kStage, 1, false, false>((unsigned)n_whole_waves, rt::kMaxChunks * sizeof(int32_t));

@@ -1,40 +1,66 @@
-"""Development: many random Delaunay meshes / quadratures through the HIP path against the oracle, bit for bit.
+"""Many seeded meshes / quadratures / k through the HIP path (C ABI) against the checker, bit for bit, with the regime
+of every run printed (rt_mesh_info / rt_last_stats).  Same cases as tools/fuzz_cpu.py (every mesh class of
+tests/meshgen.py, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on, off, and the library's default splitting.
 usage (GPU box): python tools/fuzz_many.py [first_seed] [count]"""
-import sys, os, time, importlib.util
+import os
+import sys
+import time
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import raytracing_jl_amd as rt
+from raytracing_jl_amd import _capi
 from oracle import oracle as orc
-spec = importlib.util.spec_from_file_location("m", os.path.join(ROOT, "tests", "test_gpu_random_meshes.py"))
-m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+import fuzz_cpu
+
 orc.build()
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+FIELDS = ("px", "py", "qx", "qy", "ell")
 bad = 0
 t0 = time.time()
+seg_total = walk_total = 0
 for seed in range(first, first + count):
-    rng = np.random.default_rng(seed * 7919)
-    n_int = int(rng.integers(50, 3000))
-    kw = dict(w=float(rng.choice([1.0, 0.3, 2.5, 7.0])), h=float(rng.choice([1.0, 0.4, 1.7])),
-              x0=float(rng.choice([0.0, -3.25, 11.0])), y0=float(rng.choice([0.0, 2.5, -0.75])),
-              nb=int(rng.choice([6, 12, 30])), cluster=bool(rng.integers(0, 2)))
-    n_azim = int(rng.choice([4, 8, 16, 32]))
-    delta = float(rng.choice([0.002, 0.004, 0.01])) * min(kw["w"], kw["h"])
-    model = m._random_model(rt, seed, n_int, **kw)
+    kind, model, n_azim, delta, k = fuzz_cpu.case(seed)
+    if n_azim >= 1024:  # keep a GPU run short: the CPU fuzzer covers the finest quadratures
+        n_azim = 256
     tg = rt.TrackGenerator(model, n_azim, delta)
     rt.trace(tg)
-    ref = m._oracle(orc, tg)
-    opts = [dict(), dict(split=int(rng.choice([16, 24, 40])))][: 1 + int(rng.integers(0, 2))]
-    for o in opts:
-        total, off, st, seg, vol = m._run(rt, tg, o)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi, tiny_step=tg.tiny_step,
+                        k=k, iter_cap=4000000, n_threads=0)
+    aq = tg.azimuthal_quadrature
+    vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
+    regime = ""
+    for opts in (dict(walk=1, split=0), dict(walk=0, split=0), dict(walk=1)):
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        for kk, v in opts.items():
+            dm.set_option(kk, v)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        total = dt.segmentize(tg.tiny_step, k, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        off, st = dt.fetch_offsets()
+        seg = dt.fetch_segments()
         ok = total == ref["total"] and np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and \
-            np.array_equal(seg["element"], ref["element"]) and all(np.array_equal(seg[k], ref[k]) for k in ("px", "py", "qx", "qy", "ell")) and \
-            np.allclose(vol, ref["volumes"], rtol=1e-10, atol=1e-300)
+            np.array_equal(seg["element"], ref["element"]) and all(np.array_equal(seg[f], ref[f]) for f in FIELDS) and \
+            np.allclose(dt.fetch_volumes(), vol, rtol=1e-10, atol=1e-300)
         if not ok:
             bad += 1
-            print("MISMATCH seed", seed, o, kw, n_azim, delta, flush=True)
-    print("seed %d: %d cells, %d tracks, %d segments, %d failing tracks, opts %s  [%.0f s]" %
-          (seed, model.num_cells, tg.n_total_tracks, int(ref["total"]), int(np.count_nonzero(ref["status"])), opts, time.time() - t0), flush=True)
-print("done:", count, "meshes,", bad, "mismatches")
+            print("MISMATCH seed", seed, kind, opts, n_azim, delta, k, flush=True)
+        if opts == dict(walk=1, split=0):
+            info, stats = dm.info(), dt.stats()
+            regime = "walk %s, %d/%d records walkable, eps<=%.1e, %d of %d records by the walk step" % (
+                "on" if info["walk_enabled"] else "off", info["records_walk"], info["records"], info["eps_max"], stats["walk_records"], total)
+            seg_total += total
+            walk_total += stats["walk_records"]
+        dt.close()
+        dm.close()
+    print("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | %s  [%.0f s]" %
+          (seed, kind, model.num_cells, n_azim, k, tg.n_total_tracks, int(ref["total"]), int(np.count_nonzero(ref["status"])), regime,
+           time.time() - t0), flush=True)
+print("done: %d meshes x 3 modes, %d mismatches, %d segments, %.1f %% of them by the walk step" %
+      (count, bad, seg_total, 100.0 * walk_total / max(seg_total, 1)))
 sys.exit(1 if bad else 0)
