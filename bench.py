@@ -383,6 +383,20 @@ def _main(real_stdout):
                "fetch_GBs": 44.0 * local_total / (fetch_ms * 1e-3) / 1e9 if fetch_ms > 0 else 0.0,
                "note": "one call as the shim sees it: rt_mesh_create (once per mesh), rt_tracks_create (H2D of the track arrays), "
                        "rt_segmentize, rt_fetch_segments_pinned (D2H of the 44-B records over PCIe) — never part of `value`"}
+    downstream = None
+    if rank == 0 and not args.no_extras and not dist_on:
+        # a consumer that stays on the GPU: Segment.τ for 7 energy groups from the device-resident records
+        try:
+            G = 7
+            sig = np.linspace(0.2, 1.6, dmesh.n_cells * G).reshape(dmesh.n_cells, G)
+            dt.fill_tau(sig, fetch=False)
+            ms_tau = min(dt.fill_tau(sig, fetch=False)[2] for _ in range(5))
+            nbytes = local_total * (12.0 + 8.0 * G)  # ℓ + element read, G values written per segment
+            downstream = {"kernel": "rt::k_fill_tau", "groups": G, "ms": ms_tau, "bytes_per_segment": 12.0 + 8.0 * G,
+                          "achieved_GBs": nbytes / (ms_tau * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms_tau * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "τ[s,g] = Σt[element[s],g]·ℓ[s] over the records where they lie (rt_fill_tau); outside `value`"}
+        except Exception as e:  # pragma: no cover
+            downstream = {"error": repr(e)}
     if not args.no_extras and world > 1:
         # the same global problem on rank 0's GPU alone, in the same run: the N=1 point of this strong-scaling line
         sync()
@@ -463,6 +477,8 @@ def _main(real_stdout):
             out["speedup_vs_single_gpu"] = same_workload["ms_per_step"] / ms_per_step
         if config5 is not None:
             out["config5_single_gpu"] = config5
+        if downstream is not None:
+            out["downstream_tau"] = downstream
         if world == 1 and not dist_on and not args.no_concurrent:
             out["two_batches_in_flight"] = two_in_flight(tg, aq, dmesh, dt, args.steps, local_total)
         if world == 1 and not args.no_cpu_baseline:

@@ -168,6 +168,20 @@ int32_t rt_fetch_segments_pinned(rt_tracks *tracks, void **host_ptrs);
 int32_t rt_device_pointers(rt_tracks *tracks, void **ptrs_dev);
 
 /*
+ * A consumer of the device-resident records (the reference's consumption pattern is
+ * "for track in tg.tracks_by_uid, for segment in track.segments: segment.ℓ, segment.element", README.md:127-135, and
+ * Segment.τ is its "storage for transport-related data (e.g., optical thickness)", src/segment.jl:14,28): for every
+ * segment s of the last rt_segmentize and every energy group g,
+ *     τ[s * n_groups + g] = sigma_t[(element[s] - 1) * n_groups + g] * ℓ[s]
+ * computed on the device from the records where they lie.  sigma_t: host array [n_cells * n_groups] (total cross
+ * section per cell and group).  *tau_dev (may be NULL) receives the device pointer of τ (total * n_groups doubles,
+ * owned by the handle, valid until the next rt_fill_tau / rt_segmentize / rt_tracks_destroy), *ms (may be NULL) the
+ * kernel's HIP-event duration.  rt_fetch_tau copies τ to a caller-allocated host buffer.
+ */
+int32_t rt_fill_tau(rt_tracks *tracks, const double *sigma_t, int32_t n_groups, void **tau_dev, double *ms);
+int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
+
+/*
  * HIP-event timings (milliseconds) of the last rt_segmentize on this handle, measured on
  * the stream the kernels ran on: ms[0] whole call (device side), ms[1] plan (track
  * binning), ms[2] march (the dominant kernel), ms[3] offsets scan, ms[4] compaction /

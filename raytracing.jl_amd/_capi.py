@@ -19,7 +19,7 @@ SYMBOLS = (
     "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_info", "rt_last_stats", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_volumes", "rt_device_pointers",
-    "rt_last_timing", "rt_set_option",
+    "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
     "rt_multi_failed_tracks", "rt_multi_fetch_offsets", "rt_multi_fetch_segments", "rt_multi_fetch_volumes", "rt_multi_allgather",
     "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
@@ -129,6 +129,10 @@ def lib():
     L.rt_set_option.restype = C.c_int32
     L.rt_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
     try:
+        L.rt_fill_tau.restype = C.c_int32
+        L.rt_fill_tau.argtypes = [_vp, _dp, C.c_int32, C.POINTER(_vp), _dp]
+        L.rt_fetch_tau.restype = C.c_int32
+        L.rt_fetch_tau.argtypes = [_vp, _dp]
         L.rt_multi_create.restype = _vp
         L.rt_multi_create.argtypes = [_ip, C.c_int32, _dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp, C.c_int64] + [_dp] * 9 + [_ip]
         L.rt_multi_destroy.argtypes = [_vp]
@@ -331,6 +335,22 @@ class DeviceTracks:
         _check(lib().rt_device_pointers(self._h, arr))
         names = ("offsets", "status", "px", "py", "qx", "qy", "ell", "element", "volumes")
         return {k: (arr[i] or 0) for i, k in enumerate(names)}
+
+    def fill_tau(self, sigma_t, fetch=True):
+        """``rt_fill_tau``: τ[s, g] = Σt[element[s], g]·ℓ[s] on the device (``Segment.τ``, src/segment.jl:14,28).  ``sigma_t``:
+        [n_cells, n_groups].  Returns (τ as a [total, n_groups] host array or None, device pointer, kernel ms)."""
+        sg = np.ascontiguousarray(sigma_t, np.float64)
+        if sg.ndim == 1:
+            sg = sg.reshape(-1, 1)
+        if sg.shape[0] != self.dmesh.n_cells:
+            raise ValueError("sigma_t must have one row per cell")
+        ptr, ms = _vp(), C.c_double(0.0)
+        _check(lib().rt_fill_tau(self._h, sg.ctypes.data_as(_dp), sg.shape[1], C.byref(ptr), C.byref(ms)))
+        tau = None
+        if fetch:
+            tau = np.empty((self.total, sg.shape[1]), np.float64)
+            _check(lib().rt_fetch_tau(self._h, tau.ctypes.data_as(_dp)))
+        return tau, (ptr.value or 0), ms.value
 
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""

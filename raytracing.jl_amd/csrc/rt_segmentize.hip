@@ -949,6 +949,34 @@ __global__ __launch_bounds__(1024) void k_volumes(const int64_t *__restrict__ of
     }
 }
 
+// Segment.τ (src/segment.jl:14,28: "storage for transport-related data (e.g., optical thickness)") for consumers that stay
+// on the GPU: τ[s][g] = Σt[element[s]][g] · ℓ[s] over the device-resident records, G values per segment like the
+// per-segment vector of the reference.  One thread per (segment, group) pair: ℓ and the cell id are read once per
+// G consecutive lanes, the cross-section table is cache-resident, the writes are fully coalesced.
+constexpr int kTauSegs = 2048;  // segments per workgroup
+__global__ __launch_bounds__(256) void k_fill_tau(const double *__restrict__ ell, const int32_t *__restrict__ element,
+                                                  const double *__restrict__ sigma_t, int64_t total, int32_t n_groups,
+                                                  uint32_t inv_groups, double *__restrict__ tau) {
+    // a workgroup owns kTauSegs consecutive segments: ℓ and the cell ids are read once, coalesced, into LDS; the
+    // kTauSegs·G values are then produced in memory order (index / G by a multiply-high with the precomputed reciprocal)
+    __shared__ double s_ell[kTauSegs];
+    __shared__ int32_t s_el[kTauSegs];
+    const int64_t s0 = (int64_t)blockIdx.x * kTauSegs;
+    const int ns = (int)(total - s0 < kTauSegs ? total - s0 : kTauSegs);
+    for (int j = threadIdx.x; j < ns; j += 256) {
+        s_ell[j] = __builtin_nontemporal_load(&ell[s0 + j]);
+        s_el[j] = __builtin_nontemporal_load(&element[s0 + j]) - 1;
+    }
+    __syncthreads();
+    const uint32_t nv = (uint32_t)ns * (uint32_t)n_groups;
+    double *out = tau + s0 * n_groups;
+    for (uint32_t j = threadIdx.x; j < nv; j += 256) {
+        const uint32_t sl = inv_groups ? __umulhi(j, inv_groups) : j;  // j / n_groups (exact while j < 2^32 / n_groups; 0: one group)
+        const uint32_t g = j - sl * (uint32_t)n_groups;
+        __builtin_nontemporal_store(sigma_t[(int64_t)s_el[sl] * n_groups + g] * s_ell[sl], &out[j]);
+    }
+}
+
 __global__ void k_scale_volumes(double *__restrict__ vol, int32_t n_cells, double n_azim_2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_cells) vol[i] = vol[i] / n_azim_2;  // volumes ./= n_azim_2, src/trackgenerator.jl:386
@@ -1013,6 +1041,8 @@ struct rt_tracks {
 #endif
     unsigned long long *h_ctl = nullptr;  // pinned: [0..31] init image, [32..63] read-back
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
+    DevBuf<double> tau, sigma_t;  // rt_fill_tau
+    int32_t tau_groups = 0;
     DevBuf<double> volumes_prev;  // the previous call's volumes: the two buffers alternate (see rt_device_pointers)
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy;
@@ -1155,7 +1185,7 @@ void free_tracks(rt_tracks *t) {
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     pin_release_to_cache(t);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
-    t->volumes.release(); t->volumes_prev.release(); t->delta_s.release();
+    t->volumes.release(); t->volumes_prev.release(); t->delta_s.release(); t->tau.release(); t->sigma_t.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
     t->gelement.release(); t->ctab.release(); t->cowner.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
@@ -1498,6 +1528,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     hipStream_t s = m->stream;
     const int64_t n = t->n;
     t->segmentized = false;
+    t->tau_groups = 0;  // τ of the previous records is void
     for (double &v : t->ms) v = 0.0;
 
     rt::DParams prm;
@@ -1935,6 +1966,41 @@ int32_t rt_fetch_volumes(rt_tracks *t, double *volumes) {
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
     RT_HIP(hipSetDevice(t->mesh->device));
     RT_HIP(hipMemcpy(volumes, t->volumes.p, sizeof(double) * t->mesh->n_cells, hipMemcpyDeviceToHost));
+    return RT_SUCCESS;
+}
+
+int32_t rt_fill_tau(rt_tracks *t, const double *sigma_t, int32_t n_groups, void **tau_dev, double *ms) {
+    if (!t || !sigma_t || n_groups <= 0) { set_error("rt_fill_tau: bad arguments"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    rt_mesh *m = t->mesh;
+    RT_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t n = (size_t)t->total * (size_t)n_groups;
+    RT_HIP(t->tau.reserve(n > 0 ? n : 1));
+    if (int rc = upload(t->sigma_t, sigma_t, (size_t)m->n_cells * n_groups, s)) return rc;
+    t->tau_groups = n_groups;
+    RT_HIP(hipEventRecord(t->ev[0], s));
+    if (n_groups > 1024) { set_error("rt_fill_tau: at most 1024 groups"); return RT_ERR_INVALID; }
+    if (n > 0) {
+        const unsigned blocks = (unsigned)((t->total + rt::kTauSegs - 1) / rt::kTauSegs);
+        const uint32_t inv = n_groups == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)n_groups) + 1u;  // ≥ 2^32 / G; 0 = one group
+        hipLaunchKernelGGL(rt::k_fill_tau, dim3(blocks), dim3(256), 0, s, (const double *)t->sell.p, (const int32_t *)t->element.p,
+                           (const double *)t->sigma_t.p, t->total, n_groups, inv, t->tau.p);
+    }
+    RT_HIP(hipEventRecord(t->ev[7], s));
+    RT_HIP(hipStreamSynchronize(s));
+    RT_HIP(hipGetLastError());
+    if (ms) { float f = 0; RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[7])); *ms = f; }
+    if (tau_dev) *tau_dev = t->tau.p;
+    return RT_SUCCESS;
+}
+
+int32_t rt_fetch_tau(rt_tracks *t, double *tau) {
+    if (!t || !tau) { set_error("null argument"); return RT_ERR_INVALID; }
+    if (!t->segmentized || t->tau_groups <= 0) { set_error("rt_fill_tau has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    RT_HIP(hipSetDevice(t->mesh->device));
+    const size_t n = (size_t)t->total * (size_t)t->tau_groups;
+    if (n) RT_HIP(hipMemcpy(tau, t->tau.p, n * sizeof(double), hipMemcpyDeviceToHost));
     return RT_SUCCESS;
 }
 

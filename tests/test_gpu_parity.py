@@ -133,3 +133,19 @@ def test_pinned_fetch_through_the_host_mirror(rt, traced, oracle_run):
     rt.segmentize(tg, fetch="pinned")
     _compare(tg, oracle_run(tg))
     assert not tg.segments.px.flags.writeable
+
+
+@pytest.mark.parametrize("n_groups", [1, 2, 7, 64, 1000])
+def test_device_side_consumer_fills_tau(rt, traced, oracle_run, n_groups):
+    """rt_fill_tau: the reference's consumption pattern (README.md:127-135 — segment.ℓ and segment.element per segment)
+    run on the device over the device-resident records: τ[s, g] = Σt[element[s], g]·ℓ[s] (Segment.τ, src/segment.jl:14,28).
+    One IEEE multiplication per value: bit-identical to numpy on the oracle's records."""
+    tg = traced(32, 5e-3)
+    rt.segmentize(tg, fetch=False)
+    ref = oracle_run(tg)
+    rng = np.random.default_rng(5)
+    sigma = rng.uniform(0.1, 2.0, (tg.device_mesh.n_cells, n_groups))
+    tau, ptr, ms = tg.device_tracks.fill_tau(sigma)
+    assert ptr != 0 and tau.shape == (ref["total"], n_groups)
+    assert np.array_equal(tau, sigma[ref["element"] - 1] * ref["ell"][:, None])
+    print(f"τ of {ref['total']} segments x {n_groups} groups: {ms * 1e3:.1f} us on the device")
