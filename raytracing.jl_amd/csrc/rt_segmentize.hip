@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
     if (P == 0) return;  // hybrid mode: this wave of tracks was marched whole by the non-split kernel
     for (int k = 0; k < P; ++k) sp.p_valid[(int64_t)(base + k) * 64 + lane] = 0;
     int32_t total = 0, st = RT_TRACK_OK;
+    int64_t iters = 0;
     double sum = 0.0;
     int k = 0;
 #ifdef RT_STATS
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
 #endif
         const int64_t pi = (int64_t)(base + k) * 64 + lane;
         const int32_t c = sp.p_count[pi], fl = sp.p_flags[pi];
+        iters += (int64_t)sp.p_rel[pi];  // (written by the march: the piece's iteration count; overwritten just below)
         sp.p_rel[pi] = total;
         sp.p_valid[pi] = c;
         total += c;
@@ -232,6 +234,11 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
     // then fails its Σℓ check.  Pieces count on their own, so a track that reaches the limit is flagged and the host
     // marches the batch again without splitting (practically never: est > MAX_ITER/2 already marches whole).
     if (total >= kMaxIter) atomicAdd(&fail_info[21], 1ull);  // (word 21 of the control block)
+    // likewise the library's own guard on the reference's unbounded `continue` paths (RT_TRACK_ITER_CAP) counts the
+    // iterations of a whole track: a track whose pieces together exceed it, or one of whose pieces ran into it, is marched
+    // again whole, so that status and records are what the unsplit march gives
+    // (piece boundaries shift the count by one or two iterations each: anything near the limit goes to the whole march)
+    if (iters + 4 * P >= prm.iter_cap || st == RT_TRACK_ITER_CAP) atomicAdd(&fail_info[21], 1ull);
     counts[u] = total;
     status[u] = st;
     if (st != RT_TRACK_OK) {
@@ -641,6 +648,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
         const int64_t pi = wave_id * 64 + lane;
         const int32_t tgt_k = tgt_el >= 0 ? tgt_pj / 64 - spk->w_base[pw] : 0;  // piece index of the target within its wave
         spk->p_count[pi] = i;
+        spk->p_rel[pi] = it;  // iterations of this piece (k_resolve sums them, then reuses the slot)
         spk->p_flags[pi] = (matched ? 1 : 0) | (st << 8) | (tgt_k << 16);
         spk->p_sum[pi] = sum_ell;
     } else if (MODE != kFill) {

@@ -332,3 +332,23 @@ def test_short_output_estimate_is_recovered(rt, traced, oracle_run, opts):
         for k in FIELDS:
             assert np.array_equal(s[k], ref[k]), k
         assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
+
+
+def test_iteration_guard_counts_whole_tracks_when_marched_in_pieces(rt, orc):
+    """RT_TRACK_ITER_CAP (the library's guard on the reference's unbounded `continue` paths; the checker has the same
+    guard) counts the iterations of a whole track.  Found by tools/fuzz_many.py (seed 7444): a lattice 1000 units from the
+    origin, where a track creeps for more than 4 M tiny steps — marched in pieces, no piece reached the limit and the
+    track ended as a length mismatch instead.  Such a track now sends the call to the whole-track march."""
+    import sys, os
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_cpu
+
+    kind, model, n_azim, delta, k = fuzz_cpu.case(7444)
+    tg = rt.TrackGenerator(model, 256, delta)
+    rt.trace(tg)
+    ref = _oracle(orc, tg, k=k)
+    assert np.count_nonzero(ref["status"] == 4) >= 1
+    rt.segmentize(tg, k=k, check=False)  # default options: a small batch, marched in pieces first
+    _same(tg, ref, check_volumes=False)
+    assert tg.device_tracks.stats()["split"] == 0
