@@ -232,9 +232,17 @@ def _main(real_stdout):
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (development; RT_BENCH_REHEARSAL=1): every rank uses GPU 0 and
+    # the collectives run over gloo on host copies — RCCL refuses two ranks on one device.  Timings of such a run mean nothing.
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    cdev = torch.device("cpu") if rehearsal else dev  # where the small collective payloads live
+    if rehearsal:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)
     elif args.force_dist:  # development: the multi-GPU code path with a one-rank RCCL group
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -268,7 +276,15 @@ def _main(real_stdout):
     # latency sit beside the next march instead of between two steps.  The last one is waited for inside the
     # timed region (`drain`).
     if dist_on:
-        pipe = rtd.PipelinedVolumesAllReduce(device=dev)
+        if rehearsal:
+            def _host_all_reduce(vol):  # gloo: through a host copy, synchronously
+                h = vol.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                vol.copy_(h)
+                return None
+            pipe = rtd.PipelinedVolumesAllReduce(device=None, all_reduce=_host_all_reduce)
+        else:
+            pipe = rtd.PipelinedVolumesAllReduce(device=dev)
         views = {}
         dmesh.set_enqueue_hook(pipe.hook)
 
@@ -313,8 +329,8 @@ def _main(real_stdout):
     stats = dt.stats()
     info = dmesh.info()
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(local_total), float(n_failed)], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([float(local_total), float(n_failed)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -331,6 +347,8 @@ def _main(real_stdout):
         for name in ("px", "py", "qx", "qy", "ell"):
             local[name] = torch.as_tensor(rtd.DevArray(p[name], local_total, "<f8", dt), device=dev)
         local["element"] = torch.as_tensor(rtd.DevArray(p["element"], local_total, "<i4", dt), device=dev)
+        if rehearsal:
+            local = {k: v.cpu() for k, v in local.items()}
         try:
             gather = rtd.SegmentGather()
             gather(local)  # warm-up (allocates the final buffers, opens the peer connections)
@@ -341,7 +359,7 @@ def _main(real_stdout):
                 g = gather(local)
             sync()
             g_ms = (time.perf_counter() - g0) / reps * 1e3
-            gt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
+            gt = torch.tensor([g_ms], dtype=torch.float64, device=cdev)
             if world > 1:
                 dist.all_reduce(gt, op=dist.ReduceOp.MAX)
             assert int(g["offsets"][-1].item()) == int(global_segments)
@@ -466,6 +484,8 @@ def _main(real_stdout):
             "kernels": per_kernel,
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},
         }
+        if rehearsal:
+            out["rehearsal"] = "RT_BENCH_REHEARSAL=1: all ranks on GPU 0, collectives over gloo on host copies — a functional run, its timings mean nothing"
         if latency is not None:
             out["latency"] = latency
         if e2e is not None:
