@@ -180,6 +180,72 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
     return materialize ? t : (t, views)
 end
 
+"""
+    segmentize_amd_multi!(t::TrackGenerator{Float64}; devices=[0], k=5, rtol=Base.rtoldefault(Float64))
+
+`segmentize!` over several GPUs from one Julia process: `tracks_by_uid` is cut into contiguous uid ranges of ≈ equal Σℓ,
+one per entry of `devices` (tracks are independent, src/trackgenerator.jl:362-364), every device marches its range, and the
+results come back as the arrays of an unsharded run (`rt_multi_*`; tests/c_abi_smoke.c makes the same calls from C).
+"""
+function segmentize_amd_multi!(t::TrackGenerator{Float64}; devices::Vector{Int}=[0], k::Int=5,
+                               rtol::Real=Base.rtoldefault(Float64))
+    tracks = t.tracks_by_uid
+    !isassigned(tracks, 1) && error("Segmentation is intended after tracing. Please, " *
+                                    "call `trace!` first!")
+    mesh = t.mesh
+    coords = get_node_coordinates(get_grid(mesh.model))
+    x = Float64[c[1] for c in coords]; y = Float64[c[2] for c in coords]
+    cell_nodes = Vector{Int32}(mesh.cell_nodes.data)
+    nc_ptrs = Vector{Int32}(mesh.node_cells.ptrs); nc_data = Vector{Int32}(mesh.node_cells.data)
+    bb = Float64[mesh.bb_min[1], mesh.bb_min[2], mesh.bb_max[1], mesh.bb_max[2]]
+    n = length(tracks)
+    px = Float64[tr.p[1] for tr in tracks]; py = Float64[tr.p[2] for tr in tracks]
+    ϕ = Float64[tr.ϕ for tr in tracks]; cϕ = cos.(ϕ); sϕ = sin.(ϕ)
+    A = Float64[tr.ABC[1] for tr in tracks]; B = Float64[tr.ABC[2] for tr in tracks]; C = Float64[tr.ABC[3] for tr in tracks]
+    ℓ = Float64[tr.ℓ for tr in tracks]; azim = Int32[tr.azim_idx for tr in tracks]
+    ids = Vector{Int32}(devices)
+    hm = ccall((:rt_multi_create, LIB), Ptr{Cvoid},
+               (Ptr{Int32}, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+               ids, Int32(length(ids)), x, y, Int32(length(x)), cell_nodes, Int32(length(cell_nodes) ÷ 3), nc_ptrs, nc_data, bb,
+               n, px, py, ϕ, cϕ, sϕ, A, B, C, ℓ, azim)
+    hm == C_NULL && error("rt_multi_create: " * lasterror())
+    try
+        total = ccall((:rt_multi_segmentize, LIB), Int64, (Ptr{Cvoid}, Float64, Int32, Float64, Ptr{Float64}, Int32),
+                      hm, t.tiny_step, k, rtol, t.azimuthal_quadrature.δs, nazim2(t.azimuthal_quadrature))
+        total < 0 && error("rt_multi_segmentize: " * lasterror())
+        nfail = Ref{Int64}(0); uid = Ref{Int64}(0); st = Ref{Int32}(0)
+        ccall((:rt_multi_failed_tracks, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int32}), hm, nfail, uid, st)
+        if nfail[] > 0
+            msg = unsafe_string(ccall((:rt_status_message, LIB), Cstring, (Int32,), st[]))
+            error(replace(msg, "%d" => string(uid[])))
+        end
+        offs = Vector{Int64}(undef, n + 1); status = Vector{Int32}(undef, n)
+        ccall((:rt_multi_fetch_offsets, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}), hm, offs, status)
+        spx = Vector{Float64}(undef, total); spy = similar(spx); sqx = similar(spx); sqy = similar(spx); sℓ = similar(spx)
+        sel = Vector{Int32}(undef, total)
+        rc = ccall((:rt_multi_fetch_segments, LIB), Int32,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                   hm, spx, spy, sqx, sqy, sℓ, sel)
+        rc != 0 && error("rt_multi_fetch_segments: " * lasterror())
+        Threads.@threads for u in 1:n
+            segs = tracks[u].segments
+            cnt = Int(offs[u+1] - offs[u])
+            resize!(segs, cnt)
+            base = Int(offs[u])
+            @inbounds for i in 1:cnt
+                s = base + i
+                segs[i] = Segment(Point2D(spx[s], spy[s]), Point2D(sqx[s], sqy[s]), sℓ[s], Float64[], sel[s])
+            end
+        end
+        ccall((:rt_multi_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), hm, t.volumes)
+    finally
+        ccall((:rt_multi_destroy, LIB), Cvoid, (Ptr{Cvoid},), hm)
+    end
+    return t
+end
+
 # Opt-in replacement of the reference entry point:  RayTracingAMD.install!()
 function install!()
     @eval RayTracing segmentize!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.rtoldefault(Float64)) =

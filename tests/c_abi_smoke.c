@@ -10,7 +10,8 @@
  * result array; tests/test_gpu_c_abi.py compares them with the checker's arrays.
  *
  * Build: gcc -O1 -std=c11 -o c_abi_smoke c_abi_smoke.c -ldl     (no link against the library: it is dlopen'ed)
- * Run:   c_abi_smoke <librt_segmentize.so> <mesh.msh> <n_azim> <delta> [fail_uid]
+ * Run:   c_abi_smoke <librt_segmentize.so> <mesh.msh> <n_azim> <delta> [fail_uid [n_shards]]
+ *        n_shards > 0: the same through rt_multi_* with device_ids = {0, 0, ...} (julia/RayTracingAMD.jl: segmentize_amd_multi!)
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -43,11 +44,14 @@ int main(int argc, char **argv) {
     const int32_t n_azim = atoi(argv[3]);
     const double delta = atof(argv[4]);
     const int64_t fail_uid = argc > 5 ? atoll(argv[5]) : 0; /* 1-based: spoil this track's length so that its Σℓ check fails */
+    const int32_t n_shards = argc > 6 ? atoi(argv[6]) : 0;
     void *lib = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     LOAD(rt_abi_version) LOAD(rt_last_error) LOAD(rt_status_message) LOAD(rt_device_count)
     LOAD(rt_mesh_create) LOAD(rt_mesh_destroy) LOAD(rt_mesh_info) LOAD(rt_tracks_create) LOAD(rt_tracks_destroy)
     LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_volumes)
+    LOAD(rt_multi_create) LOAD(rt_multi_destroy) LOAD(rt_multi_segmentize) LOAD(rt_multi_failed_tracks) LOAD(rt_multi_fetch_offsets)
+    LOAD(rt_multi_fetch_segments) LOAD(rt_multi_fetch_volumes) LOAD(rt_multi_shards)
     LOAD(rt_msh_load) LOAD(rt_msh_sizes) LOAD(rt_msh_fetch) LOAD(rt_msh_free) LOAD(rt_trace_counts) LOAD(rt_trace)
     if (p_rt_abi_version() != RT_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
     if (p_rt_device_count() < 1) { fprintf(stderr, "no GPU\n"); return 3; }
@@ -82,20 +86,48 @@ int main(int argc, char **argv) {
                    b8[1], b8[2], b8[3], nf, nb)) { fprintf(stderr, "rt_trace: %s\n", p_rt_last_error()); return 1; }
     if (fail_uid >= 1 && fail_uid <= n) ell[fail_uid - 1] *= 1.0 + 1e-6;
 
+    const double rtol = 1.4901161193847656e-8; /* Base.rtoldefault(Float64) */
+    int64_t total, n_failed = 0, first_uid = 0;
+    int32_t first_status = 0, walk_enabled = -1;
+    int64_t *offs = malloc(sizeof(int64_t) * ((size_t)n + 1));
+    int32_t *status = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    double *volumes = malloc(sizeof(double) * n_cells);
+    void *hp[6];
+    rt_mesh *hm = NULL;
+    rt_tracks *ht = NULL;
+    rt_multi *mm = NULL;
+    if (n_shards > 0) {
+        /* ---- several devices behind one call (here: the one device, n_shards times) */
+        int32_t ids[64];
+        for (int i = 0; i < n_shards && i < 64; ++i) ids[i] = 0;
+        mm = p_rt_multi_create(ids, n_shards, x, y, n_nodes, cell_nodes, n_cells, nc_ptrs, nc_data, bb, n, px, py, phi, cs, sn, A, B, C, ell, azim);
+        if (!mm) { fprintf(stderr, "rt_multi_create: %s\n", p_rt_last_error()); return 1; }
+        total = p_rt_multi_segmentize(mm, 1e-8, 5, rtol, delta_s, n2);
+        if (total < 0) { fprintf(stderr, "rt_multi_segmentize: %s\n", p_rt_last_error()); return 1; }
+        p_rt_multi_failed_tracks(mm, &n_failed, &first_uid, &first_status);
+        if (p_rt_multi_fetch_offsets(mm, offs, status)) { fprintf(stderr, "rt_multi_fetch_offsets: %s\n", p_rt_last_error()); return 1; }
+        for (int a = 0; a < 6; ++a) hp[a] = malloc((size_t)(total > 0 ? total : 1) * (a < 5 ? sizeof(double) : sizeof(int32_t)));
+        if (p_rt_multi_fetch_segments(mm, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5])) { fprintf(stderr, "rt_multi_fetch_segments: %s\n", p_rt_last_error()); return 1; }
+        if (p_rt_multi_fetch_volumes(mm, volumes)) { fprintf(stderr, "rt_multi_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
+        int64_t ub[65], sb[65];
+        if (p_rt_multi_shards(mm, ub, sb) != n_shards || ub[n_shards] != n || sb[n_shards] != total) { fprintf(stderr, "rt_multi_shards: inconsistent\n"); return 1; }
+    } else {
     /* ---- the shim's sequence */
-    rt_mesh *hm = p_rt_mesh_create(0, x, y, n_nodes, cell_nodes, n_cells, nc_ptrs, nc_data, bb);
+    hm = p_rt_mesh_create(0, x, y, n_nodes, cell_nodes, n_cells, nc_ptrs, nc_data, bb);
     if (!hm) { fprintf(stderr, "rt_mesh_create: %s\n", p_rt_last_error()); return 1; }
     double info[RT_MESH_INFO_COUNT];
     char note[128];
     p_rt_mesh_info(hm, info, RT_MESH_INFO_COUNT, note, sizeof note);
-    rt_tracks *ht = p_rt_tracks_create(hm, n, px, py, phi, cs, sn, A, B, C, ell, azim);
+    walk_enabled = (int32_t)info[RT_MESH_INFO_WALK_ENABLED];
+    ht = p_rt_tracks_create(hm, n, px, py, phi, cs, sn, A, B, C, ell, azim);
     if (!ht) { fprintf(stderr, "rt_tracks_create: %s\n", p_rt_last_error()); return 1; }
-    const double rtol = 1.4901161193847656e-8; /* Base.rtoldefault(Float64) */
-    const int64_t total = p_rt_segmentize(ht, 1e-8, 5, rtol, delta_s, n2);
+    total = p_rt_segmentize(ht, 1e-8, 5, rtol, delta_s, n2);
     if (total < 0) { fprintf(stderr, "rt_segmentize: %s\n", p_rt_last_error()); return 1; }
-    int64_t n_failed = 0, first_uid = 0;
-    int32_t first_status = 0;
     p_rt_failed_tracks(ht, &n_failed, &first_uid, &first_status);
+    if (p_rt_fetch_offsets(ht, offs, status)) { fprintf(stderr, "rt_fetch_offsets: %s\n", p_rt_last_error()); return 1; }
+    if (p_rt_fetch_segments_pinned(ht, hp)) { fprintf(stderr, "rt_fetch_segments_pinned: %s\n", p_rt_last_error()); return 1; }
+    if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
+    }
     char message[512] = "";
     if (n_failed > 0) { /* error(replace(msg, "%d" => string(uid))) */
         const char *msg = p_rt_status_message(first_status);
@@ -103,13 +135,6 @@ int main(int argc, char **argv) {
         if (at) snprintf(message, sizeof message, "%.*s%" PRId64 "%s", (int)(at - msg), msg, first_uid, at + 2);
         else snprintf(message, sizeof message, "%s", msg);
     }
-    int64_t *offs = malloc(sizeof(int64_t) * ((size_t)n + 1));
-    int32_t *status = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
-    if (p_rt_fetch_offsets(ht, offs, status)) { fprintf(stderr, "rt_fetch_offsets: %s\n", p_rt_last_error()); return 1; }
-    void *hp[6];
-    if (p_rt_fetch_segments_pinned(ht, hp)) { fprintf(stderr, "rt_fetch_segments_pinned: %s\n", p_rt_last_error()); return 1; }
-    double *volumes = malloc(sizeof(double) * n_cells);
-    if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
     double vsum = 0.0;
     for (int32_t c = 0; c < n_cells; ++c) vsum += volumes[c];
     /* per-track rebuild as the shim does it: walk the CSR ranges once (here: just check they tile the arrays) */
@@ -119,10 +144,11 @@ int main(int argc, char **argv) {
            ", \"first_uid\": %" PRId64 ", \"first_status\": %d, \"message\": \"%s\", \"walk_enabled\": %d, "
            "\"sum_offsets\": %" PRIu64 ", \"sum_status\": %" PRIu64 ", \"px\": %" PRIu64 ", \"py\": %" PRIu64 ", \"qx\": %" PRIu64
            ", \"qy\": %" PRIu64 ", \"ell\": %" PRIu64 ", \"element\": %" PRIu64 ", \"volumes_sum\": %.17g, \"tracks_px\": %" PRIu64 "}\n",
-           n, total, walked, n_failed, first_uid, first_status, message, (int)info[RT_MESH_INFO_WALK_ENABLED],
+           n, total, walked, n_failed, first_uid, first_status, message, (int)walk_enabled,
            sum_bits64(offs, n + 1), sum_bits32(status, n), sum_bits64(hp[0], total), sum_bits64(hp[1], total), sum_bits64(hp[2], total),
            sum_bits64(hp[3], total), sum_bits64(hp[4], total), sum_bits32((const int32_t *)hp[5], total), vsum, sum_bits64(px, n));
-    p_rt_tracks_destroy(ht);
-    p_rt_mesh_destroy(hm);
+    if (mm) p_rt_multi_destroy(mm);
+    if (ht) p_rt_tracks_destroy(ht);
+    if (hm) p_rt_mesh_destroy(hm);
     return 0;
 }

@@ -41,10 +41,12 @@ def test_harness_builds_and_library_refuses_without_gpu(rt):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_azim,delta", [(8, 0.02), (32, 5e-3)])
-def test_c_caller_matches_checker(rt, orc, n_azim, delta):
+@pytest.mark.parametrize("n_azim,delta,shards", [(8, 0.02, 0), (32, 5e-3, 0), (32, 5e-3, 3)])
+def test_c_caller_matches_checker(rt, orc, n_azim, delta, shards):
+    """shards > 0: the same through rt_multi_* (device_ids = {0, 0, 0}), what segmentize_amd_multi! of the shim calls."""
     exe = _build()
-    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), str(n_azim), str(delta)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), str(n_azim), str(delta), "0", str(shards)], capture_output=True, text=True,
+                       timeout=300)
     assert r.returncode == 0, r.stderr
     got = json.loads(r.stdout)
     model = rt.GmshDiscreteModel(rt.data_path("pincell.msh"))
@@ -55,7 +57,7 @@ def test_c_caller_matches_checker(rt, orc, n_azim, delta):
     aq = tg.azimuthal_quadrature
     vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
     assert got["n_tracks"] == tg.n_total_tracks and got["tracks_px"] == _bits64(tg.px)  # same inputs
-    assert got["total"] == ref["total"] == got["walked"] and got["n_failed"] == 0 and got["walk_enabled"] == 1
+    assert got["total"] == ref["total"] == got["walked"] and got["n_failed"] == 0 and got["walk_enabled"] == (-1 if shards else 1)
     assert got["sum_offsets"] == _bits64(ref["offsets"]) and got["sum_status"] == 0
     for k in ("px", "py", "qx", "qy", "ell"):
         assert got[k] == _bits64(ref[k]), k
@@ -64,9 +66,10 @@ def test_c_caller_matches_checker(rt, orc, n_azim, delta):
 
 
 @pytest.mark.gpu
-def test_c_caller_reports_the_reference_error_text(rt):
+@pytest.mark.parametrize("shards", [0, 4])
+def test_c_caller_reports_the_reference_error_text(rt, shards):
     exe = _build()
-    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), "8", "0.02", "17"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, LIB, rt.data_path("pincell.msh"), "8", "0.02", "17", str(shards)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     got = json.loads(r.stdout)
     assert got["n_failed"] == 1 and got["first_uid"] == 17 and got["first_status"] == 2
