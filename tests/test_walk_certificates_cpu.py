@@ -171,3 +171,23 @@ def test_host_code_under_sanitizers(tmp_path):
     text = log.read_text()
     assert text.count("exit code: 0") == 2 and "ERROR" not in text and "runtime error" not in text, text[-2000:]
     assert "12 refused" in text and "walk on == walk off == checker: yes" in text
+
+
+@pytest.mark.parametrize("tiny,shuffle", [(1e-8, True), (1e-5, False), (1e-6, True), (1e-10, False)])
+def test_reseeding_distance_and_cell_node_order(rt, orc, tiny, shuffle):
+    """tiny_step far from the reference's default, and cells whose three nodes come in random order (both edge
+    orientations on either side of an edge; Gridap lists them ascending, the C ABI takes any order)."""
+    model = meshgen.sliver_model(rt, 11, 12, 12, gap=1e-4)
+    if shuffle:
+        rs = np.random.default_rng(3)
+        cells = np.asarray(model.cell_node_ids).copy()
+        for c in range(len(cells)):
+            cells[c] = cells[c][rs.permutation(3)]
+        model = rt.DiscreteModel(model.node_coordinates, cells)
+    tg = rt.TrackGenerator(model, 16, 0.01, tiny_step=tiny)
+    rt.trace(tg)
+    ref = _oracle(orc, tg)
+    on = hm.run(tg, walk=True)
+    _same(on, ref, "walk on")
+    _same(hm.run(tg, walk=False), ref, "walk off")
+    assert on["stats"]["walk_emits"] > 0.5 * ref["total"]

@@ -43,12 +43,26 @@ def case(seed):
     return kind, model, n_azim, delta, k
 
 
+def tiny_of(seed):
+    """tiny_step of the case (TrackGenerator's keyword, src/trackgenerator.jl:80): the reference's default mostly, sometimes
+    much larger or smaller — the walk step's certificates must hold (or refuse) whatever the re-seeding distance is."""
+    return float(np.random.default_rng(seed * 31 + 5).choice([1e-8, 1e-8, 1e-8, 1e-6, 1e-5, 1e-10, 1e-7]))
+
+
 def run(seed):
     import raytracing_jl_amd as rt
     from oracle import oracle as orc
     import hostmarch as hm
     kind, model, n_azim, delta, k = case(seed)
-    tg = rt.TrackGenerator(model, n_azim, delta)
+    if os.environ.get("FUZZ_SHUFFLE"):
+        # cells with their three nodes in random order (rotations and reflections: both edge orientations occur on either
+        # side of an edge) — Gridap's oriented grids list them ascending, but the C ABI takes any order
+        rs = np.random.default_rng(seed + 77)
+        cells = np.asarray(model.cell_node_ids).copy()
+        for c in range(len(cells)):
+            cells[c] = cells[c][rs.permutation(3)]
+        model = rt.DiscreteModel(model.node_coordinates, cells)
+    tg = rt.TrackGenerator(model, n_azim, delta, tiny_step=tiny_of(seed) if os.environ.get("FUZZ_TINY") else 1e-8)
     rt.trace(tg)
     om = orc.OracleMesh.from_mesh(tg.mesh, omp=False)
     ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
@@ -63,9 +77,9 @@ def run(seed):
             bad.append(walk)
         res[walk] = r
     s, info = res[True]["stats"], res[True]["info"]
-    line = ("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | records walkable %5d/%5d eps≤%.1e fragile %d degenerate %d | "
+    line = ("seed %d %-11s tiny %.0e cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | records walkable %5d/%5d eps≤%.1e fragile %d degenerate %d | "
             "walk emits %8d skips %6d generic emits %7d refused %6d%s" %
-            (seed, kind, model.num_cells, n_azim, k, tg.n_total_tracks, ref["total"], int(np.count_nonzero(ref["status"])),
+            (seed, kind, tg.tiny_step, model.num_cells, n_azim, k, tg.n_total_tracks, ref["total"], int(np.count_nonzero(ref["status"])),
              int(info["records_walk"]), int(info["records"]), info["eps_max"], int(info["cells_fragile"]), int(info["cells_degenerate"]),
              s["walk_emits"], s["walk_skips"], s["generic_emits"], s["refused"], ("  MISMATCH walk=%s" % bad) if bad else ""))
     return seed, bool(bad), line, s["walk_emits"], ref["total"]
