@@ -1014,7 +1014,6 @@ struct rt_mesh {
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
     int hybrid = 0;        // 1: batches that fill the chip march only their longest waves in pieces, beside the whole-track march of the rest
                            // (measured slower at every threshold on MI355X — the full batch is within 1.6x of its throughput floor — DESIGN.md §4)
-    int use_graph = 0;     // 1: one attempt's kernels and event records are captured into a HIP graph once and replayed
     int lds_records = 0;   // experiment: 1 = eight-wave workgroups with all walk records in LDS (meshes that fit), 2 = the same shape from L2
     int hybrid_pct = 55;   // ... those whose expected segment count exceeds this percentage of the batch's longest
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
@@ -1068,9 +1067,6 @@ struct rt_tracks {
     double sum_ell = 0.0;
     int32_t azim_min = 1, azim_max = 0;  // range of azim_idx (checked against n_azim_2 by rt_segmentize)
     int64_t n_generic_records = 0;       // rt_last_stats
-    struct GraphSlot { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
-    GraphSlot graphs[2];     // one per volumes buffer (the two alternate from call to call)
-    uint32_t graph_parity = 0;
     bool force_unsplit = false;  // a track reached MAX_ITER segments in split mode: this track set marches whole from now on
     int32_t last_march_waves = 0, last_split = 0, last_widek = 0;  // which instantiation of the march the last call launched
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
@@ -1205,8 +1201,6 @@ void free_tracks(rt_tracks *t) {
     t->s_px.release(); t->s_py.release(); t->s_qx.release(); t->s_qy.release(); t->s_ell.release(); t->p_sum.release();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
-    for (auto &g : t->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     if (t->aux_stream) (void)hipStreamDestroy(t->aux_stream);
@@ -1350,7 +1344,6 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
-    if (!strcmp(name, "graph")) { mesh->use_graph = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
     if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
@@ -1568,7 +1561,6 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tile_sums writes it)
     RT_HIP(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
     std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
-    ++t->graph_parity;
     RT_HIP(t->volumes.reserve(m->n_cells));
     if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
         t->h_delta_s.assign(delta_s, delta_s + n_azim_2);
@@ -1728,8 +1720,9 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             if (hybrid) stg_pieces.ctab = stg.ctab + n_whole_waves * rt::kMaxChunks;
             rt::DTracks d_whole = t->d;
             if (hybrid) { d_whole.perm = as_global(t->perm_whole.p); d_whole.n = t->n_whole; }
-            // Everything one attempt puts on the stream(s), as one function: enqueued directly, or captured once into a HIP
-            // graph and replayed (option "graph"): the same kernels and event records, launched with one call.
+            // Everything one attempt puts on the stream(s), as one function.  (Capturing it once into a HIP graph and replaying it
+            // was tried: the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on
+            // events that were only ever recorded inside a graph — DESIGN.md §4.)
             auto enqueue_attempt = [&]() -> int {
                 hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, 32) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
                                    t->volumes.p, m->n_cells);
@@ -1789,47 +1782,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
                 return RT_SUCCESS;
             };
-            {
-                int rc_enq = RT_SUCCESS;
-                // a graph is replayed only while every kernel argument is what it was at capture: the arguments are hashed
-                uint64_t key = 1469598103934665603ull;
-                auto mix = [&](const void *p_, size_t nb) { const unsigned char *q_ = (const unsigned char *)p_; for (size_t i_ = 0; i_ < nb; ++i_) { key ^= q_[i_]; key *= 1099511628211ull; } };
-                const bool graph_ok = m->use_graph && n > 0 && !hybrid && attempt == 0 && !m->enqueue_hook;
-                if (graph_ok) {
-                    mix(&m->d, sizeof(m->d)); mix(&t->d, sizeof(t->d)); mix(&d_whole, sizeof(d_whole)); mix(&prm, sizeof(prm)); mix(&out, sizeof(out));
-                    mix(&stg, sizeof(stg)); mix(&sp, sizeof(sp)); mix(&corder, sizeof(corder));
-                    const void *ptrs_[] = {t->counts.p, t->status.p, t->offsets.p, t->tile_sums.p, t->ctl.p, h_res_dev, t->volumes.p, t->delta_s.p, t->azim.p};
-                    mix(ptrs_, sizeof(ptrs_));
-                    const int64_t sc_[] = {n, n_tiles, (int64_t)split, (int64_t)fuse, (int64_t)fuse_waves, (int64_t)widek, (int64_t)m->volumes_mode,
-                                           (int64_t)m->lds_records, (int64_t)n_whole_waves, (int64_t)m->n_cells, (int64_t)n_azim_2};
-                    mix(sc_, sizeof(sc_));
-                    rt_tracks::GraphSlot &gs = t->graphs[t->graph_parity & 1];
-                    if (gs.exec && gs.key == key) {
-                        RT_HIP(hipGraphLaunch(gs.exec, s));
-                        volumes_pass = !(fuse && n > 0);
-                    } else {
-                        if (gs.exec) { (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; }
-                        hipGraph_t g_ = nullptr;
-                        RT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                        rc_enq = enqueue_attempt();
-                        const hipError_t ec = hipStreamEndCapture(s, &g_);
-                        if (rc_enq == RT_SUCCESS && ec == hipSuccess && g_ && hipGraphInstantiate(&gs.exec, g_, nullptr, nullptr, 0) == hipSuccess) {
-                            gs.key = key;
-                            (void)hipGraphDestroy(g_);
-                            RT_HIP(hipGraphLaunch(gs.exec, s));
-                        } else {  // capture is not possible here: enqueue directly, and do not try again on this mesh
-                            if (g_) (void)hipGraphDestroy(g_);
-                            gs.exec = nullptr;
-                            (void)hipGetLastError();
-                            m->use_graph = 0;
-                            rc_enq = enqueue_attempt();
-                        }
-                    }
-                } else {
-                    rc_enq = enqueue_attempt();
-                }
-                if (rc_enq) return rc_enq;
-            }
+            if (int rc_enq = enqueue_attempt()) return rc_enq;
             int32_t cur[4] = {0, 0, 0, 0};
             if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
