@@ -49,6 +49,15 @@ static_assert(sizeof(WalkRec) == 80, "WalkRec layout");
 // What only the generic step reads (locate + intersections): kept behind a pointer in constant address space,
 // so that the march loop, which runs the walk step >99.9 % of the time, does not hold ~30 SGPRs of pointers
 // and grid parameters it never uses there (the kernel was spilling SGPRs to VGPR lanes in its hot path).
+// One incident cell of a node, as find_element's scan needs it: the cell id and its three vertices in the cell's own node
+// order (the values of x[], y[] behind cn[]) — 64 B, four independent 16-B loads instead of the chain ncd -> cn -> x, y.
+struct __attribute__((aligned(16))) FanEntry {
+    double x1, y1, x2, y2, x3, y3;
+    int32_t cell, pad_[3];
+};
+static_assert(sizeof(FanEntry) == 64, "FanEntry layout");
+struct Tri { double x1, y1, x2, y2, x3, y3; };  // a cell's vertices in its node order
+
 struct DGeo {
     const RT_G double *x;        // [n_nodes]
     const RT_G double *y;        // [n_nodes]
@@ -57,6 +66,10 @@ struct DGeo {
     const RT_G int32_t *ncd;     // node -> cells, ascending cell id per node
     const RT_G int32_t *gstart;  // [gnx*gny+1] uniform node grid CSR (row-major, y-major rows)
     const RT_G int32_t *gnode;   // node ids grouped by bucket
+    const RT_G int32_t *c3start; // [gnx*gny+1] per bucket: the nodes of its 3x3 block of buckets, contiguous ...
+    const RT_G int32_t *c3node;  // ... their ids ...
+    const RT_G double *c3x, *c3y;  // ... and coordinates (same values as x[], y[]: the distances come out bit-identical)
+    const RT_G struct FanEntry *fan;  // [ncp[n_nodes]] node -> incident cells WITH their vertex coordinates, in ncd's order
     double gx0, gy0, gh, ginv;   // grid origin, bucket size and its inverse
     int32_t gnx, gny;
     int32_t n_nodes, pad_;
@@ -77,6 +90,7 @@ struct DMesh {
 RT_HD __forceinline__ DGeo load_geo(const RT_K DGeo *p) {
     DGeo g;
     g.x = p->x; g.y = p->y; g.cn = p->cn; g.ncp = p->ncp; g.ncd = p->ncd; g.gstart = p->gstart; g.gnode = p->gnode;
+    g.c3start = p->c3start; g.c3node = p->c3node; g.c3x = p->c3x; g.c3y = p->c3y; g.fan = p->fan;
     g.gx0 = p->gx0; g.gy0 = p->gy0; g.gh = p->gh; g.ginv = p->ginv;
     g.gnx = p->gnx; g.gny = p->gny; g.n_nodes = p->n_nodes; g.pad_ = 0;
     return g;
@@ -148,11 +162,8 @@ RT_HD __forceinline__ bool inboundary(const DMesh &m, double x, double y, double
 // src/mesh.jl:158-176: λ = [x1 x2 x3; y1 y2 y3; 1 1 1] \ [x, y, 1] by the closed form
 // StaticArrays uses for 3x3 (cofactors / det, det = col1 · (col2 × col3)); inside iff every
 // λ ∈ [0 - tol, 1 + tol], tol = sqrt(eps).
-RT_HD __forceinline__ bool point_in_triangle(const DGeo &m, int32_t cell, double x, double y) {
-    const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
-    const double x1 = m.x[n1], y1 = m.y[n1];
-    const double x2 = m.x[n2], y2 = m.y[n2];
-    const double x3 = m.x[n3], y3 = m.y[n3];
+RT_HD __forceinline__ bool point_in_triangle(const Tri &t, double x, double y) {
+    const double x1 = t.x1, y1 = t.y1, x2 = t.x2, y2 = t.y2, x3 = t.x3, y3 = t.y3;
     const double d = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
     const double l1 = ((y2 - y3) * x + (x3 - x2) * y + (x2 * y3 - x3 * y2)) / d;
     const double l2 = ((y3 - y1) * x + (x1 - x3) * y + (x3 * y1 - x1 * y3)) / d;
@@ -214,7 +225,18 @@ RT_HD __forceinline__ int32_t nearest_node(const DGeo &m, double qx, double qy) 
     double best = __builtin_huge_val();
     int32_t best_id = 0x7fffffff;
     const int rmax = m.gnx > m.gny ? m.gnx : m.gny;
-    for (int r = 0; r <= rmax; ++r) {
+    {   // rings 0 and 1 in one go: the bucket's 3x3 block as one contiguous range of (id, x, y)
+        const int b = iy * m.gnx + ix;
+        for (int32_t s = m.c3start[b]; s < m.c3start[b + 1]; ++s) {
+            const int32_t id = m.c3node[s];
+            const double dx = qx - m.c3x[s], dy = qy - m.c3y[s];
+            const double d2 = dx * dx + dy * dy;
+            if (node_before(d2, id, best, best_id)) { best = d2; best_id = id; }
+        }
+        const double lb = ring_bound(m, qx, qy, ix, iy, 1) - 1e-9 * m.gh;
+        if (lb == __builtin_huge_val() || (best_id != 0x7fffffff && lb > 0.0 && best < lb * lb)) return best_id == 0x7fffffff ? -1 : best_id;
+    }
+    for (int r = 2; r <= rmax; ++r) {
         const int y0 = iy - r, y1 = iy + r;
         for (int by = (y0 < 0 ? 0 : y0); by <= (y1 >= m.gny ? m.gny - 1 : y1); ++by) {
             const int xl = ix - r < 0 ? 0 : ix - r, xr = ix + r >= m.gnx ? m.gnx - 1 : ix + r;
@@ -283,10 +305,19 @@ RT_HD __noinline__ void knearest_nodes(const DGeo &m, double qx, double qy, int 
     }
 }
 
-RT_HD __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node, double x, double y) {
+RT_HD __forceinline__ Tri load_tri(const DGeo &m, int32_t cell) {
+    const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
+    Tri t;
+    t.x1 = m.x[n1]; t.y1 = m.y[n1]; t.x2 = m.x[n2]; t.y2 = m.y[n2]; t.x3 = m.x[n3]; t.y3 = m.y[n3];
+    return t;
+}
+// The cells of node_cells[node] in stored order, first hit wins (src/mesh.jl:110-118); `tri` receives the hit's vertices.
+RT_HD __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node, double x, double y, Tri &tri) {
     for (int32_t s = m.ncp[node]; s < m.ncp[node + 1]; ++s) {
-        const int32_t c = m.ncd[s];
-        if (point_in_triangle(m, c, x, y)) return c;
+        const RT_G FanEntry *e = m.fan + s;
+        Tri t;
+        t.x1 = e->x1; t.y1 = e->y1; t.x2 = e->x2; t.y2 = e->y2; t.x3 = e->x3; t.y3 = e->y3;
+        if (point_in_triangle(t, x, y)) { tri = t; return e->cell; }
     }
     return -1;
 }
@@ -298,7 +329,7 @@ RT_HD __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node,
 // WIDEK (k > kMaxK; src/mesh.jl:123 takes any k): the same sorted node list, kMaxK nodes at a time.  A separate
 // instantiation, so that the march of the usual k keeps its register budget.
 template <bool WIDEK>
-RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double y, int k, int32_t nn_id) {
+RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double y, int k, int32_t nn_id, Tri &tri) {
     KBest kb;
     const int kk = k > 2 ? k : 2;
     if (WIDEK) {
@@ -307,7 +338,7 @@ RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double
         for (int done = 0; done < kk; done += kMaxK) {
             knearest_nodes<true>(m, x, y, kk - done < kMaxK ? kk - done : kMaxK, nn_id, d2p, idp, kb);
             for (int j = 0; j < kb.n; ++j) {
-                const int32_t c = first_cell_containing(m, kb.id[j], x, y);
+                const int32_t c = first_cell_containing(m, kb.id[j], x, y, tri);
                 if (c >= 0) return c;
             }
             if (kb.n < kMaxK) break;  // no more nodes
@@ -318,12 +349,12 @@ RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double
     knearest_nodes<false>(m, x, y, kk, nn_id, -1.0, -1, kb);
     const int first = kb.n < 2 ? kb.n : 2;
     for (int j = 0; j < first; ++j) {
-        const int32_t c = first_cell_containing(m, kb.id[j], x, y);
+        const int32_t c = first_cell_containing(m, kb.id[j], x, y, tri);
         if (c >= 0) return c;
     }
     const int lim = kb.n < k ? kb.n : k;  // second call: knn(k) — only new nodes can succeed
     for (int j = first; j < lim; ++j) {
-        const int32_t c = first_cell_containing(m, kb.id[j], x, y);
+        const int32_t c = first_cell_containing(m, kb.id[j], x, y, tri);
         if (c >= 0) return c;
     }
     return -1;
@@ -331,12 +362,12 @@ RT_HD __noinline__ int32_t find_element_fallback(const DGeo &m, double x, double
 
 // find_element (src/mesh.jl:103-146), 0-based cell id or -1.
 template <bool WIDEK = false>
-RT_HD __forceinline__ int32_t find_element(const DGeo &m, double x, double y, int k) {
+RT_HD __forceinline__ int32_t find_element(const DGeo &m, double x, double y, int k, Tri &tri) {
     const int32_t nn_id = nearest_node(m, x, y);
     if (nn_id < 0) return -1;
-    const int32_t c = first_cell_containing(m, nn_id, x, y);
+    const int32_t c = first_cell_containing(m, nn_id, x, y, tri);
     if (c >= 0) return c;
-    return find_element_fallback<WIDEK>(m, x, y, k, nn_id);
+    return find_element_fallback<WIDEK>(m, x, y, k, nn_id, tri);
 }
 
 // ------------------------------------------------------- intersections -------------------
@@ -379,13 +410,10 @@ RT_HD __forceinline__ bool order_points(double phi, double x1, double y1, double
 // branch in which the reference reads an unassigned variable (n_int == 3, all coincident).
 // `eq` receives the index (0..2) of the cell edge the exit point q lies on (-1 if q was not
 // produced): the walk step uses it to predict the next cell through the adjacency table.
-RT_HD __forceinline__ bool intersections(const DGeo &m, int32_t cell, double phi, double tA, double tB,
+RT_HD __forceinline__ bool intersections(const Tri &t, double phi, double tA, double tB,
                                               double tC, double &px, double &py, double &qx, double &qy, int &eq) {
     eq = -1;
-    const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
-    const double x1 = m.x[n1], y1 = m.y[n1];
-    const double x2 = m.x[n2], y2 = m.y[n2];
-    const double x3 = m.x[n3], y3 = m.y[n3];
+    const double x1 = t.x1, y1 = t.y1, x2 = t.x2, y2 = t.y2, x3 = t.x3, y3 = t.y3;
     double ex0 = 0, ey0 = 0, ex1 = 0, ey1 = 0, ex2 = 0, ey2 = 0;
     const int h0 = edge_hit(tA, tB, tC, x1, y1, x2, y2, ex0, ey0);
     const int h1 = edge_hit(tA, tB, tC, x2, y2, x3, y3, ex1, ey1);
@@ -435,12 +463,13 @@ struct GenericOut {
 template <bool WIDEK>
 RT_HD __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element, double phi,
                                          double tA, double tB, double tC, GenericOut &o) {
-    const int32_t element = find_element<WIDEK>(m, xpx, xpy, k);  // src/track.jl:122 and :138-139
+    Tri tri;
+    const int32_t element = find_element<WIDEK>(m, xpx, xpy, k, tri);  // src/track.jl:122 and :138-139
     o.element = element;
     if (element < 0) return 2;
     if (element == prev_element) return 1;  // :147-150
     int eq;
-    if (!intersections(m, element, phi, tA, tB, tC, o.px, o.py, o.qx, o.qy, eq)) return 3;  // :153
+    if (!intersections(tri, phi, tA, tB, tC, o.px, o.py, o.qx, o.qy, eq)) return 3;  // :153
     o.eq = eq;
     if (isapprox_v2(o.px, o.py, o.qx, o.qy)) return 1;  // :156-159
     o.ell = norm2(o.px - o.qx, o.py - o.qy);            // Segment ctor, src/segment.jl:31-33
@@ -452,12 +481,13 @@ RT_HD __noinline__ int generic_step(const DGeo &m, double xpx, double xpy, int k
 template <bool WIDEK>
 RT_HD __noinline__ bool generic_tiny_step(const DGeo &m, double xpx, double xpy, int k, int32_t prev_element,
                                                double phi, double tA, double tB, double tC) {
-    const int32_t element = find_element<WIDEK>(m, xpx, xpy, k);
+    Tri tri;
+    const int32_t element = find_element<WIDEK>(m, xpx, xpy, k, tri);
     if (element < 0) return false;
     if (element == prev_element) return true;
     double px, py, qx, qy;
     int eq;
-    if (!intersections(m, element, phi, tA, tB, tC, px, py, qx, qy, eq)) return false;
+    if (!intersections(tri, phi, tA, tB, tC, px, py, qx, qy, eq)) return false;
     return isapprox_v2(px, py, qx, qy);
 }
 
@@ -497,9 +527,8 @@ struct Walk {
 
 // State for the next walk step after a segment was emitted by the generic step in `cell` with
 // its exit point on edge `ko` (0..2).
-RT_HD __forceinline__ void walk_enter(const DMesh &m, const DGeo &g, Walk &w, int32_t cell, int ko) {
-    const int32_t n1 = g.cn[3 * cell], n2 = g.cn[3 * cell + 1], n3 = g.cn[3 * cell + 2];
-    const double x1 = g.x[n1], y1 = g.y[n1], x2 = g.x[n2], y2 = g.y[n2], x3 = g.x[n3], y3 = g.y[n3];
+RT_HD __forceinline__ void walk_enter(const DMesh &m, const Tri &t, Walk &w, int32_t cell, int ko) {
+    const double x1 = t.x1, y1 = t.y1, x2 = t.x2, y2 = t.y2, x3 = t.x3, y3 = t.y3;
     w.T = cell;
     w.dT = m.wrec[3 * cell].dT;
     w.ax = ko == 0 ? x1 : (ko == 1 ? x2 : x3);

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
             element = spk->s_el[pi];
             px = spk->s_px[pi]; py = spk->s_py[pi]; qx = spk->s_qx[pi]; qy = spk->s_qy[pi]; ell = spk->s_ell[pi];
             const int seq = spk->s_eq[pi];
-            if (m.walk_ok && seq >= 0) walk_enter(m, load_geo(m.geo), wk, element, seq);
+            if (m.walk_ok && seq >= 0) walk_enter(m, load_tri(load_geo(m.geo), element), wk, element, seq);
             else { wk.T = element; wk.pred = -1; }
             seed_pending = false;
         } else {
@@ -483,7 +483,8 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
 #endif
         if (__builtin_expect(res == kWalkGeneric, 0)) {
             const DGeo g = load_geo(m.geo);  // scalar loads, here only: the generic step's pointers and grid parameters
-            element = find_element<WIDEK>(g, xpx, xpy, prm.k);        // :122 and :138-139
+            Tri tri;
+            element = find_element<WIDEK>(g, xpx, xpy, prm.k, tri);   // :122 and :138-139
             if (element < 0) { st = RT_TRACK_LOCATE_FAILED; break; }  // :140-143
             // Creep: a track that leaves a cell at a very small angle next to a vertex takes hundreds of tiny
             // steps here (BWR-like config 4: 229 in a row through a 7e-8 sliver), each a full locate by one
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
                 continue;
             }
             int eq;
-            if (!intersections(g, element, phi, tA, tB, tC, px, py, qx, qy, eq)) {  // :153
+            if (!intersections(tri, phi, tA, tB, tC, px, py, qx, qy, eq)) {  // :153
                 st = RT_TRACK_UNDEF_INTERSECTION;
                 break;
             }
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
                                                                   offsetof(MarchArgsLayout, fail_info)) + 15,
                               (unsigned long long)__popcll(act));
             }
-            if (m.walk_ok && eq >= 0) walk_enter(m, g, wk, element, eq);
+            if (m.walk_ok && eq >= 0) walk_enter(m, tri, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
         }
         }
@@ -999,7 +1000,9 @@ struct rt_mesh {
     hipStream_t stream = nullptr;
     int32_t n_nodes = 0, n_cells = 0;
     DevBuf<double> x, y;
-    DevBuf<int32_t> cn, ncp, ncd, gstart, gnode;
+    DevBuf<int32_t> cn, ncp, ncd, gstart, gnode, c3start, c3node;
+    DevBuf<double> c3x, c3y;
+    DevBuf<rt::FanEntry> fan;
     DevBuf<rt::WalkRec> wrec;
     DevBuf<int32_t> adjr;
     DevBuf<rt::DGeo> geo;
@@ -1144,6 +1147,18 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     if ((rc = upload(m->ncd, ncd.data(), (size_t)nnz, s))) return rc;
     if ((rc = upload(m->gstart, gstart.data(), gstart.size(), s))) return rc;
     if ((rc = upload(m->gnode, gnode.data(), (size_t)n_nodes, s))) return rc;
+    if ((rc = upload(m->c3start, P.c3start.data(), P.c3start.size(), s))) return rc;
+    if ((rc = upload(m->c3node, P.c3node.data(), P.c3node.size(), s))) return rc;
+    if ((rc = upload(m->c3x, P.c3x.data(), P.c3x.size(), s))) return rc;
+    if ((rc = upload(m->c3y, P.c3y.data(), P.c3y.size(), s))) return rc;
+    std::vector<rt::FanEntry> fan((size_t)std::max(nnz, 1));
+    for (int32_t i = 0; i < nnz; ++i) {  // node -> cells with the cells' vertices, in the table's own order
+        const int32_t c = ncd[i];
+        rt::FanEntry &e = fan[i];
+        e.x1 = x[cn[3 * c]]; e.y1 = y[cn[3 * c]]; e.x2 = x[cn[3 * c + 1]]; e.y2 = y[cn[3 * c + 1]]; e.x3 = x[cn[3 * c + 2]]; e.y3 = y[cn[3 * c + 2]];
+        e.cell = c; e.pad_[0] = e.pad_[1] = e.pad_[2] = 0;
+    }
+    if ((rc = upload(m->fan, fan.data(), fan.size(), s))) return rc;
     if ((rc = upload(m->wrec, reinterpret_cast<const rt::WalkRec *>(P.wrec.data()), P.wrec.size(), s))) return rc;
     if ((rc = upload(m->adjr, P.adjr.data(), P.adjr.size(), s))) return rc;
     RT_HIP(hipStreamSynchronize(s));  // host vectors die at return
@@ -1154,6 +1169,8 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     rt::DGeo g{};
     g.x = as_global(m->x.p); g.y = as_global(m->y.p); g.cn = as_global(m->cn.p); g.ncp = as_global(m->ncp.p);
     g.ncd = as_global(m->ncd.p); g.gstart = as_global(m->gstart.p); g.gnode = as_global(m->gnode.p);
+    g.c3start = as_global(m->c3start.p); g.c3node = as_global(m->c3node.p); g.c3x = as_global(m->c3x.p); g.c3y = as_global(m->c3y.p);
+    g.fan = as_global((const rt::FanEntry *)m->fan.p);
     g.gx0 = bb[0]; g.gy0 = bb[1]; g.gh = gh; g.ginv = ginv; g.gnx = gnx; g.gny = gny;
     g.n_nodes = n_nodes;
     if ((rc = upload(m->geo, &g, 1, s))) return rc;
@@ -1175,7 +1192,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
 
 void free_mesh(rt_mesh *m) {
     m->x.release(); m->y.release(); m->cn.release(); m->ncp.release(); m->ncd.release();
-    m->gstart.release(); m->gnode.release(); m->wrec.release(); m->adjr.release(); m->geo.release();
+    m->gstart.release(); m->gnode.release(); m->c3start.release(); m->c3node.release(); m->c3x.release(); m->c3y.release(); m->fan.release(); m->wrec.release(); m->adjr.release(); m->geo.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }

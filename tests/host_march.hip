@@ -113,14 +113,15 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
                 ++cnt[4];
                 __atomic_fetch_add(&g_reasons[refusal_reason(m, wk, nr, kk, phi, tA, tB, tC, xpx, xpy, lqx, lqy)], 1, __ATOMIC_RELAXED);
             }
-            element = k > kMaxK ? find_element<true>(g, xpx, xpy, k) : find_element<false>(g, xpx, xpy, k);
+            Tri tri;
+            element = k > kMaxK ? find_element<true>(g, xpx, xpy, k, tri) : find_element<false>(g, xpx, xpy, k, tri);
             if (element < 0) { st = 1; break; }
             if (element == prev_element) { xpx = xpx + sx; xpy = xpy + sy; continue; }
             int eq;
-            if (!intersections(g, element, phi, tA, tB, tC, px, py, qx, qy, eq)) { st = 3; break; }
+            if (!intersections(tri, phi, tA, tB, tC, px, py, qx, qy, eq)) { st = 3; break; }
             if (isapprox_v2(px, py, qx, qy)) { xpx = xpx + sx; xpy = xpy + sy; continue; }
             ell = norm2(px - qx, py - qy);
-            if (m.walk_ok && eq >= 0) walk_enter(m, g, wk, element, eq);
+            if (m.walk_ok && eq >= 0) walk_enter(m, tri, wk, element, eq);
             else { wk.T = element; wk.pred = -1; }
             ++cnt[2];
         } else {
@@ -157,6 +158,16 @@ int64_t hostmarch_run(const double *x, const double *y, int32_t n_nodes, const i
     g.x = rt::as_global(x); g.y = rt::as_global(y); g.cn = rt::as_global((const int32_t *)cn.data());
     g.ncp = rt::as_global(ncp); g.ncd = rt::as_global((const int32_t *)ncd.data());
     g.gstart = rt::as_global((const int32_t *)P.gstart.data()); g.gnode = rt::as_global((const int32_t *)P.gnode.data());
+    g.c3start = rt::as_global((const int32_t *)P.c3start.data()); g.c3node = rt::as_global((const int32_t *)P.c3node.data());
+    g.c3x = rt::as_global((const double *)P.c3x.data()); g.c3y = rt::as_global((const double *)P.c3y.data());
+    std::vector<rt::FanEntry> fan((size_t)std::max(ncp[n_nodes], 1));
+    for (int32_t i = 0; i < ncp[n_nodes]; ++i) {
+        const int32_t c = ncd[i];
+        rt::FanEntry &e = fan[i];
+        e.x1 = x[cn[3 * c]]; e.y1 = y[cn[3 * c]]; e.x2 = x[cn[3 * c + 1]]; e.y2 = y[cn[3 * c + 1]]; e.x3 = x[cn[3 * c + 2]]; e.y3 = y[cn[3 * c + 2]];
+        e.cell = c;
+    }
+    g.fan = rt::as_global((const rt::FanEntry *)fan.data());
     g.gx0 = bb[0]; g.gy0 = bb[1]; g.gh = P.gh; g.ginv = P.ginv; g.gnx = P.gnx; g.gny = P.gny; g.n_nodes = n_nodes;
     rt::DMesh m{};
     m.wrec = rt::as_global(reinterpret_cast<const rt::WalkRec *>(P.wrec.data()));
