@@ -53,10 +53,10 @@ static_assert(sizeof(WalkRec) == 80, "WalkRec layout");
 // order (the values of x[], y[] behind cn[]) — 64 B, four independent 16-B loads instead of the chain ncd -> cn -> x, y.
 struct __attribute__((aligned(16))) FanEntry {
     double x1, y1, x2, y2, x3, y3;
-    int32_t cell, pad_[3];
+    int32_t cell, adj[3];  // adj[k]: the walk record reached across edge k of the cell (adjr[3*cell + k]), -1 on the boundary
 };
 static_assert(sizeof(FanEntry) == 64, "FanEntry layout");
-struct Tri { double x1, y1, x2, y2, x3, y3; };  // a cell's vertices in its node order
+struct Tri { double x1, y1, x2, y2, x3, y3; int32_t adj[3]; };  // a cell's vertices in its node order + its three successors
 
 struct DGeo {
     const RT_G double *x;        // [n_nodes]
@@ -309,6 +309,7 @@ RT_HD __forceinline__ Tri load_tri(const DGeo &m, int32_t cell) {
     const int32_t n1 = m.cn[3 * cell], n2 = m.cn[3 * cell + 1], n3 = m.cn[3 * cell + 2];
     Tri t;
     t.x1 = m.x[n1]; t.y1 = m.y[n1]; t.x2 = m.x[n2]; t.y2 = m.y[n2]; t.x3 = m.x[n3]; t.y3 = m.y[n3];
+    t.adj[0] = t.adj[1] = t.adj[2] = -2;  // not loaded: walk_enter reads adjr
     return t;
 }
 // The cells of node_cells[node] in stored order, first hit wins (src/mesh.jl:110-118); `tri` receives the hit's vertices.
@@ -317,7 +318,11 @@ RT_HD __forceinline__ int32_t first_cell_containing(const DGeo &m, int32_t node,
         const RT_G FanEntry *e = m.fan + s;
         Tri t;
         t.x1 = e->x1; t.y1 = e->y1; t.x2 = e->x2; t.y2 = e->y2; t.x3 = e->x3; t.y3 = e->y3;
-        if (point_in_triangle(t, x, y)) { tri = t; return e->cell; }
+        if (point_in_triangle(t, x, y)) {
+            t.adj[0] = e->adj[0]; t.adj[1] = e->adj[1]; t.adj[2] = e->adj[2];
+            tri = t;
+            return e->cell;
+        }
     }
     return -1;
 }
@@ -530,14 +535,17 @@ struct Walk {
 RT_HD __forceinline__ void walk_enter(const DMesh &m, const Tri &t, Walk &w, int32_t cell, int ko) {
     const double x1 = t.x1, y1 = t.y1, x2 = t.x2, y2 = t.y2, x3 = t.x3, y3 = t.y3;
     w.T = cell;
-    w.dT = m.wrec[3 * cell].dT;
+    // det of the barycentric system in the cell's node order, with the reference's operations (src/mesh.jl:166-168): the
+    // same expression the host evaluated for the walk records, hence the same bits — no load
+    w.dT = x1 * (y2 - y3) + y1 * (x3 - x2) + (x2 * y3 - y2 * x3);
     w.ax = ko == 0 ? x1 : (ko == 1 ? x2 : x3);
     w.ay = ko == 0 ? y1 : (ko == 1 ? y2 : y3);
     w.bx = ko == 0 ? x2 : (ko == 1 ? x3 : x1);
     w.by = ko == 0 ? y2 : (ko == 1 ? y3 : y1);
     w.cx = ko == 0 ? x3 : (ko == 1 ? x1 : x2);
     w.cy = ko == 0 ? y3 : (ko == 1 ? y1 : y2);
-    w.pred = m.adjr[3 * cell + ko];
+    const int32_t a = ko == 0 ? t.adj[0] : (ko == 1 ? t.adj[1] : t.adj[2]);
+    w.pred = a != -2 ? a : m.adjr[3 * cell + ko];
 }
 
 enum WalkResult { kWalkGeneric = 0, kWalkSkip = 1, kWalkEmit = 2 };

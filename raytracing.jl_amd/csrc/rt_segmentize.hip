@@ -1156,7 +1156,8 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
         const int32_t c = ncd[i];
         rt::FanEntry &e = fan[i];
         e.x1 = x[cn[3 * c]]; e.y1 = y[cn[3 * c]]; e.x2 = x[cn[3 * c + 1]]; e.y2 = y[cn[3 * c + 1]]; e.x3 = x[cn[3 * c + 2]]; e.y3 = y[cn[3 * c + 2]];
-        e.cell = c; e.pad_[0] = e.pad_[1] = e.pad_[2] = 0;
+        e.cell = c;
+        for (int q = 0; q < 3; ++q) e.adj[q] = P.adjr[(size_t)3 * c + q];
     }
     if ((rc = upload(m->fan, fan.data(), fan.size(), s))) return rc;
     if ((rc = upload(m->wrec, reinterpret_cast<const rt::WalkRec *>(P.wrec.data()), P.wrec.size(), s))) return rc;

@@ -166,6 +166,7 @@ int64_t hostmarch_run(const double *x, const double *y, int32_t n_nodes, const i
         rt::FanEntry &e = fan[i];
         e.x1 = x[cn[3 * c]]; e.y1 = y[cn[3 * c]]; e.x2 = x[cn[3 * c + 1]]; e.y2 = y[cn[3 * c + 1]]; e.x3 = x[cn[3 * c + 2]]; e.y3 = y[cn[3 * c + 2]];
         e.cell = c;
+        for (int q = 0; q < 3; ++q) e.adj[q] = P.adjr[(size_t)3 * c + q];
     }
     g.fan = rt::as_global((const rt::FanEntry *)fan.data());
     g.gx0 = bb[0]; g.gy0 = bb[1]; g.gh = P.gh; g.ginv = P.ginv; g.gnx = P.gnx; g.gny = P.gny; g.n_nodes = n_nodes;
