@@ -83,7 +83,9 @@ def kernel_names(stats):
     beside the split kernel that marches the longest waves in pieces; the phase time covers both."""
     w = stats["march_waves"]
     sp = stats["split"] == 1
-    return {"march": "rt::k_march<2, %d, %s, %s, false>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false"),
+    cheap = stats.get("cheap_records", 0) > 0  # the TOPO instantiation (cheap steps) ran
+    return {"march": "rt::k_march<2, %d, %s, %s, false, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
+                                                                  "true" if cheap else "false"),
             "compact": "rt::k_compact3<%s>" % ("true" if sp else "false"), "scan": "rt::k_scan_write"}
 
 

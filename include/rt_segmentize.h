@@ -93,7 +93,9 @@ void rt_mesh_destroy(rt_mesh *mesh);
 #define RT_MESH_INFO_PREP_MS 11          /* host time of the preprocessing inside rt_mesh_create */
 #define RT_MESH_INFO_KAPPA 12            /* expected segments per unit track length (Cauchy-Crofton) */
 #define RT_MESH_INFO_WALK_AVAILABLE 13   /* 1: at least one record can be walked */
-#define RT_MESH_INFO_COUNT 14
+#define RT_MESH_INFO_RECORDS_CHEAP 14    /* records on which the cheap step's certificates can hold (subset of RECORDS_WALK) */
+#define RT_MESH_INFO_TINY_MAX 15         /* ... for tiny_step <= this value (larger tiny_step: exact walk steps only) */
+#define RT_MESH_INFO_COUNT 16
 int32_t rt_mesh_info(rt_mesh *mesh, double *info, int32_t n_info, char *note, int32_t note_cap);
 
 /* Enqueue all later work of this mesh's track sets on an existing hipStream_t (NULL = the
@@ -193,7 +195,9 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
  * literal step (the walk step produced the rest; track pieces' seeds in split mode count as neither), stats[2]
  * staging chunks used, stats[3] staging chunks allocated; if n allows: stats[4] waves per workgroup of the march kernel
  * the call launched, stats[5] 1 if it marched track pieces (split mode; 2: only the longest waves), stats[6] 1 for the wide-k instantiation,
- * stats[7] bytes of device memory this handle holds (inputs, staging pools, tables, results).
+ * stats[7] bytes of device memory this handle holds (inputs, staging pools, tables, results), stats[8] records decided by
+ * cheap steps (a subset of the walk step's: the decision from the vertices' signed distances to the track line alone,
+ * option "topo"; 0 when the call did not use them).
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 

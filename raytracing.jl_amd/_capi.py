@@ -212,7 +212,8 @@ class DeviceMesh:
             raise RtError(f"rt_mesh_create failed: {last_error()}")
 
     INFO_NAMES = ("walk_enabled", "records", "records_walk", "eps_min", "eps_max", "d_vertex", "l_min", "cells_fragile",
-                  "cells_degenerate", "edges_nonmanifold", "extras_max", "prep_ms", "kappa", "walk_available")
+                  "cells_degenerate", "edges_nonmanifold", "extras_max", "prep_ms", "kappa", "walk_available", "records_cheap",
+                  "cheap_tiny_max")
 
     def info(self) -> dict:
         """``rt_mesh_info``: which regime the march of this mesh runs in (walk step on / off, how many
@@ -222,7 +223,7 @@ class DeviceMesh:
         _check(lib().rt_mesh_info(self._h, v, len(self.INFO_NAMES), note, 256))
         d = {k: float(v[i]) for i, k in enumerate(self.INFO_NAMES)}
         for k in ("walk_enabled", "records", "records_walk", "cells_fragile", "cells_degenerate", "edges_nonmanifold",
-                  "extras_max", "walk_available"):
+                  "extras_max", "walk_available", "records_cheap"):
             d[k] = int(d[k])
         d["note"] = note.value.decode("utf-8", "replace")
         return d
@@ -354,10 +355,11 @@ class DeviceTracks:
 
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
-        v = (C.c_int64 * 8)()
-        _check(lib().rt_last_stats(self._h, v, 8))
+        v = (C.c_int64 * 9)()
+        _check(lib().rt_last_stats(self._h, v, 9))
         return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
-                    chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]), device_bytes=int(v[7]))
+                    chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]), device_bytes=int(v[7]),
+                    cheap_records=int(v[8]))
 
     def timing(self):
         ms = getattr(self, "_ms_buf", None)

@@ -58,6 +58,19 @@ struct __attribute__((aligned(16))) FanEntry {
 static_assert(sizeof(FanEntry) == 64, "FanEntry layout");
 struct Tri { double x1, y1, x2, y2, x3, y3; int32_t adj[3]; };  // a cell's vertices in its node order + its three successors
 
+// Cheap-step record of the two-phase march for (cell, entry edge): 32 B, two 16-B loads (rt_mesh_prep.hpp, TopoRecHost).
+constexpr uint32_t kTopoEndV = (1u << kWalkIdBits) - 1;  // successor field: the exit edge lies on a vertical border
+constexpr uint32_t kTopoEndH = (1u << kWalkIdBits) - 2;  // ... on a horizontal border
+constexpr int kTopoKcap = 4096;
+struct __attribute__((aligned(16))) TopoRec {
+    uint64_t hdr;       // as WalkRec::hdr; successor fields may hold kTopoEndV / kTopoEndH; own extras / eps code
+    double x2, y2;      // the vertex opposite the entry edge
+    uint32_t c01, c23;  // bfloat16 patterns: g1 | k2 << 16, dtf | lc << 16
+};
+static_assert(sizeof(TopoRec) == 32, "TopoRec layout");
+struct __attribute__((aligned(16))) EdgeABC { double A, B, C, pad; };
+static_assert(sizeof(EdgeABC) == 32, "EdgeABC layout");
+
 struct DGeo {
     const RT_G double *x;        // [n_nodes]
     const RT_G double *y;        // [n_nodes]
@@ -84,6 +97,8 @@ struct DMesh {
     int32_t n_cells;
     double bx0, by0, bx1, by1;   // bounding box (bb_min, bb_max)
     const RT_K DGeo *geo;        // device copy of the generic step's data
+    const RT_G struct TopoRec *trec;  // [3*n_cells] cheap-step records of the two-phase march (topo_step)
+    const RT_G struct EdgeABC *etab;  // [3*n_cells] general_form of edge k of cell c at 3*c + k
 };
 
 // The generic step's data, fetched with scalar loads where it is needed.
@@ -111,6 +126,7 @@ struct DParams {
     int32_t k;
     int32_t n_azim_2;
     int64_t iter_cap;
+    double topo_tiny_max, topo_rmax, topo_end_err;  // two-phase march (topo_track); unused elsewhere
 };
 
 // ---------------------------------------------------------------- Base.isapprox ----------
@@ -720,6 +736,151 @@ RT_HD __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const 
     bool tie;
     const bool t_first = shallow_T_first(w, numT, rT, adT, x2, y2, (int32_t)((uint32_t)(w.pred >= 0 ? w.pred : 0) / 3u), xpx, xpy, tie);
     return !tie && t_first;
+}
+
+// ------------------------------------------------------------ two-phase march: cheap step -
+// The two-phase march (k_march<..., TOPO> + k_emit) splits a walk step into the DECISION — which cell the
+// reference emits next, entered and left through which edges — and the ARITHMETIC of the record (exit point,
+// length), which k_emit evaluates later for all records in parallel with the reference's formulas.  The decision
+// needs no point at all: with s_i the signed distances of the predicted cell's vertices from the track line,
+//   * the line leaves T' through the edge whose end points lie on opposite sides (|s_i| >= d_vertex: certificate 1
+//     of walk_step, unchanged);
+//   * every position xp the reference visits before it emits in T' — q + tiny·d and further tiny steps while it
+//     still locates T (src/track.jl:147-150) — stays where only T and T' can pass the reference's test, T' does
+//     pass, and `inboundary` is false.  Sufficient, in terms of m = min(|s0|, |s1|) and D = |s0| + |s1| (the entry
+//     point has barycentric coordinates (|s1|, |s0|, 0) / D in T'):  m >= E·D + g1,  D >= k2,  D·c1 >= dtf
+//     (rt_mesh_prep.hpp derives the per-record constants E, g1, k2, dtf, lc);
+//   * the record is (previous exit point, exit point on the predicted edge): the chord is >= lc-guarded above l_min
+//     and above the rounding that could flip order_intersection_points (src/intersection.jl:151-159).
+// Whether the reference took 0 or 300 tiny steps before emitting does not reach the output, so unlike walk_step
+// the cheap step does not decide skip/emit per position; it bounds the number of those steps (kTopoKcap) and adds
+// the bound to the iteration counter — a track whose bound reaches the iteration cap is marched again with exact
+// steps only.  A lane whose cheap step refuses takes the exact step (walk_step / generic) for that record:
+// results never depend on which path was taken.
+struct TopoTrack {   // per-track constants
+    double dv;       // vertex clearance
+    double c1;       // (kTopoKcap - 2) · tiny / √eps
+    float c2;        // √eps / tiny · 1.01: tiny steps per unit of dtf / D
+    double lcf;      // max(1, topo_rmax / |cos ϕ|)
+    bool end_v, end_h;  // an exit through an edge on a vertical / horizontal border ends the track for sure
+    bool on;         // the cheap step may be used for this track
+};
+struct TopoState {
+    int32_t pred;    // record of the predicted cell (3·T' + entry edge), -1: none
+    int32_t last;    // 3·T + exit edge of the last emitted record
+    double sa, sb;   // signed distances of the end points (a, b) of T's exit edge, in T's edge orientation
+};
+enum TopoResult { kTopoFull = 0, kTopoEmit = 1, kTopoEnd = 2 };
+
+RT_HD __forceinline__ double bf16_lo(uint32_t w) { return (double)__builtin_bit_cast(float, w << 16); }
+RT_HD __forceinline__ double bf16_hi(uint32_t w) { return (double)__builtin_bit_cast(float, w & 0xffff0000u); }
+
+// intersection(track.ABC, edge.ABC) — src/intersection.jl:127-138 (the expression walk_step uses for its exit point)
+RT_HD __forceinline__ void edge_exit_point(double tA, double tB, double tC, double eA, double eB, double eC, double &qx, double &qy) {
+    const double a = tB * eA;
+    const double b = eB * tA;
+    const double det = a - b;
+    qx = (tC * eB - eC * tB) / det;
+    qy = (tA * eC - eA * tC) / det;
+}
+
+// The cheap step in three pieces (k_march issues the loads of the NEXT record between the first and the second):
+// topo_geo — which edge the line leaves T' through and what comes behind it; topo_certified — the certificates;
+// topo_commit — advance the state.  topo_step is the three in a row (tests/host_march.hip).
+struct TopoGeo {
+    double s0, s1, s2;  // signed distances of v0, v1 (entry edge, in T''s orientation) and v2 from the track line
+    bool exit1;         // the line leaves through rotated edge 1 = (v1, v2), else edge 2 = (v2, v0)
+    uint32_t nx;        // successor field behind the exit edge: record + 1, 0, kTopoEndV / kTopoEndH
+    int32_t code;       // 3·T' + exit edge (in T''s own edge numbering)
+    int32_t cell;       // T'
+};
+RT_HD __forceinline__ TopoGeo topo_geo(const TopoState &ts, uint64_t hdr, double x2, double y2, double tA, double tB, double tC) {
+    TopoGeo g;
+    const bool same = rec_same(hdr);
+    g.s0 = same ? ts.sa : ts.sb; g.s1 = same ? ts.sb : ts.sa;
+    g.s2 = __builtin_fma(tA, x2, __builtin_fma(tB, y2, tC));
+    g.exit1 = (g.s1 > 0) != (g.s2 > 0);
+    g.nx = g.exit1 ? (uint32_t)(hdr & ((1u << kWalkIdBits) - 1)) : (uint32_t)((hdr >> kWalkIdBits) & ((1u << kWalkIdBits) - 1));
+    const int32_t pr = ts.pred >= 0 ? ts.pred : 0;
+    const int32_t Tn = (int32_t)((uint32_t)pr / 3u), e = pr - 3 * Tn;
+    int ko = e + (g.exit1 ? 1 : 2);
+    ko = ko >= 3 ? ko - 3 : ko;
+    g.code = 3 * Tn + ko;
+    g.cell = Tn;
+    return g;
+}
+// successor record behind the exit edge, -1: none (boundary, or no certified record)
+RT_HD __forceinline__ int32_t topo_next(const TopoGeo &g) { return (g.nx - 1u) < (kTopoEndH - 1u) ? (int32_t)g.nx - 1 : -1; }
+// `kub`: upper bound of the reference's iterations for this record — 1 + at most √eps·dtf / (tiny·D) + 2 tiny steps (<= kTopoKcap)
+RT_HD __forceinline__ bool topo_certified(const TopoTrack &tt, const TopoState &ts, const TopoGeo &g, uint64_t hdr, uint32_t c01,
+                                          uint32_t c23, int kk, int32_t &kub) {
+    const double a0 = fabs(g.s0), a1 = fabs(g.s1), a2 = fabs(g.s2);
+    const double D = a0 + a1, m = a0 < a1 ? a0 : a1;
+    const double sv = g.exit1 ? a1 : a0, Dx = a2 + sv;
+    const double g1 = bf16_lo(c01), k2 = bf16_hi(c01), dtf = bf16_lo(c23), lc = bf16_hi(c23);
+    // (evaluated without short-circuits: a branch here would also pull the record's second load behind the first compare)
+    const int ok = (int)(ts.pred >= 0) & (int)(rec_extras(hdr) <= kk) & (int)(a2 >= tt.dv) & (int)((g.s0 > 0) != (g.s1 > 0)) &
+                   (int)(m >= __builtin_fma(rec_eps(hdr), D, g1)) & (int)(D >= k2) & (int)(Dx >= k2) & (int)(D * tt.c1 >= dtf) &
+                   (int)(sv >= lc * tt.lcf);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float kf = (float)dtf * tt.c2 * __builtin_amdgcn_rcpf((float)D) * 1.001f;
+#else
+    float kf = (float)dtf * tt.c2 / (float)D * 1.001f;
+#endif
+    kf = kf < (float)kTopoKcap ? kf : (float)kTopoKcap;  // (D·c1 >= dtf: never more than kTopoKcap; also absorbs a NaN)
+    kub = (int32_t)kf + 4;
+    return ok != 0;
+}
+// kTopoEmit: on to the successor (pred = -1 when there is none with a certificate: exact steps from `last`);
+// kTopoEnd: the exit edge lies on the border and the track ends for sure after this record
+RT_HD __forceinline__ int topo_commit(const TopoTrack &tt, TopoState &ts, const TopoGeo &g) {
+    ts.last = g.code;
+    ts.sa = g.exit1 ? g.s1 : g.s2;
+    ts.sb = g.exit1 ? g.s2 : g.s0;
+    ts.pred = topo_next(g);
+    return ((g.nx == kTopoEndV && tt.end_v) || (g.nx == kTopoEndH && tt.end_h)) ? kTopoEnd : kTopoEmit;
+}
+// One cheap step.  kTopoEmit / kTopoEnd: `code` = 3·T' + exit edge of the emitted record, `kub` bounds the reference's
+// iterations for it, the state is advanced.  kTopoFull: nothing changed.
+RT_HD __forceinline__ int topo_step(const TopoTrack &tt, TopoState &ts, uint64_t hdr, double x2, double y2, uint32_t c01,
+                                    uint32_t c23, int kk, double tA, double tB, double tC, int32_t &code, int32_t &kub) {
+    const TopoGeo g = topo_geo(ts, hdr, x2, y2, tA, tB, tC);
+    if (!topo_certified(tt, ts, g, hdr, c01, c23, kk, kub)) return kTopoFull;
+    code = g.code;
+    return topo_commit(tt, ts, g);
+}
+
+// Can the lane take cheap steps after an exact step left it in cell wk.T with the prediction wk.pred?
+RT_HD __forceinline__ bool topo_enter(const DMesh &m, const TopoTrack &tt, const Walk &wk, double tA, double tB, double tC, TopoState &ts) {
+    if (!(tt.on && wk.pred >= 0)) return false;
+    const double sa = __builtin_fma(tA, wk.ax, __builtin_fma(tB, wk.ay, tC)), sb = __builtin_fma(tA, wk.bx, __builtin_fma(tB, wk.by, tC));
+    if (!(fabs(sa) >= tt.dv && fabs(sb) >= tt.dv && ((sa > 0) != (sb > 0)))) return false;
+    ts.pred = wk.pred; ts.sa = sa; ts.sb = sb;
+    ts.last = m.adjr[wk.pred];  // the record reached back across T''s entry edge: 3·T + exit edge
+    return true;
+}
+
+// The exact step's state after cheap steps: the last record was emitted in cell last / 3 with exit edge last % 3.
+RT_HD __forceinline__ void topo_materialize(const DMesh &m, const DGeo &g, int32_t last, double tA, double tB, double tC, Walk &wk,
+                                            double &lqx, double &lqy) {
+    const int32_t cell = (int32_t)((uint32_t)last / 3u), ko = last - 3 * cell;
+    walk_enter(m, load_tri(g, cell), wk, cell, ko);
+    const RT_G EdgeABC *e = m.etab + last;
+    edge_exit_point(tA, tB, tC, e->A, e->B, e->C, lqx, lqy);
+}
+
+RT_HD __forceinline__ TopoTrack topo_track(bool mesh_on, double d_vertex, double tiny_max, double rmax, double end_err, double tiny,
+                                           double cs, double sn) {
+    TopoTrack tt;
+    tt.dv = d_vertex;
+    tt.c1 = (double)(kTopoKcap - 2) * tiny / kRtolDefault;
+    tt.c2 = (float)(1.01 * kRtolDefault / tiny);
+    const double ac = fabs(cs), as = fabs(sn);
+    tt.lcf = ac * 1.0 >= rmax ? 1.0 : rmax / ac;
+    tt.end_v = tiny * (1.0 - ac) >= 2.0 * end_err + 1e-300;
+    tt.end_h = tiny * (1.0 - as) >= 2.0 * end_err + 1e-300;
+    tt.on = mesh_on && tiny > 0.0 && tiny <= tiny_max && ac > 0.0 && tt.lcf < 1e6;
+    return tt;
 }
 
 }  // namespace rt

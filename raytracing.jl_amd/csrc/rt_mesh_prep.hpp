@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -64,9 +65,55 @@ struct WalkRecHost {
 };
 static_assert(sizeof(WalkRecHost) == 80, "WalkRec layout");
 
+// Topological walk record for (cell T', entry edge e) — the "cheap step" of the two-phase march (rt_device.hpp,
+// `topo_step`): what a lane needs to decide, from the signed distances of the cell's vertices to the track line alone,
+// that the reference emits its next segment in T' with entry on the shared edge and exit on one other edge — without
+// computing any point.  32 B = two 16-B loads.  Must match rt::TopoRec.
+//   hdr: as WalkRecHost::hdr, except that a successor field may hold kTopoEndV / kTopoEndH (the exit edge lies on a
+//        vertical / horizontal border of the bounding box) and that extras / eps code are the cheap step's own;
+//   x2, y2: the vertex opposite the entry edge;
+//   g1, k2, dtf, lc: certificate constants, bfloat16 bit patterns rounded UP (see `prepare`).
+constexpr uint32_t kTopoEndV = (1u << kWalkIdBits) - 1;
+constexpr uint32_t kTopoEndH = (1u << kWalkIdBits) - 2;
+constexpr int kTopoKcap = 4096;  // tiny steps the reference may take between two emitted segments under a cheap step
+struct TopoRecHost {
+    uint64_t hdr;
+    double x2, y2;
+    uint16_t g1, k2, dtf, lc;
+};
+static_assert(sizeof(TopoRecHost) == 32, "TopoRec layout");
+struct EdgeABCHost { double A, B, C, pad; };  // general_form of edge k of cell c at [3*c + k], reference operations
+static_assert(sizeof(EdgeABCHost) == 32, "EdgeABC layout");
+
+// smallest bfloat16 (as its 16-bit pattern) that is >= v, for v > 0; 0x7f80 (inf) when out of range
+inline uint16_t bf16_up(double v) {
+    if (!(v > 0)) return 0;
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, INFINITY);
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    uint32_t hi = b >> 16;
+    if ((b & 0xffffu) != 0) ++hi;
+    if (hi >= 0x7f80u) return 0x7f80u;
+    return (uint16_t)hi;
+}
+inline double bf16_value(uint16_t h) {
+    const uint32_t b = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return (double)f;
+}
+
 struct Prep {
     std::vector<WalkRecHost> wrec;  // [3*n_cells]
     std::vector<int32_t> adjr;      // [3*n_cells] record index reached across edge k of cell c, -1 on the boundary
+    std::vector<TopoRecHost> trec;  // [3*n_cells] cheap-step records of the two-phase march
+    std::vector<EdgeABCHost> etab;  // [3*n_cells] general forms of the cells' edges
+    bool topo_ok = false;           // some record can take the cheap step
+    double topo_tiny_max = 0.0;     // the cheap step's certificates hold for tiny_step <= this
+    double topo_rmax = 0.0;         // order guard: a track needs |s_v| >= lc * max(1, topo_rmax / |cos ϕ|)
+    double topo_end_err = 0.0;      // |computed exit coordinate - border| bound on border edges
+    int64_t n_records_topo = 0;
     // node grid
     int gnx = 1, gny = 1;
     double gh = 1.0, ginv = 1.0;
@@ -460,6 +507,110 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         }
     }
     if (P.n_records_walk == 0) { P.eps_min = 0.0; if (P.walk_ok) { P.walk_ok = false; if (P.note.empty()) P.note = "no cell passes the walk certificates"; } }
+
+    // ---- cheap-step ("topological") records of the two-phase march.  rt_device.hpp `topo_step` states what the
+    //      lane checks; here are the constants, each a sufficient bound with room to spare:
+    //  With s_i the signed (scaled, |s| <= distance) distances of v0, v1, v2 from the track line, D = |s0| + |s1|,
+    //  m = min(|s0|, |s1|): the entry point has barycentric coordinates (1-u, u, 0), u = |s0| / D, in T'.
+    //   * δ, the error of the computed entry point (= the exit point computed for T) plus the rounding of up to
+    //     kTopoKcap additions of the step vector: |δ| <= κ0·lmax/D + δ_add; k2 = κ0·lmax·g / (0.3·tol) makes
+    //     g·κ0·lmax/D <= 0.3·tol (g = 1 / smallest altitude of T'), and records with g·δ_add > 0.075·tol are left out:
+    //     xp is never more than 0.375·tol (barycentric) outside the entry edge — the depth the isolation regions
+    //     above were computed for, and T' passes its own test there.
+    //   * the reference keeps stepping while it locates T again, which ends for sure once xp is 1.5·tol·h_T (+|δ|)
+    //     beyond the shared edge, after a path of at most tol·dtf/D + tiny with dtf = 1.5·|dT| + 0.375·|dT'|;
+    //     D·(kTopoKcap - 2)·tiny/tol >= dtf bounds the number of those steps by kTopoKcap.
+    //   * along that path the two exit-side coordinates stay >= E (isolation margin of the walk records, and the
+    //     distance > tiny from every border that `inboundary` needs) if m >= (E + 0.375·tol + g·tiny_max)·D + g·tol·dtf:
+    //     the record's eps code holds the first factor, g1 = g·tol·dtf.
+    //   * lc: the chord in T' is at least 2·tan(γ/2)·|s_v| (v: the vertex shared by entry and exit edge, γ its angle);
+    //     |s_v| >= lc keeps it above l_min and (with the per-track factor topo_rmax/|cos ϕ|) above twice the rounding of
+    //     both end points divided by |cos ϕ| — the order of the pair cannot flip (src/intersection.jl:151-159).
+    P.trec.assign((size_t)3 * std::max(n_cells, 1), TopoRecHost{});
+    P.etab.assign((size_t)3 * std::max(n_cells, 1), EdgeABCHost{});
+    for (int32_t c = 0; c < n_cells; ++c)
+        for (int k = 0; k < 3; ++k) P.etab[(size_t)3 * c + k] = {P.rec[c].eA[k], P.rec[c].eB[k], P.rec[c].eC[k], 0.0};
+    {
+        const double corner = std::hypot(cmax_x, cmax_y);
+        const double kappa0 = 20.0 * kUlp * corner;
+        const double dadd = 3.0 * kTopoKcap * kUlp * corner;
+        P.topo_tiny_max = 1e-6 * l_max;
+        const bool ids_fit = (uint64_t)3 * (uint64_t)n_cells + 3 < (1ull << kWalkIdBits);
+        double rmax = 0.0, end_err = 0.0;
+        for (int32_t c = 0; c < n_cells; ++c) {
+            const CellRecHost &R = P.rec[c];
+            for (int e = 0; e < 3; ++e) {
+                const WalkRecHost &Wr = P.wrec[(size_t)3 * c + e];
+                TopoRecHost &Tr = P.trec[(size_t)3 * c + e];
+                const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+                int extras = (int)((Wr.hdr >> (2 * kWalkIdBits)) & 15);
+                int code = (int)((Wr.hdr >> (2 * kWalkIdBits + 4)) & 31);
+                uint64_t n1 = Wr.hdr & ((1ull << kWalkIdBits) - 1), n2 = (Wr.hdr >> kWalkIdBits) & ((1ull << kWalkIdBits) - 1);
+                // border exits: the edge lies exactly on a side of the bounding box
+                auto end_code = [&](int ia, int ib) -> uint64_t {
+                    const double xa = R.vx[ia], ya = R.vy[ia], xb = R.vx[ib], yb = R.vy[ib];
+                    if (xa == xb && (xa == bb[0] || xa == bb[2]) && ya != yb) {
+                        end_err = std::max(end_err, std::fabs(xa) * (2 * kUlp * (std::fabs(ya) + std::fabs(yb)) / std::fabs(ya - yb) + 12 * kUlp));
+                        return kTopoEndV;
+                    }
+                    if (ya == yb && (ya == bb[1] || ya == bb[3]) && xa != xb) {
+                        end_err = std::max(end_err, std::fabs(ya) * (2 * kUlp * (std::fabs(xa) + std::fabs(xb)) / std::fabs(xa - xb) + 12 * kUlp));
+                        return kTopoEndH;
+                    }
+                    return 0;
+                };
+                if (n1 == 0 && R.adj[i1] < 0) n1 = end_code(i1, i2);
+                if (n2 == 0 && R.adj[i2] < 0) n2 = end_code(i2, i0);
+                double g1 = 0, k2 = 0, dtf = 0, lc = 0;
+                bool ok = ids_fit && P.walk_ok && extras < kExtrasNever && R.cls == 0 && R.adj[e] >= 0 && P.rec[R.adj[e]].cls == 0;
+                if (ok) {
+                    const CellRecHost &Tp = P.rec[R.adj[e]];
+                    const double hmin = R.area2 / R.lmax, g = 1.0 / hmin;
+                    ok = g * dadd <= 0.075 * kTol;
+                    // isolation margin, border clearance (inboundary(xp, tiny) must stay false along the path)
+                    double E = std::ldexp(1.0, code - 20);
+                    const double b0[4] = {R.vx[i0] - bb[0], bb[2] - R.vx[i0], R.vy[i0] - bb[1], bb[3] - R.vy[i0]};
+                    const double b1[4] = {R.vx[i1] - bb[0], bb[2] - R.vx[i1], R.vy[i1] - bb[1], bb[3] - R.vy[i1]};
+                    const double b2[4] = {R.vx[i2] - bb[0], bb[2] - R.vx[i2], R.vy[i2] - bb[1], bb[3] - R.vy[i2]};
+                    for (int q = 0; q < 4 && ok; ++q) {
+                        const double den = b0[q] + b1[q];
+                        if (!(den > 0)) { ok = false; break; }
+                        E = std::max(E, (1.001 * P.topo_tiny_max + 16 * kUlp * corner + 0.375 * kTol * std::fabs(b2[q])) / den);
+                    }
+                    const double E1 = 1.01 * (E + 0.375 * kTol + g * P.topo_tiny_max);
+                    int tcode = kEpsCodeMin;
+                    while (tcode <= kEpsCodeMax && std::ldexp(1.0, tcode - 20) < E1) ++tcode;
+                    ok = ok && tcode <= kEpsCodeMax;
+                    code = std::min(tcode, kEpsCodeMax);
+                    dtf = 1.01 * (1.5 * Tp.area2 + 0.375 * R.area2);
+                    g1 = 1.01 * g * kTol * dtf;
+                    k2 = 1.01 * kappa0 * R.lmax * g / (0.3 * kTol);
+                    // angles at v0 and v1 (the ends of the entry edge)
+                    auto half_tan = [&](int iv, int ia, int ib) {
+                        const double ux = R.vx[ia] - R.vx[iv], uy = R.vy[ia] - R.vy[iv], wx = R.vx[ib] - R.vx[iv], wy = R.vy[ib] - R.vy[iv];
+                        const double cr = std::fabs(ux * wy - uy * wx), dt = ux * wx + uy * wy;
+                        return std::tan(0.5 * std::atan2(cr, dt));
+                    };
+                    const double cv = 2.0 * std::min(half_tan(i0, i1, i2), half_tan(i1, i2, i0)) * (1.0 - 1e-9);
+                    ok = ok && cv > 1e-3;
+                    if (ok) {
+                        lc = 1.05 * (P.l_min + 1.2 * kTol * hmin) / cv;
+                        rmax = std::max(rmax, 1.2 * kTol * hmin / (P.l_min + 1.2 * kTol * hmin));
+                    }
+                    ok = ok && bf16_up(g1) < 0x7f80u && bf16_up(k2) < 0x7f80u && bf16_up(dtf) < 0x7f80u && bf16_up(lc) < 0x7f80u;
+                }
+                if (!ok) { extras = kExtrasNever; code = kEpsCodeMax; }
+                else ++P.n_records_topo;
+                Tr.hdr = n1 | (n2 << kWalkIdBits) | ((uint64_t)(extras & 15) << (2 * kWalkIdBits)) |
+                         ((uint64_t)(code & 31) << (2 * kWalkIdBits + 4)) | (Wr.hdr & (1ull << 63));
+                Tr.x2 = R.vx[i2]; Tr.y2 = R.vy[i2];
+                Tr.g1 = bf16_up(g1); Tr.k2 = bf16_up(k2); Tr.dtf = bf16_up(dtf); Tr.lc = bf16_up(lc);
+            }
+        }
+        P.topo_rmax = 1.01 * rmax;
+        P.topo_end_err = end_err;
+        P.topo_ok = P.n_records_topo > 0;
+    }
     return P;
 }
 

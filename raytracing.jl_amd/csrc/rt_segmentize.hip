@@ -286,8 +286,17 @@ __device__ __forceinline__ const RT_K DStage *march_stage_args() {
 // LDSREC (experiment, option "lds_records"): the workgroup first copies ALL walk records of the mesh into LDS and the
 // lanes fetch their next record from there instead of from L2 — only meshes of a few hundred cells fit (80 B per record,
 // three per cell); see DESIGN.md §4 for what it measures.
-template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false, bool LDSREC = false>
-__global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 3 : 0) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
+// TOPO (whole tracks, staged): the walk step split into a DECISION that needs no point at all (rt_device.hpp, topo_geo /
+// topo_certified: which cell the reference emits next, through which edges — from the signed distances of the cell's
+// vertices to the track line) and the ARITHMETIC of the record (exit point on the predicted edge with the reference's
+// formula, ℓ), which no longer feeds the next iteration: a lane's dependent chain per record is one 32-B record fetch and
+// a dozen instructions, and the next record's fetch is in flight while the certificates and the record are evaluated.
+// The exact step (walk_step / generic) runs only for the lanes whose cheap step refused.
+template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false, bool LDSREC = false, bool TOPO = false>
+#ifndef RT_TOPO_OCC
+#define RT_TOPO_OCC 0
+#endif
+__global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) ? 3 : (TOPO ? RT_TOPO_OCC : 0)) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
                                                       unsigned long long *__restrict__ fail_info, DSplit sp) {
@@ -296,6 +305,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
     // that their 17 pointers do not occupy scalar registers across the loop.
     const RT_K DSplit *spk = (const RT_K DSplit *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, sp));
     (void)sp;
+    static_assert(!TOPO || (MODE == kStage && !SPLIT && !LDSREC), "two-phase march: staged whole tracks only");
     constexpr bool FUSE = WAVES > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
@@ -390,6 +400,22 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
     asm volatile("" : "+v"(mh.d_vertex), "+v"(mh.l_min), "+v"(mh.wrec));
     NextRec nr;
     load_next(mh, -1, nr);
+    // two-phase march: per-lane state of the cheap step
+    TopoTrack tt = topo_track(TOPO && m.walk_ok, m.d_vertex, prm.topo_tiny_max, prm.topo_rmax, prm.topo_end_err, prm.tiny_step, t.cs[u], t.sn[u]);
+    TopoState ts;
+    ts.pred = -1; ts.last = 0; ts.sa = ts.sb = 0.0;
+    // kFlCheap: the lane takes cheap steps; kFlUsed: it has taken some (`it` is then an upper bound of the reference's
+    // iterations); kFlMat: the exact step's state has to be rebuilt from `ts.last`; kFlWait: nothing to do until the wave
+    // has no cheap lane left (an uncertified last step, a finished track); kFlDone / kFlRestart: see below
+    constexpr uint32_t kFlCheap = 1, kFlUsed = 2, kFlMat = 4, kFlWait = 8, kFlDone = 16, kFlRestart = 32;
+    uint32_t fl = 0;
+    int32_t last_word = 0;  // staging word of the lane's last record
+    // (the cheap loop stores without a branch: should the pool run out before a lane's first chunk — the attempt is void
+    //  then and the host re-runs it — its row pointers must still be addresses inside the pool)
+    if (TOPO) { row_qx = stg.qx + lane; row_qy = stg.qy + lane; row_el = stg.element + lane; }
+    const RT_G TopoRec *trec_v = m.trec;
+    const RT_G EdgeABC *etab_v = m.etab;
+    if (TOPO) asm volatile("" : "+v"(trec_v), "+v"(etab_v));
     // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
     // band.  Run as its own loop so that the 64 lanes of the wave, whose bands differ in length
     // (≈1/sin ϕ or 1/|cos ϕ| steps), reach their first locate together.
@@ -401,6 +427,35 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
     unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tn = 0, tD = 0, wits = 0, wgen = 0;
     const unsigned long long tstart = rt_tick(xpx);
 #endif
+    // First row of a new chunk for a lane: wave-aggregated allocation among the lanes that are here.
+    // chunk_lds[j] caches what the wave already owns.
+    auto alloc_chunk = [&](const int j) -> int32_t {
+        bool pending = true;
+        int32_t mine = -1;
+        for (;;) {
+            const unsigned long long mask = __ballot(pending);
+            if (!mask) break;
+            const int L = __ffsll((long long)mask) - 1;
+            const int jL = __shfl(j, L);
+            int32_t c = chunk_lds[jL];
+            if (c == -1) {
+                if (lane == L) {
+                    const RT_K DStage *sk = march_stage_args();
+                    RT_G int32_t *cursor = sk->cursor;
+                    c = atomicAdd((int32_t *)&cursor[0], 1);
+                    if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
+                    else {
+                        sk->ctab[wave_id * kMaxChunks + jL] = c;
+                        sk->cowner[c] = (int32_t)(wave_id * kMaxChunks + jL);
+                    }
+                    chunk_lds[jL] = c;
+                }
+                c = __shfl(c, L);
+            }
+            if (pending && j == jL) { mine = c; pending = false; }
+        }
+        return mine;
+    };
     // A lane whose track creeps (see below) for more than kCreepLocal tiny steps leaves the march loop and
     // waits for the wave: once every lane is out, all 64 lanes test 64 consecutive creep positions of that
     // track at a time (cooperative creep), then the lane marches on.
@@ -408,7 +463,102 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
     int creep_run = 0;  // generic tiny steps in a row
     for (;;) {
     while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter && !creep_escalate) {  // :119
-        if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
+        if (TOPO) {
+            // ---- cheap steps: a wave-uniform inner loop that runs while some lane is in cheap mode and no lane is due
+            //      for an exact step (lanes whose track has ended, or that wait with an uncertified last step, idle here)
+            {
+                // Software pipeline, one record deep: iteration n decides record n (A) and does the arithmetic of record
+                // n - 1 (B).  Its loads — the next record and record n's exit edge — are issued before B's stores and
+                // waited for at the end of the iteration, behind B's ≈150 instructions: gfx950 retires loads and stores
+                // through one in-order counter, so a load issued after a store would wait for that store's
+                // acknowledgement as well (that, not the arithmetic, was half of an iteration's time).
+                const RT_G TopoRec *R = trec_v + (ts.pred >= 0 ? ts.pred : 0);
+                uint64_t c_hdr = R->hdr;
+                double c_x2 = R->x2, c_y2 = R->y2;
+                uint32_t c_c01 = R->c01, c_c23 = R->c23;
+                bool pend = false;              // a decided record waits for its arithmetic
+                double pe_A = 0.0, pe_B = 0.0, pe_C = 0.0;  // its exit edge's general form
+                int32_t p_cell = 0;
+                // record i - 1: exit point, length, staging, fill_volumes, Σℓ.  Executed by every lane, without a branch
+                // around the stores (the compiler counts outstanding memory operations per path: behind a conditional
+                // store it waits for everything): a lane without a pending record stores its last record again.
+                auto arithmetic = [&]() {
+                    double qx, qy;
+                    edge_exit_point(tA, tB, tC, pe_A, pe_B, pe_C, qx, qy);  // the walk step's exit point, src/intersection.jl:127-138
+                    const double ell = norm2(lqx - qx, lqy - qy);            // Segment ctor, src/segment.jl:31-33
+                    const int rw = (i - 1) & (kChunkRows - 1);
+                    if (__builtin_expect(pend && rw == 0, 0)) {
+                        my_chunk = alloc_chunk((i - 1) >> kChunkLog2);
+                        if (my_chunk >= 0) {
+                            const int64_t o0 = stage_slot(my_chunk, 0, lane);
+                            const RT_K DStage *sk = march_stage_args();
+                            row_qx = sk->qx + o0; row_qy = sk->qy + o0; row_el = sk->element + o0;
+                        }
+                    }
+                    lqx = pend ? qx : lqx; lqy = pend ? qy : lqy;
+                    last_word = pend ? p_cell + 1 : last_word;
+                    row_qx[rw * 16] = lqx; row_qy[rw * 16] = lqy; row_el[rw * 16] = last_word;
+                    if (FUSE) atomicAdd(&hist[p_cell], pend ? w * ell : 0.0);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
+                    sum_ell += pend ? ell : 0.0;
+                };
+                for (;;) {
+                    const bool cheap = (fl & kFlCheap) != 0;
+                    if (!__ballot(cheap)) break;
+                    if (__ballot((fl & (kFlCheap | kFlWait)) == 0)) break;
+                    // (A) record n: where the line leaves the cell; its loads
+                    const TopoGeo g = topo_geo(ts, c_hdr, c_x2, c_y2, tA, tB, tC);
+                    const int32_t np = topo_next(g);
+                    const RT_G TopoRec *Rn = trec_v + (np >= 0 ? np : 0);
+                    const uint64_t n_hdr = Rn->hdr;
+                    const double n_x2 = Rn->x2, n_y2 = Rn->y2;
+                    const uint32_t n_c01 = Rn->c01, n_c23 = Rn->c23;
+                    const RT_G EdgeABC *E = etab_v + g.code;
+                    const double eA = E->A, eB = E->B, eC = E->C;
+                    asm volatile("" ::: "memory");  // the loads above stay above the stores below
+                    // (B) record n - 1
+                    arithmetic();
+                    // (A) the certificates of record n
+                    int32_t kub;
+                    const bool ok = topo_certified(tt, ts, g, c_hdr, c_c01, c_c23, kk, kub);
+                    const bool over = it + kub > cap;  // (`it` is an upper bound of the reference's iterations after cheap steps)
+                    pend = cheap && ok && !over;
+                    if (pend) {
+                        ++i;
+                        it += kub;
+                        const int r = topo_commit(tt, ts, g);
+                        fl |= kFlUsed;
+                        if (r == kTopoEnd) fl = (fl & ~kFlCheap) | kFlDone | kFlWait;  // on the border, within tiny_step: :130-132
+                        else if (ts.pred < 0) fl = (fl & ~kFlCheap) | kFlMat | kFlWait;
+                        else if (i >= kMaxIter) fl = (fl & ~kFlCheap) | kFlWait;
+                    } else if (cheap) {
+                        fl = (fl & ~kFlCheap) | (ok ? kFlRestart : kFlMat);  // refused: the exact step decides this record
+                    }
+                    c_hdr = n_hdr; c_x2 = n_x2; c_y2 = n_y2; c_c01 = n_c01; c_c23 = n_c23;
+                    pe_A = eA; pe_B = eB; pe_C = eC; p_cell = g.cell;
+                }
+                if (pend) arithmetic();
+            }
+            const bool any_cheap = __ballot((fl & kFlCheap) != 0) != 0;
+            if ((fl & kFlDone) || i >= kMaxIter) break;
+            if ((fl & kFlCheap) || ((fl & kFlWait) && any_cheap)) continue;  // (an uncertified last step waits until no lane is cheap)
+            if (__builtin_expect((fl & kFlRestart) || ((fl & kFlUsed) && it >= cap), 0)) {
+                // the bound reached the iteration cap: this track is marched again from its start with exact steps only
+                asm volatile("" ::: "memory");
+                tt.on = false; fl = 0;
+                i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
+                xpx = t.px[u] + sx; xpy = t.py[u] + sy;
+                continue;
+            }
+        }
+        if (++it > cap) { if (TOPO && (fl & kFlUsed)) continue; st = RT_TRACK_ITER_CAP; break; }
+        if (TOPO && __builtin_expect((fl & kFlMat) != 0, 0)) {
+            asm volatile("" ::: "memory");
+            fl &= ~kFlMat;
+            const int32_t cell = (int32_t)((uint32_t)ts.last / 3u);
+            walk_enter(m, load_tri(load_geo(m.geo), cell), wk, cell, ts.last - 3 * cell);
+            xpx = lqx + sx; xpy = lqy + sy;
+            prev_element = cell;
+        }
 #ifdef RT_TIMING
         const unsigned long long tA_ = rt_tick(xpx);
         unsigned long long tC_ = 0;
@@ -469,6 +619,14 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
             continue;
         }
         px = lqx; py = lqy; element = wk.T;  // valid when res == kWalkEmit
+        if (TOPO && res == kWalkEmit) {
+            // per-call statistic: records of exact walk steps in a two-phase call (the cheap steps made the rest)
+            const unsigned long long act = __ballot(1);
+            if (lane == __ffsll((long long)act) - 1)
+                atomicAdd(*(unsigned long long *const RT_K *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                              offsetof(MarchArgsLayout, fail_info)) + 14,
+                          (unsigned long long)__popcll(act));
+        }
 #ifdef RT_STATS
         if (MODE != kFill && !SPLIT) {
             const unsigned long long any_gen = __ballot(res == kWalkGeneric);
@@ -534,35 +692,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
             if (out.fused_volumes) unsafeAtomicAdd((double *)&out.volumes[element], w * ell);  // src/trackgenerator.jl:382
         } else if (MODE == kStage) {
             const int r = i & (kChunkRows - 1);
-            if (__builtin_expect(r == 0, 0)) {
-                // First row of a new chunk for this lane: wave-aggregated allocation among the
-                // lanes that are here.  chunk_lds[j] caches what the wave already owns.
-                const int j = i >> kChunkLog2;
-                bool pending = true;
-                my_chunk = -1;
-                for (;;) {
-                    const unsigned long long mask = __ballot(pending);
-                    if (!mask) break;
-                    const int L = __ffsll((long long)mask) - 1;
-                    const int jL = __shfl(j, L);
-                    int32_t c = chunk_lds[jL];
-                    if (c == -1) {
-                        if (lane == L) {
-                            const RT_K DStage *sk = march_stage_args();
-                            RT_G int32_t *cursor = sk->cursor;
-                            c = atomicAdd((int32_t *)&cursor[0], 1);
-                            if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
-                            else {
-                                sk->ctab[wave_id * kMaxChunks + jL] = c;
-                                sk->cowner[c] = (int32_t)(wave_id * kMaxChunks + jL);
-                            }
-                            chunk_lds[jL] = c;
-                        }
-                        c = __shfl(c, L);
-                    }
-                    if (pending && j == jL) { my_chunk = c; pending = false; }
-                }
-            }
+            if (__builtin_expect(r == 0, 0)) my_chunk = alloc_chunk(i >> kChunkLog2);
             if (my_chunk >= 0) {
                 if (r == 0) {  // per-lane addresses of the chunk's row 0, kept in VGPRs (the staging pointers are
                                // SGPR tuples that do not survive the generic branch unspilled)
@@ -577,6 +707,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
                 const bool derived = res == kWalkEmit && !from_seed;
                 row_qx[r * 16] = qx; row_qy[r * 16] = qy;
                 row_el[r * 16] = derived ? element + 1 : -(element + 1);
+                if (TOPO) last_word = derived ? element + 1 : -(element + 1);
                 if (__builtin_expect(!derived, 0)) {
                     const int64_t o = stage_slot(my_chunk, r, lane);
                     const RT_K DStage *sk = march_stage_args();
@@ -594,6 +725,7 @@ __global__ __launch_bounds__(64 * WAVES, SPLIT && MODE == kStage && WAVES > 1 ? 
         xpx = qx + sx; xpy = qy + sy;  // :165
         prev_element = element;        // :166
         ++i;                           // :168
+        if (TOPO) fl = (fl & kFlUsed) | (topo_enter(mh, tt, wk, tA, tB, tC, ts) ? kFlCheap : 0u);
     }
     // ---- cooperative creep: every lane of the wave is out of the march loop here
     unsigned long long need = __ballot(creep_escalate);
@@ -1005,6 +1137,8 @@ struct rt_mesh {
     DevBuf<rt::FanEntry> fan;
     DevBuf<rt::WalkRec> wrec;
     DevBuf<int32_t> adjr;
+    DevBuf<rt::TopoRec> trec;   // two-phase march: cheap-step records and the cells' edge general forms
+    DevBuf<rt::EdgeABC> etab;
     DevBuf<rt::DGeo> geo;
     rt::DMesh d{};
     rt_enqueue_hook enqueue_hook = nullptr;  // see rt_mesh_set_enqueue_hook
@@ -1015,6 +1149,11 @@ struct rt_mesh {
     int single_pass = 1;   // 1: staged single-pass march + compaction, 0: count / scan / fill (two marches)
     int split = -1;         // track splitting (see DSplit), read by rt_tracks_create: -1 auto (only batches that leave the chip
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
+    int n_cus = 256;
+    int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it
+    bool topo_available = false;
+    double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0;
+    int64_t n_records_topo = 0;
     int hybrid = 0;        // 1: batches that fill the chip march only their longest waves in pieces, beside the whole-track march of the rest
                            // (measured slower at every threshold on MI355X — the full batch is within 1.6x of its throughput floor — DESIGN.md §4)
     int lds_records = 0;   // experiment: 1 = eight-wave workgroups with all walk records in LDS (meshes that fit), 2 = the same shape from L2
@@ -1071,6 +1210,8 @@ struct rt_tracks {
     int32_t azim_min = 1, azim_max = 0;  // range of azim_idx (checked against n_azim_2 by rt_segmentize)
     int64_t n_generic_records = 0;       // rt_last_stats
     bool force_unsplit = false;  // a track reached MAX_ITER segments in split mode: this track set marches whole from now on
+    int32_t last_topo = 0;  // 1: the last call ran the two-phase march
+    int64_t n_exact_walk_records = 0;  // ... and this many of its records came from exact walk steps
     int32_t last_march_waves = 0, last_split = 0, last_widek = 0;  // which instantiation of the march the last call launched
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     void *pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rt_fetch_segments_pinned
@@ -1162,6 +1303,8 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     if ((rc = upload(m->fan, fan.data(), fan.size(), s))) return rc;
     if ((rc = upload(m->wrec, reinterpret_cast<const rt::WalkRec *>(P.wrec.data()), P.wrec.size(), s))) return rc;
     if ((rc = upload(m->adjr, P.adjr.data(), P.adjr.size(), s))) return rc;
+    if ((rc = upload(m->trec, reinterpret_cast<const rt::TopoRec *>(P.trec.data()), P.trec.size(), s))) return rc;
+    if ((rc = upload(m->etab, reinterpret_cast<const rt::EdgeABC *>(P.etab.data()), P.etab.size(), s))) return rc;
     RT_HIP(hipStreamSynchronize(s));  // host vectors die at return
     m->n_nodes = n_nodes;
     m->n_cells = n_cells;
@@ -1181,6 +1324,10 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     d.n_cells = n_cells;
     d.wrec = as_global(m->wrec.p); d.adjr = as_global(m->adjr.p); d.d_vertex = P.d_vertex; d.l_min = P.l_min;
     d.walk_ok = P.walk_ok ? 1 : 0;
+    d.trec = as_global((const rt::TopoRec *)m->trec.p); d.etab = as_global((const rt::EdgeABC *)m->etab.p);
+    m->topo_available = P.walk_ok && P.topo_ok;
+    m->topo_tiny_max = P.topo_tiny_max; m->topo_rmax = P.topo_rmax; m->topo_end_err = P.topo_end_err;
+    m->n_records_topo = P.n_records_topo;
     m->walk_available = P.walk_ok;
     m->kappa = P.kappa;
     m->prep_note = P.note;
@@ -1193,7 +1340,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
 
 void free_mesh(rt_mesh *m) {
     m->x.release(); m->y.release(); m->cn.release(); m->ncp.release(); m->ncd.release();
-    m->gstart.release(); m->gnode.release(); m->c3start.release(); m->c3node.release(); m->c3x.release(); m->c3y.release(); m->fan.release(); m->wrec.release(); m->adjr.release(); m->geo.release();
+    m->gstart.release(); m->gnode.release(); m->c3start.release(); m->c3node.release(); m->c3x.release(); m->c3y.release(); m->fan.release(); m->wrec.release(); m->adjr.release(); m->trec.release(); m->etab.release(); m->geo.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -1312,6 +1459,10 @@ static rt_mesh *mesh_create_impl(int32_t device, const double *x, const double *
     rt_mesh *m = new rt_mesh();
     struct Guard { rt_mesh *p; ~Guard() { if (p) free_mesh(p); } } guard{m};  // released on success
     m->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->n_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipStreamCreate failed");
         return nullptr;
@@ -1363,6 +1514,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "topo")) { mesh->topo = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
     if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
@@ -1559,6 +1711,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
     rt::DParams prm;
     prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
+    prm.topo_tiny_max = m->topo_tiny_max; prm.topo_rmax = m->topo_rmax; prm.topo_end_err = m->topo_end_err;
 
     const int64_t n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
     const int64_t n_waves = (n + 63) / 64;
@@ -1602,6 +1755,10 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     const bool plan_ok = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit;
     const bool hybrid = plan_ok && t->hybrid && fuse_;
     const bool split = plan_ok && (!t->hybrid || hybrid);  // pieces are marched in this call
+    // Cheap steps (k_march<..., TOPO>): whole-track batches on meshes with cheap-step records, the usual k, fill_volumes fused.
+    const bool topo = m->single_pass && m->topo && m->topo_available && m->d.walk_ok && !split && !hybrid && !widek_ && n > 0 &&
+                      fuse_ && tiny_step > 0 && tiny_step <= m->topo_tiny_max && m->lds_records == 0;
+    t->last_topo = topo ? 1 : 0;
     if (split) {
         sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
         sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
@@ -1675,11 +1832,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     hipStream_t march_stream = s;          // (the hybrid path launches its pieces on the auxiliary stream)
     const rt::DTracks *march_tracks = &t->d;
     const rt::DStage *march_stage = &stg;
-    auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK, bool LDSREC = false>(unsigned blocks, size_t smem) -> int {
+    auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK, bool LDSREC = false, bool TOPO = false>(unsigned blocks, size_t smem) -> int {
         t->last_march_waves = WAVES; t->last_split = std::max(t->last_split, SPLIT ? 1 : 0); t->last_widek = WIDEK ? 1 : 0;
         if (smem > 48 * 1024)
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC>), dim3(blocks), dim3(64 * WAVES), smem, march_stream, m->d, *march_tracks, prm,
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC, TOPO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC, TOPO>), dim3(blocks), dim3(64 * WAVES), smem, march_stream, m->d, *march_tracks, prm,
                            t->counts.p, t->status.p, march_offsets, out, *march_stage, d_fail, sp);
         return RT_SUCCESS;
     };
@@ -1772,7 +1929,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     // experiment: eight-wave workgroups (one per CU) with all walk records in LDS (1), or from L2 as usual (2: its control)
                     const size_t lds_base = ((hist_bytes + 8 * rt::kMaxChunks * sizeof(int32_t) + 15) & ~(size_t)15);
                     const size_t lds_smem = lds_base + (size_t)3 * m->n_cells * sizeof(rt::WalkRec);
-                    if (fuse && m->lds_records == 1 && !hybrid && lds_smem <= 160 * 1024)
+                    if (topo && fuse_waves == 4)
+                        rc = march.template operator()<rt::kStage, 4, false, false, false, true>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
+                    else if (topo)
+                        rc = march.template operator()<rt::kStage, 6, false, false, false, true>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
+                    else if (fuse && m->lds_records == 1 && !hybrid && lds_smem <= 160 * 1024)
                         rc = march.template operator()<rt::kStage, 8, false, false, true>((unsigned)((n_whole_waves + 7) / 8), lds_smem);
                     else if (fuse && m->lds_records == 2 && !hybrid && lds_smem <= 160 * 1024)
                         rc = march.template operator()<rt::kStage, 8, false, false, false>((unsigned)((n_whole_waves + 7) / 8), lds_smem);
@@ -1895,6 +2056,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     t->total = total;
     t->total_last = total;
     t->n_generic_records = (int64_t)fi[15];
+    t->n_exact_walk_records = topo ? (int64_t)fi[14] : 0;
     t->n_failed = (int64_t)fi[0];
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
     t->first_failed_status = 0;
@@ -2051,7 +2213,8 @@ int32_t rt_mesh_info(rt_mesh *m, double *info, int32_t n_info, char *note, int32
     const double v[RT_MESH_INFO_COUNT] = {
         (double)(m->d.walk_ok ? 1 : 0), (double)m->n_records, (double)m->n_records_walk, m->eps_min, m->eps_max,
         m->d.d_vertex, m->d.l_min, (double)m->n_cells_fragile, (double)m->n_cells_wild, (double)m->n_edges_nonmanifold,
-        (double)m->extras_max, m->prep_ms, m->kappa, (double)(m->walk_available ? 1 : 0)};
+        (double)m->extras_max, m->prep_ms, m->kappa, (double)(m->walk_available ? 1 : 0),
+        (double)(m->topo_available ? m->n_records_topo : 0), m->topo_tiny_max};
     for (int i = 0; i < n_info && i < RT_MESH_INFO_COUNT; ++i) info[i] = v[i];
     if (note && note_cap > 0) {
         strncpy(note, m->prep_note.c_str(), (size_t)note_cap - 1);
@@ -2070,6 +2233,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 4) stats[4] = t->last_march_waves;
     if (n > 5) stats[5] = t->last_split;  // 0 whole tracks, 1 pieces, 2 hybrid (pieces for the longest waves only)
     if (n > 6) stats[6] = t->last_widek;
+    if (n > 8) stats[8] = t->last_topo ? t->total - t->n_generic_records - t->n_exact_walk_records : 0;  // records made by cheap steps
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
         stats[7] = b(t->px) + b(t->py) + b(t->phi) + b(t->cs) + b(t->sn) + b(t->A) + b(t->B) + b(t->C) + b(t->ell) + b(t->azim) + b(t->perm) +

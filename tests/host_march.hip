@@ -66,10 +66,18 @@ int64_t g_reasons[8];
 
 // counters: [0] walk emits, [1] walk skips (incl. creep passes), [2] generic emits, [3] generic iterations in total,
 // [4] generic iterations taken although a prediction existed (a certificate refused)
+// `tt0.on`: two-phase march — cheap steps (topo_step) wherever their certificates hold, the record's arithmetic as
+// k_emit evaluates it (edge_exit_point with the cell's edge table, p = previous q, ℓ = ‖p − q‖); cnt[5] cheap emits,
+// cnt[6] cheap refusals (mid-track), cnt[7] restarts with exact steps only (iteration bound reached the cap).
 void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, double phi, double cs, double sn, double tA,
                  double tB, double tC, double track_ell, double tiny, int k, double rtol, int64_t iter_cap,
-                 std::vector<Rec> &out, int32_t &status, int64_t *cnt) {
+                 std::vector<Rec> &out, int32_t &status, int64_t *cnt, rt::TopoTrack tt0 = rt::TopoTrack{}) {
     using namespace rt;
+    const size_t out_base = out.size();
+    TopoTrack tt = tt0;
+    TopoState ts{-1, -1, 0.0, 0.0};
+    bool cheap = false, used_cheap = false;
+restart:
     const double sx = tiny * cs, sy = tiny * sn;  // advance_step, src/point.jl:43
     double xpx = px0 + sx, xpy = py0 + sy;        // src/track.jl:114
     int i = 0;
@@ -88,9 +96,46 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
         xpx = xpx + sx; xpy = xpy + sy;
     }
     while (st == 0 && i < kMaxIter) {
-        if (++it > iter_cap) { st = 4; break; }
+        if (tt.on && used_cheap && it > iter_cap) {
+            // the iteration count is only an upper bound after cheap steps: march this track again, exactly
+            out.resize(out_base);
+            tt.on = false; cheap = false; used_cheap = false;
+            ++cnt[7];
+            goto restart;
+        }
         double px, py, qx, qy, ell;
         int32_t element = -1;
+        if (cheap) {
+            const RT_G TopoRec *R = m.trec + ts.pred;
+            int32_t code, kub;
+            const int32_t last_before = ts.last;
+            const int r = topo_step(tt, ts, R->hdr, R->x2, R->y2, R->c01, R->c23, kk, tA, tB, tC, code, kub);
+            if (r != kTopoFull) {
+                const RT_G EdgeABC *e = m.etab + code;
+                edge_exit_point(tA, tB, tC, e->A, e->B, e->C, qx, qy);
+                px = lqx; py = lqy;
+                ell = norm2(px - qx, py - qy);
+                out.push_back({px, py, qx, qy, ell, code / 3 + 1});
+                sum_ell += ell;
+                lqx = qx; lqy = qy;
+                ++i; it += kub; ++cnt[5];
+                used_cheap = true;
+                if (r == kTopoEnd) break;
+                if (ts.pred >= 0) continue;
+            } else {
+                ++cnt[6];
+                (void)last_before;
+            }
+            // exact steps from the last emitted record
+            cheap = false;
+            double mqx, mqy;
+            topo_materialize(m, g, ts.last, tA, tB, tC, wk, mqx, mqy);
+            lqx = mqx; lqy = mqy;
+            xpx = lqx + sx; xpy = lqy + sy;
+            prev_element = wk.T;
+            if (!(i < kMaxIter)) break;
+        }
+        if (++it > iter_cap) { if (tt.on && used_cheap) continue; st = 4; break; }
         if (inboundary(m, xpx, xpy, tiny)) {
             if (i == 0) { xpx = xpx + sx; xpy = xpy + sy; continue; }
             break;
@@ -133,6 +178,7 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
         xpx = qx + sx; xpy = qy + sy;
         prev_element = element;
         ++i;
+        if (tt.on && wk.T == element) cheap = topo_enter(m, tt, wk, tA, tB, tC, ts);
     }
     if (st == 0 && !isapprox_s(track_ell, sum_ell, rtol)) st = 2;
     status = st;
@@ -176,6 +222,9 @@ int64_t hostmarch_run(const double *x, const double *y, int32_t n_nodes, const i
     m.d_vertex = P.d_vertex; m.l_min = P.l_min; m.walk_ok = (P.walk_ok && walk) ? 1 : 0; m.n_cells = n_cells;
     m.bx0 = bb[0]; m.by0 = bb[1]; m.bx1 = bb[2]; m.by1 = bb[3];
     m.geo = nullptr;
+    m.trec = rt::as_global(reinterpret_cast<const rt::TopoRec *>(P.trec.data()));
+    m.etab = rt::as_global(reinterpret_cast<const rt::EdgeABC *>(P.etab.data()));
+    const bool topo = walk == 2 && P.walk_ok && P.topo_ok;
     if (info) {
         info[0] = P.walk_ok ? 1 : 0; info[1] = (double)P.n_records; info[2] = (double)P.n_records_walk; info[3] = P.eps_min;
         info[4] = P.eps_max; info[5] = P.d_vertex; info[6] = (double)P.n_cells_fragile; info[7] = (double)P.n_cells_wild;
@@ -195,7 +244,8 @@ int64_t hostmarch_run(const double *x, const double *y, int32_t n_nodes, const i
                 const size_t before = part[t].size();
                 int32_t st = 0;
                 march_track(m, g, px[u], py[u], phi[u], cs[u], sn[u], A[u], B[u], C[u], ell[u], tiny, k, rtol, iter_cap,
-                            part[t], st, cnt[t].data());
+                            part[t], st, cnt[t].data(),
+                            rt::topo_track(topo, P.d_vertex, P.topo_tiny_max, P.topo_rmax, P.topo_end_err, tiny, cs[u], sn[u]));
                 counts[u] = (int64_t)(part[t].size() - before);
                 g_res.status[u] = st;
             }

@@ -69,7 +69,7 @@ def run(tg, *, k=5, rtol=None, walk=True, iter_cap=4000000, n_threads=0):
     total = lib().hostmarch_run(p(x, _dp), p(y, _dp), len(x), p(cn, _ip), len(cn) // 3, p(ptr, _ip), p(dat, _ip), p(bb, _dp),
                                 n, *[p(a, _dp) for a in arrs], float(tg.tiny_step), int(k),
                                 float(rtol if rtol is not None else 1.4901161193847656e-8), int(iter_cap),
-                                1 if walk else 0, int(n_threads), p(info, _dp))
+                                (2 if walk == 'topo' else 1) if walk else 0, int(n_threads), p(info, _dp))
     if total < 0:
         raise RuntimeError("hostmarch_run failed")
     out = {k2: np.zeros(total, np.float64) for k2 in ("px", "py", "qx", "qy", "ell")}
@@ -82,7 +82,8 @@ def run(tg, *, k=5, rtol=None, walk=True, iter_cap=4000000, n_threads=0):
     out["status"] = out["status"][:n]
     out["total"] = int(total)
     out["stats"] = dict(walk_emits=int(stats[0]), walk_skips=int(stats[1]), generic_emits=int(stats[2]),
-                        generic_iterations=int(stats[3]), refused=int(stats[4]))
+                        generic_iterations=int(stats[3]), refused=int(stats[4]),
+                        cheap_emits=int(stats[5]), cheap_refused=int(stats[6]), cheap_restarts=int(stats[7]))
     out["info"] = {k2: float(info[i]) for i, k2 in enumerate(INFO)}
     return out
 

@@ -123,7 +123,9 @@ def test_single_track_and_empty_batch(rt, orc, traced):
 
 @pytest.mark.parametrize("opts", [dict(single_pass=0), dict(single_pass=0, volumes_mode=1), dict(walk=0),
                                   dict(sort_mode=0), dict(sort_mode=1), dict(fuse_volumes=0), dict(split=48), dict(split=8), dict(split=20, walk=0),
-                                  dict(split=24, test_volumes_fallback=1), dict(split=24, fuse_volumes=0)])
+                                  dict(split=24, test_volumes_fallback=1), dict(split=24, fuse_volumes=0),
+                                  dict(split=0), dict(split=0, topo=0), dict(split=0, pool_chunks_hint=8), dict(split=0, sort_mode=0),
+                                  dict(split=0, test_out_records=20000)])
 def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
     from raytracing_jl_amd import _capi
 
@@ -352,3 +354,31 @@ def test_iteration_guard_counts_whole_tracks_when_marched_in_pieces(rt, orc):
     rt.segmentize(tg, k=k, check=False)  # default options: a small batch, marched in pieces first
     _same(tg, ref, check_volumes=False)
     assert tg.device_tracks.stats()["split"] == 0
+
+
+@pytest.mark.parametrize("iter_cap", [40, 300])
+def test_cheap_steps_keep_the_iteration_guard_exact(rt, orc, traced, iter_cap):
+    """Cheap steps bound the reference's tiny steps between two records instead of replaying them, so the iteration counter
+    is an upper bound after them; a track whose bound reaches the cap is marched again with exact steps only.  cap = 300:
+    no track of this batch really reaches it (the bound does); cap = 40: most do.  Status, counts and records equal the
+    checker's at the same cap."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(8, 2e-2)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                        tiny_step=tg.tiny_step, iter_cap=iter_cap, n_threads=0, k=5)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("split", 0)
+    dm.set_option("iter_cap", iter_cap)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    off, st = dt.fetch_offsets()
+    s = dt.fetch_segments()
+    assert np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and np.array_equal(s["element"], ref["element"])
+    for k in FIELDS:
+        assert np.array_equal(s[k], ref[k]), k
+    assert (np.count_nonzero(ref["status"] == 4) > 0) == (iter_cap == 40)
+    assert dm.info()["records_cheap"] > 0
+    print(f"iter_cap={iter_cap}: {dt.stats()}, failing {int(np.count_nonzero(st))}")

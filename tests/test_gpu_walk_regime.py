@@ -2,8 +2,9 @@
 
 56 fixed seeds of meshes on which the walk step is enabled — jittered lattices (what a mesh generator produces),
 lattices far from the origin, needle bands (gap 1e-2 … 1e-7 of the spacing), random Delaunay clouds and clusters.
-For every mesh the C-ABI path runs with the walk step on and off; both must equal the checker bit for bit, and the
-test asserts through rt_mesh_info / rt_last_stats that the first run really took walk steps and the second none."""
+For every mesh the C-ABI path runs with the walk step on (exact steps only, and with the cheap steps of the default) and
+off; all must equal the checker bit for bit, and the test asserts through rt_mesh_info / rt_last_stats that the runs really
+took walk steps / cheap steps / none."""
 import numpy as np
 import pytest
 
@@ -32,14 +33,16 @@ def _make(rt, kind, seed):
     return meshgen.random_model(rt, 1500 + seed, 300 + 250 * seed, cluster=True), 1.0
 
 
-def _run(rt, tg, walk, k=5, split=0):
+def _run(rt, tg, walk, k=5, split=0, cheap=0):
     """split=0: whole tracks per lane, so that rt_last_stats' counts are exact (pieces' seeds count as neither
-    kind); split=-1: the library's default, which marches small batches like these in pieces."""
+    kind); split=-1: the library's default, which marches small batches like these in pieces.  cheap=1: the walk step's
+    decision from the vertices' signed distances (option "topo", the default for whole-track batches), 0: exact walk steps."""
     from raytracing_jl_amd import _capi
 
     dm = _capi.DeviceMesh(tg.mesh, 0)
     dm.set_option("walk", 1 if walk else 0)
     dm.set_option("split", split)
+    dm.set_option("topo", cheap)
     dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
     aq = tg.azimuthal_quadrature
     total = dt.segmentize(tg.tiny_step, k, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
@@ -71,12 +74,19 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
                         tiny_step=tg.tiny_step, iter_cap=4000000, n_threads=0)
     aq = tg.azimuthal_quadrature
     ref["volumes"] = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
-    on, off = _run(rt, tg, True), _run(rt, tg, False)
+    on, off, cheap = _run(rt, tg, True), _run(rt, tg, False), _run(rt, tg, True, cheap=1)
     _same(on, ref, "walk on")
     _same(off, ref, "walk off")
-    _same(_run(rt, tg, True, split=-1), ref, "walk on, default splitting")
+    _same(cheap, ref, "walk on, cheap steps")
+    _same(_run(rt, tg, True, split=-1, cheap=1), ref, "walk on, default splitting")
     info = on["info"]
     assert off["info"]["walk_enabled"] == 0 and off["stats"]["walk_records"] == 0
+    assert on["stats"]["cheap_records"] == 0 and off["stats"]["cheap_records"] == 0
+    assert cheap["stats"]["cheap_records"] <= cheap["stats"]["walk_records"] == on["stats"]["walk_records"]
+    if info["records_cheap"] > 0 and tg.tiny_step <= info["cheap_tiny_max"]:
+        assert cheap["stats"]["cheap_records"] > 0, (info, cheap["stats"])
+    else:
+        assert cheap["stats"]["cheap_records"] == 0
     frac = on["stats"]["walk_records"] / max(ref["total"], 1)
     if info["cells_fragile"] == model.num_cells:
         # thousands of units from the origin the reference's own barycentric test is rounding noise at the √eps level
@@ -87,6 +97,8 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
         assert on["stats"]["walk_records"] > 0
     if kind == "lattice":
         assert info["records_walk"] >= 0.85 * info["records"] and frac > 0.7, (info, on["stats"])
+        assert cheap["stats"]["cheap_records"] >= 0.9 * on["stats"]["walk_records"], (info, cheap["stats"])
     print(f"{kind} seed {seed}: {model.num_cells} cells nφ={n_azim} {ref['total']} segments | regime: walk on, "
           f"{info['records_walk']}/{info['records']} records walkable, eps ≤ {info['eps_max']:.1e}, fragile {info['cells_fragile']}, "
-          f"{frac:.1%} of the records by the walk step | {int(np.count_nonzero(ref['status']))} tracks on which the reference throws")
+          f"{frac:.1%} of the records by the walk step, {cheap['stats']['cheap_records'] / max(ref['total'], 1):.1%} by cheap steps "
+          f"({info['records_cheap']} records) | {int(np.count_nonzero(ref['status']))} tracks on which the reference throws")

@@ -1,6 +1,6 @@
 """The walk step's certificates without a GPU: the device march's per-lane logic and the mesh preprocessing,
 compiled for the host (tests/host_march.hip — test infrastructure built from the product's own headers), against
-the CPU checker.  Walk step on == walk step off == checker, bit for bit, on every mesh class, and the
+the CPU checker.  Walk step on == walk step off == cheap steps == checker, bit for bit, on every mesh class, and the
 preprocessing's per-record switches behave as documented.  The kernels themselves are tested on the GPU
 (tests/test_gpu_*.py); tools/fuzz_cpu.py runs the same comparison over hundreds of seeds."""
 import os
@@ -35,9 +35,12 @@ def _both_modes(rt, orc, model, n_azim, delta, k=5):
     ref = _oracle(orc, tg, k=k)
     on = hm.run(tg, k=k, walk=True)
     off = hm.run(tg, k=k, walk=False)
+    cheap = hm.run(tg, k=k, walk="topo")  # cheap steps (decision from signed distances) + exact steps where they refuse
     _same(on, ref, "walk on")
     _same(off, ref, "walk off")
-    assert off["stats"]["walk_emits"] == 0
+    _same(cheap, ref, "cheap steps")
+    assert off["stats"]["walk_emits"] == 0 and off["stats"]["cheap_emits"] == 0 and on["stats"]["cheap_emits"] == 0
+    on["cheap_stats"] = cheap["stats"]
     return tg, ref, on
 
 
@@ -48,7 +51,9 @@ def test_pincell_walk_on_off_checker(rt, orc, pincell, n_azim, delta):
     assert info["walk_ok"] == 1 and info["records_walk"] == info["records"] - 160  # all but the 160 boundary-entry records
     assert info["cells_fragile"] == 0 and info["cells_degenerate"] == 0
     assert s["walk_emits"] >= 0.97 * ref["total"] - tg.n_total_tracks  # every track's first step is literal
-    print(f"pincell nφ={n_azim}: {ref['total']} segments, {s}")
+    cs = on["cheap_stats"]
+    assert cs["cheap_emits"] >= 0.999 * s["walk_emits"] and cs["cheap_restarts"] == 0  # nearly every walk step is a cheap one here
+    print(f"pincell nφ={n_azim}: {ref['total']} segments, {s}; cheap steps: {cs}")
 
 
 CASES = [("lattice", s) for s in range(4)] + [("lattice_far", s) for s in range(2)] + [("sliver", s) for s in range(4)] + \
@@ -191,3 +196,25 @@ def test_reseeding_distance_and_cell_node_order(rt, orc, tiny, shuffle):
     _same(on, ref, "walk on")
     _same(hm.run(tg, walk=False), ref, "walk off")
     assert on["stats"]["walk_emits"] > 0.5 * ref["total"]
+
+
+@pytest.mark.parametrize("iter_cap", [40, 300, 100000])
+def test_cheap_steps_iteration_bound(rt, orc, pincell, iter_cap):
+    """After cheap steps the iteration counter is an upper bound of the reference's (the tiny steps it takes while it still
+    locates the cell it just left are bounded, not replayed).  A track whose bound reaches the cap is marched again with
+    exact steps only: the status at the cap — and everything else — equals the checker's at any cap."""
+    tg = rt.TrackGenerator(pincell, 8, 2e-2)
+    rt.trace(tg)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                        tiny_step=tg.tiny_step, iter_cap=iter_cap, n_threads=0, k=5)
+    r = hm.run(tg, k=5, walk="topo", iter_cap=iter_cap)
+    _same(r, ref, "cheap steps, iter_cap=%d" % iter_cap)
+    s = r["stats"]
+    if iter_cap == 40:
+        assert np.count_nonzero(ref["status"] == 4) > 0 and s["cheap_restarts"] > 0  # tracks that do hit the cap
+    if iter_cap == 300:
+        assert np.count_nonzero(ref["status"]) == 0 and s["cheap_restarts"] > 0      # only the bound reached it
+    if iter_cap == 100000:
+        assert s["cheap_restarts"] == 0
+    print(f"iter_cap={iter_cap}: restarts {s['cheap_restarts']}, cheap emits {s['cheap_emits']}, failing {np.count_nonzero(ref['status'])}")

@@ -1,6 +1,7 @@
 """Many seeded meshes / quadratures / k through the HIP path (C ABI) against the checker, bit for bit, with the regime
 of every run printed (rt_mesh_info / rt_last_stats).  Same cases as tools/fuzz_cpu.py (every mesh class of
-tests/meshgen.py, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on, off, and the library's default splitting.
+tests/meshgen.py, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on with exact steps only, off, on with cheap steps, and the
+library's defaults (pieces for small batches).
 usage (GPU box): python tools/fuzz_many.py [first_seed] [count]"""
 import os
 import sys
@@ -23,7 +24,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 FIELDS = ("px", "py", "qx", "qy", "ell")
 bad = 0
 t0 = time.time()
-seg_total = walk_total = 0
+seg_total = walk_total = cheap_total = 0
 for seed in range(first, first + count):
     kind, model, n_azim, delta, k = fuzz_cpu.case(seed)
     if n_azim >= 1024:  # keep a GPU run short: the CPU fuzzer covers the finest quadratures
@@ -36,7 +37,8 @@ for seed in range(first, first + count):
     aq = tg.azimuthal_quadrature
     vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
     regime = ""
-    for opts in (dict(walk=1, split=0), dict(walk=0, split=0), dict(walk=1)):
+    cheap_n = 0
+    for opts in (dict(walk=1, split=0, topo=0), dict(walk=0, split=0), dict(walk=1, split=0, topo=1), dict(walk=1)):
         dm = _capi.DeviceMesh(tg.mesh, 0)
         for kk, v in opts.items():
             dm.set_option(kk, v)
@@ -50,7 +52,10 @@ for seed in range(first, first + count):
         if not ok:
             bad += 1
             print("MISMATCH seed", seed, kind, opts, n_azim, delta, k, flush=True)
-        if opts == dict(walk=1, split=0):
+        if opts == dict(walk=1, split=0, topo=1):
+            cheap_n = dt.stats()["cheap_records"]
+            cheap_total += cheap_n
+        if opts == dict(walk=1, split=0, topo=0):
             info, stats = dm.info(), dt.stats()
             regime = "walk %s, %d/%d records walkable, eps<=%.1e, %d of %d records by the walk step" % (
                 "on" if info["walk_enabled"] else "off", info["records_walk"], info["records"], info["eps_max"], stats["walk_records"], total)
@@ -58,9 +63,9 @@ for seed in range(first, first + count):
             walk_total += stats["walk_records"]
         dt.close()
         dm.close()
-    print("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | %s  [%.0f s]" %
+    print("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | %s, %d by cheap steps  [%.0f s]" %
           (seed, kind, model.num_cells, n_azim, k, tg.n_total_tracks, int(ref["total"]), int(np.count_nonzero(ref["status"])), regime,
-           time.time() - t0), flush=True)
-print("done: %d meshes x 3 modes, %d mismatches, %d segments, %.1f %% of them by the walk step" %
-      (count, bad, seg_total, 100.0 * walk_total / max(seg_total, 1)))
+           cheap_n, time.time() - t0), flush=True)
+print("done: %d meshes x 4 modes, %d mismatches, %d segments, %.1f %% of them by the walk step, %.1f %% by cheap steps" %
+      (count, bad, seg_total, 100.0 * walk_total / max(seg_total, 1), 100.0 * cheap_total / max(seg_total, 1)))
 sys.exit(1 if bad else 0)
