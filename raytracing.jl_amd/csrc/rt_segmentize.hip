@@ -409,6 +409,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     // has no cheap lane left (an uncertified last step, a finished track); kFlDone / kFlRestart: see below
     constexpr uint32_t kFlCheap = 1, kFlUsed = 2, kFlMat = 4, kFlWait = 8, kFlDone = 16, kFlRestart = 32;
     uint32_t fl = 0;
+    int32_t n_cheap_it = 0, n_cheap_ref = 0;  // wave-uniform: cheap iterations of this wave, and those in which a lane was refused
     int32_t last_word = 0;  // staging word of the lane's last record
     // (the cheap loop stores without a branch: should the pool run out before a lane's first chunk — the attempt is void
     //  then and the host re-runs it — its row pointers must still be addresses inside the pool)
@@ -521,6 +522,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     int32_t kub;
                     const bool ok = topo_certified(tt, ts, g, c_hdr, c_c01, c_c23, kk, kub);
                     const bool over = it + kub > cap;  // (`it` is an upper bound of the reference's iterations after cheap steps)
+                    ++n_cheap_it;
+                    n_cheap_ref += __ballot(cheap && !ok) != 0 ? 1 : 0;
                     pend = cheap && ok && !over;
                     if (pend) {
                         ++i;
@@ -537,6 +540,13 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     pe_A = eA; pe_B = eB; pe_C = eC; p_cell = g.cell;
                 }
                 if (pend) arithmetic();
+            }
+            // A wave whose lanes are refused in more than one iteration out of eight (a mesh with many records that carry the
+            // walk step's certificates but not the cheap step's: every refusal is an exact pass the other lanes wait for)
+            // goes on with exact steps only, i.e. as the march without cheap steps.
+            if (__builtin_expect(tt.on && n_cheap_ref >= 16 && 8 * n_cheap_ref > n_cheap_it, 0)) {
+                tt.on = false;
+                if (fl & kFlCheap) fl = (fl & ~kFlCheap) | kFlMat;
             }
             const bool any_cheap = __ballot((fl & kFlCheap) != 0) != 0;
             if ((fl & kFlDone) || i >= kMaxIter) break;
@@ -1757,7 +1767,8 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     const bool split = plan_ok && (!t->hybrid || hybrid);  // pieces are marched in this call
     // Cheap steps (k_march<..., TOPO>): whole-track batches on meshes with cheap-step records, the usual k, fill_volumes fused.
     const bool topo = m->single_pass && m->topo && m->topo_available && m->d.walk_ok && !split && !hybrid && !widek_ && n > 0 &&
-                      fuse_ && tiny_step > 0 && tiny_step <= m->topo_tiny_max && m->lds_records == 0;
+                      fuse_ && tiny_step > 0 && tiny_step <= m->topo_tiny_max && m->lds_records == 0 &&
+                      10 * m->n_records_topo >= 9 * m->n_records_walk;
     t->last_topo = topo ? 1 : 0;
     if (split) {
         sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);

@@ -13,7 +13,14 @@ mesh = sys.argv[1] if len(sys.argv) > 1 else "pincell.msh"
 na = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 d = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3
 extra = [a.split("=") for a in sys.argv[4:]]
-model = rt.GmshDiscreteModel(rt.data_path(mesh)) if mesh.endswith(".msh") else rt.DiscreteModelFromFile(rt.data_path(mesh))
+if mesh.startswith("fuzz:"):  # fuzz:<seed> — the mesh of tools/fuzz_cpu.py's case <seed>
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_cpu
+    kind, model, _, _, _ = fuzz_cpu.case(int(mesh[5:]))
+    print("mesh", kind, model.num_cells, "cells")
+else:
+    model = rt.GmshDiscreteModel(rt.data_path(mesh)) if mesh.endswith(".msh") else rt.DiscreteModelFromFile(rt.data_path(mesh))
 tg = rt.TrackGenerator(model, na, d)
 rt.trace(tg)
 aq = tg.azimuthal_quadrature
@@ -35,7 +42,9 @@ for topo in (0, 1):
     seg = dt.fetch_segments()
     vol = dt.fetch_volumes()
     res[topo] = (off, st, seg, vol)
-    print("topo", topo, "segs", total, acc, "stats", dt.stats(), "failed", int(np.count_nonzero(st)), flush=True)
+    info = dm.info()
+    print("topo", topo, "segs", total, acc, "stats", dt.stats(), "failed", int(np.count_nonzero(st)),
+          "records walk/cheap %d/%d" % (info["records_walk"], info["records_cheap"]), flush=True)
 a, b = res[0], res[1]
 ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 for k in ("px", "py", "qx", "qy", "ell", "element"):
