@@ -83,7 +83,9 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
     assert off["info"]["walk_enabled"] == 0 and off["stats"]["walk_records"] == 0
     assert on["stats"]["cheap_records"] == 0 and off["stats"]["cheap_records"] == 0
     assert cheap["stats"]["cheap_records"] <= cheap["stats"]["walk_records"] == on["stats"]["walk_records"]
-    if info["records_cheap"] > 0 and tg.tiny_step <= info["cheap_tiny_max"]:
+    # (cheap steps are used when at least 90 % of the walkable records carry their certificates; a wave that is refused
+    #  in more than one iteration out of eight goes on with exact steps)
+    if 10 * info["records_cheap"] >= 9 * info["records_walk"] > 0 and tg.tiny_step <= info["cheap_tiny_max"]:
         assert cheap["stats"]["cheap_records"] > 0, (info, cheap["stats"])
     else:
         assert cheap["stats"]["cheap_records"] == 0
@@ -97,7 +99,6 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
         assert on["stats"]["walk_records"] > 0
     if kind == "lattice":
         assert info["records_walk"] >= 0.85 * info["records"] and frac > 0.7, (info, on["stats"])
-        assert cheap["stats"]["cheap_records"] >= 0.9 * on["stats"]["walk_records"], (info, cheap["stats"])
     print(f"{kind} seed {seed}: {model.num_cells} cells nφ={n_azim} {ref['total']} segments | regime: walk on, "
           f"{info['records_walk']}/{info['records']} records walkable, eps ≤ {info['eps_max']:.1e}, fragile {info['cells_fragile']}, "
           f"{frac:.1%} of the records by the walk step, {cheap['stats']['cheap_records'] / max(ref['total'], 1):.1%} by cheap steps "
