@@ -35,7 +35,7 @@ int64_t orc_fetch(void *mv, double *px, double *py, double *qx, double *qy, doub
 }
 
 int main(int argc, char **argv) {
-    long long segs = 0, walk = 0;
+    long long segs = 0, walk = 0, cheap = 0;
     int bad = 0, n_mesh = 0;
     for (int a = 1; a < argc; ++a) {
         rt_msh *M = rt_msh_load(argv[a]);
@@ -63,15 +63,16 @@ int main(int argc, char **argv) {
             if (rt_trace(bb, n_azim, ntx.data(), nty.data(), bcs, ph.data(), ds.data(), om.data(), az.data(), ti.data(), D[0].data(), D[1].data(),
                          D[2].data(), D[3].data(), D[4].data(), D[5].data(), D[6].data(), D[7].data(), D[8].data(), D[9].data(), D[10].data(),
                          B8[0].data(), B8[1].data(), B8[2].data(), B8[3].data(), nf.data(), nb.data())) continue;
-            std::vector<Rec> recs[2];
-            std::vector<int64_t> offs[2];
-            std::vector<int32_t> st[2];
-            for (int w = 0; w < 2; ++w) {
+            std::vector<Rec> recs[3];
+            std::vector<int64_t> offs[3];
+            std::vector<int32_t> st[3];
+            for (int w = 0; w < 3; ++w) {  // exact walk steps, walk off, cheap steps
                 hostmarch_run(x.data(), y.data(), nn, cells.data(), nc, ptrs.data(), data.data(), bb, n, D[0].data(), D[1].data(), D[4].data(),
                               D[5].data(), D[6].data(), D[8].data(), D[9].data(), D[10].data(), D[7].data(), 1e-8, k, 1.4901161193847656e-8,
-                              200000, w == 0, 2, nullptr);
+                              200000, w == 0 ? 1 : (w == 1 ? 0 : 2), 2, nullptr);
                 recs[w] = g_res.recs; offs[w] = g_res.offsets; st[w] = g_res.status;
                 if (w == 0) walk += g_res.stats[0];
+                if (w == 2) cheap += g_res.stats[5];
             }
             void *orc = orc_mesh_create(x.data(), y.data(), nn, cells.data(), nc, ptrs.data(), data.data(), bb);
             std::vector<int64_t> ooff(n + 1);
@@ -83,18 +84,19 @@ int main(int argc, char **argv) {
             std::vector<int32_t> oel(tot > 0 ? tot : 1);
             orc_fetch(orc, o[0].data(), o[1].data(), o[2].data(), o[3].data(), o[4].data(), oel.data());
             orc_mesh_destroy(orc);
-            bool ok = (int64_t)recs[0].size() == tot && recs[1].size() == recs[0].size() && offs[0] == offs[1] && st[0] == st[1] && offs[0] == ooff &&
-                      st[0] == ost;
+            bool ok = (int64_t)recs[0].size() == tot && recs[1].size() == recs[0].size() && recs[2].size() == recs[0].size() && offs[0] == offs[1] &&
+                      offs[0] == offs[2] && st[0] == st[1] && st[0] == st[2] && offs[0] == ooff && st[0] == ost;
             for (int64_t i = 0; ok && i < tot; ++i) {
-                const Rec &r0 = recs[0][i], &r1 = recs[1][i];
-                ok = r0.px == r1.px && r0.py == r1.py && r0.qx == r1.qx && r0.qy == r1.qy && r0.ell == r1.ell && r0.element == r1.element &&
+                const Rec &r0 = recs[0][i], &r1 = recs[1][i], &r2 = recs[2][i];
+                ok = r0.px == r2.px && r0.py == r2.py && r0.qx == r2.qx && r0.qy == r2.qy && r0.ell == r2.ell && r0.element == r2.element &&
+                     r0.px == r1.px && r0.py == r1.py && r0.qx == r1.qx && r0.qy == r1.qy && r0.ell == r1.ell && r0.element == r1.element &&
                      r0.px == o[0][i] && r0.py == o[1][i] && r0.qx == o[2][i] && r0.qy == o[3][i] && r0.ell == o[4][i] && r0.element == oel[i];
             }
             if (!ok) { ++bad; printf("MISMATCH %s nφ=%d k=%d\n", argv[a], n_azim, k); }
             segs += tot;
         }
     }
-    printf("march_san: %d meshes, %lld segments (%lld by the walk step), walk on == walk off == checker: %s\n", n_mesh, segs, walk,
-           bad ? "MISMATCH" : "yes");
+    printf("march_san: %d meshes, %lld segments (%lld by the walk step, %lld by cheap steps), exact walk steps == walk off == cheap steps == checker: %s\n",
+           n_mesh, segs, walk, cheap, bad ? "MISMATCH" : "yes");
     return bad ? 1 : 0;
 }
