@@ -78,7 +78,7 @@ def run(seed):
         res[walk] = r
     s, info = res[True]["stats"], res[True]["info"]
     line = ("seed %d %-11s tiny %.0e cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | records walkable %5d/%5d eps≤%.1e fragile %d degenerate %d | "
-            "walk emits %8d skips %6d generic emits %7d refused %6d | two-phase: cheap emits %8d refused %5d restarts %d%s" %
+            "walk emits %8d skips %6d generic emits %7d refused %6d | cheap steps: emits %8d refused %5d restarts %d%s" %
             (seed, kind, tg.tiny_step, model.num_cells, n_azim, k, tg.n_total_tracks, ref["total"], int(np.count_nonzero(ref["status"])),
              int(info["records_walk"]), int(info["records"]), info["eps_max"], int(info["cells_fragile"]), int(info["cells_degenerate"]),
              s["walk_emits"], s["walk_skips"], s["generic_emits"], s["refused"], res["topo"]["stats"]["cheap_emits"],
@@ -104,6 +104,6 @@ if __name__ == "__main__":
         for seed, bad, line, we, tot, ce in pool.imap_unordered(run, range(first, first + count)):
             print(line, flush=True)
             n_bad += bad; walk_total += we; seg_total += tot; cheap_total += ce
-    print("done: %d meshes, %d mismatches, %d segments, %.1f %% of them by the walk step (%.1f %% by cheap steps in the two-phase march), %.0f s" %
+    print("done: %d meshes, %d mismatches, %d segments, %.1f %% of them by the walk step (%.1f %% by cheap steps), %.0f s" %
           (count, n_bad, seg_total, 100.0 * walk_total / max(seg_total, 1), 100.0 * cheap_total / max(seg_total, 1), time.time() - t0))
     sys.exit(1 if n_bad else 0)
