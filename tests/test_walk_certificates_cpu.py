@@ -175,7 +175,7 @@ def test_host_code_under_sanitizers(tmp_path):
     subprocess.check_call(["bash", os.path.join(root, "tests", "sanitize", "run.sh"), "15", str(log)], stdout=subprocess.DEVNULL)
     text = log.read_text()
     assert text.count("exit code: 0") == 2 and "ERROR" not in text and "runtime error" not in text, text[-2000:]
-    assert "12 refused" in text and "walk on == walk off == checker: yes" in text
+    assert "12 refused" in text and "exact walk steps == walk off == cheap steps == checker: yes" in text
 
 
 @pytest.mark.parametrize("tiny,shuffle", [(1e-8, True), (1e-5, False), (1e-6, True), (1e-10, False)])
