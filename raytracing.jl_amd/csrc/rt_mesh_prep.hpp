@@ -534,7 +534,10 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         const double corner = std::hypot(cmax_x, cmax_y);
         const double kappa0 = 20.0 * kUlp * corner;
         const double dadd = 3.0 * kTopoKcap * kUlp * corner;
-        P.topo_tiny_max = 1e-6 * l_max;
+        // the certificates hold for tiny_step up to this bound (it enters the margins below): relative to the mesh, but
+        // never below 4e-8 — the reference's default tiny_step is 1e-8, and a fine mesh must not lose the cheap step to it
+        // (cells too small for the resulting margins simply get no cheap record)
+        P.topo_tiny_max = std::max(1e-6 * l_max, 4e-8);
         const bool ids_fit = (uint64_t)3 * (uint64_t)n_cells + 3 < (1ull << kWalkIdBits);
         double rmax = 0.0, end_err = 0.0;
         for (int32_t c = 0; c < n_cells; ++c) {
