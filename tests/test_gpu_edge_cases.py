@@ -182,9 +182,23 @@ def test_enqueue_hook_runs_once_per_call_beside_the_kernels(rt, traced, oracle_r
 
 def test_handles_release_their_device_memory(rt, traced):
     """Create / segmentize / destroy in a loop: free device memory must come back (no leak in the handles)."""
-    import torch
+    import ctypes as C
+    import importlib.util
+    import os
 
     from raytracing_jl_amd import _capi
+
+    # hipMemGetInfo of the HIP runtime the library runs on (torch's bundled copy when torch is installed, see
+    # _capi._share_hip_runtime_with_torch) — without importing torch, which can take minutes on a cold box
+    _capi.lib()
+    spec = importlib.util.find_spec("torch")
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else ""
+    hip = C.CDLL(cand if os.path.exists(cand) else "libamdhip64.so")
+
+    def free_bytes():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
 
     tg = traced(32, 5e-3)
     aq = tg.azimuthal_quadrature
@@ -197,12 +211,10 @@ def test_handles_release_their_device_memory(rt, traced):
         dm.close()
 
     cycle()
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    free0 = free_bytes()
     for _ in range(20):
         cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    free1 = free_bytes()
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)  # allocator granularity, not 20 pools (≈ 20 x 100 MB)
 
 
