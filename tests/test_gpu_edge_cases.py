@@ -63,6 +63,30 @@ def test_tiny_step(rt, orc, pincell, tiny):
     _same(tg, _oracle(orc, tg))
 
 
+@pytest.mark.parametrize("tiny", [1e-6, 5e-8, 1e-8, 1e-10])
+def test_tiny_step_with_and_without_cheap_steps(rt, orc, pincell, tiny):
+    """The cheap step's certificates hold up to RT_MESH_INFO_TINY_MAX (pincell: 5.5e-8); a larger tiny_step marches with
+    exact walk steps, a smaller one bounds more tiny steps per record.  Whole tracks (split = 0), against the checker."""
+    from raytracing_jl_amd import _capi
+
+    tg = rt.TrackGenerator(pincell, 16, 0.01, tiny_step=tiny)
+    rt.trace(tg)
+    ref = _oracle(orc, tg)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("split", 0)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+    off, st = dt.fetch_offsets()
+    s = dt.fetch_segments()
+    assert np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and np.array_equal(s["element"], ref["element"])
+    for k in FIELDS:
+        assert np.array_equal(s[k], ref[k]), k
+    info, stats = dm.info(), dt.stats()
+    assert (stats["cheap_records"] > 0) == (tiny <= info["cheap_tiny_max"]), (info["cheap_tiny_max"], stats)
+    print(f"tiny_step={tiny:g}: tiny_max {info['cheap_tiny_max']:.2e}, {stats['cheap_records']} of {stats['records']} records by cheap steps")
+
+
 def test_rtol_controls_length_check(rt, orc, pincell):
     tg = rt.TrackGenerator(pincell, 8, 0.05)
     rt.trace(tg)
