@@ -65,7 +65,7 @@ def test_tiny_step(rt, orc, pincell, tiny):
 
 @pytest.mark.parametrize("tiny", [1e-6, 5e-8, 1e-8, 1e-10])
 def test_tiny_step_with_and_without_cheap_steps(rt, orc, pincell, tiny):
-    """The cheap step's certificates hold up to RT_MESH_INFO_TINY_MAX (pincell: 5.5e-8); a larger tiny_step marches with
+    """The cheap step's certificates hold up to RT_MESH_INFO_TINY_MAX (pincell: 5.1e-8); a larger tiny_step marches with
     exact walk steps, a smaller one bounds more tiny steps per record.  Whole tracks (split = 0), against the checker."""
     from raytracing_jl_amd import _capi
 
