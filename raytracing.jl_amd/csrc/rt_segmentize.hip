@@ -109,6 +109,7 @@ struct DStage {
     RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
+    int32_t static0;        // 1: chunk w is reserved as the first chunk of march wave w (whole-track march; cursor starts at n_waves)
 #ifdef RT_TIMING
     unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
 #endif
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     int32_t it = 0;
     const int32_t cap = (int32_t)(prm.iter_cap < 0x7fffffff ? prm.iter_cap : 0x7fffffff);
     int32_t prev_element = -1;
+    int32_t n_generic = 0;  // records of this lane made by the generic step (whole-track kernels)
     int st = RT_TRACK_OK;
     double sum_ell = 0.0;
     Walk wk;
@@ -443,7 +445,10 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 if (lane == L) {
                     const RT_K DStage *sk = march_stage_args();
                     RT_G int32_t *cursor = sk->cursor;
-                    c = atomicAdd((int32_t *)&cursor[0], 1);
+                    // a wave's first chunk is chunk `wave_id` when the host reserved one per wave (the cursor then starts
+                    // behind them): every wave allocates at the same moment, on its first record — 2,039 atomics on one word
+                    if (!SPLIT && jL == 0 && sk->static0) c = (int32_t)wave_id;
+                    else c = atomicAdd((int32_t *)&cursor[0], 1);
                     if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
                     else {
                         sk->ctab[wave_id * kMaxChunks + jL] = c;
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             if (__builtin_expect((fl & kFlRestart) || ((fl & kFlUsed) && it >= cap), 0)) {
                 // the bound reached the iteration cap: this track is marched again from its start with exact steps only
                 asm volatile("" ::: "memory");
-                tt.on = false; fl = 0;
+                tt.on = false; fl = 0; n_generic = 0;
                 i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
                 xpx = t.px[u] + sx; xpy = t.py[u] + sy;
                 continue;
@@ -674,7 +679,9 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             }
             creep_run = 0;
             ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
-            if (MODE != kFill) {
+            if (MODE != kFill && !SPLIT) ++n_generic;  // (added to the call's statistic when the wave ends: 2,039 waves doing
+                                                       //  this atomic at the same moment, on their first step, cost the march 5 µs)
+            if (MODE != kFill && SPLIT) {
                 // per-call statistic (rt_last_stats): records the generic step produced — the walk step made the rest
                 // (the control block's address is read from the argument segment here, not held across the loop)
                 const unsigned long long act = __ballot(1);
@@ -799,6 +806,13 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
         counts[u] = i;
         status[u] = st;
+        {
+            // per-call statistic (rt_last_stats): records the generic step produced, summed over the wave's active lanes
+            // bit by bit with ballots (n_generic <= kMaxIter < 2^14)
+            unsigned long long ng = 0;
+            for (int b = 0; b < 14; ++b) ng += (unsigned long long)__popcll(__ballot((n_generic >> b) & 1)) << b;
+            if (lane == __ffsll((long long)__ballot(1)) - 1 && ng) atomicAdd(&fail_info[15], ng);
+        }
         if (st != RT_TRACK_OK) {
             atomicAdd(&fail_info[0], 1ull);
             atomicMin(&fail_info[1], (unsigned long long)(u + 1));
@@ -948,9 +962,10 @@ constexpr int kScanTile = kScanBlock * kScanPer;
 
 // Start of a call: the control block (failure summary, total, pool cursor, scan ticket) and `volumes` are reset
 // by one small kernel instead of a host-to-device copy and a memset.
-__global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells) {
+__global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells, int32_t first_chunk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 32) ctl[i] = i == 1 ? ~0ull : 0ull;  // [1]: first failing uid, an atomicMin target
+    // [1]: first failing uid, an atomicMin target; [18]: pool cursor (low word; chunks below first_chunk are reserved) + overflow flag
+    if (i < 32) ctl[i] = i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk : 0ull);
     if (i < n_cells) volumes[i] = 0.0;
 }
 
@@ -1896,6 +1911,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
+            stg.static0 = (!split && n_whole_waves < stg.pool_chunks) ? 1 : 0;
 #ifdef RT_TIMING
             RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
             RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
@@ -1911,7 +1927,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             // events that were only ever recorded inside a graph — DESIGN.md §4.)
             auto enqueue_attempt = [&]() -> int {
                 hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, 32) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
-                                   t->volumes.p, m->n_cells);
+                                   t->volumes.p, m->n_cells, stg.static0 ? (int32_t)n_whole_waves : 0);
                 RT_HIP(hipEventRecord(t->ev[1], s));
                 if (n > 0 && split) {
                     hipStream_t ps = s;  // the stream the pieces march on
