@@ -58,7 +58,7 @@ struct __attribute__((aligned(16))) FanEntry {
 static_assert(sizeof(FanEntry) == 64, "FanEntry layout");
 struct Tri { double x1, y1, x2, y2, x3, y3; int32_t adj[3]; };  // a cell's vertices in its node order + its three successors
 
-// Cheap-step record of the two-phase march for (cell, entry edge): 32 B, two 16-B loads (rt_mesh_prep.hpp, TopoRecHost).
+// Cheap-step record for (cell, entry edge): 32 B, two 16-B loads (rt_mesh_prep.hpp, TopoRecHost).
 constexpr uint32_t kTopoEndV = (1u << kWalkIdBits) - 1;  // successor field: the exit edge lies on a vertical border
 constexpr uint32_t kTopoEndH = (1u << kWalkIdBits) - 2;  // ... on a horizontal border
 constexpr int kTopoKcap = 4096;
@@ -97,7 +97,7 @@ struct DMesh {
     int32_t n_cells;
     double bx0, by0, bx1, by1;   // bounding box (bb_min, bb_max)
     const RT_K DGeo *geo;        // device copy of the generic step's data
-    const RT_G struct TopoRec *trec;  // [3*n_cells] cheap-step records of the two-phase march (topo_step)
+    const RT_G struct TopoRec *trec;  // [3*n_cells] cheap-step records (topo_step)
     const RT_G struct EdgeABC *etab;  // [3*n_cells] general_form of edge k of cell c at 3*c + k
 };
 
@@ -126,7 +126,7 @@ struct DParams {
     int32_t k;
     int32_t n_azim_2;
     int64_t iter_cap;
-    double topo_tiny_max, topo_rmax, topo_end_err;  // two-phase march (topo_track); unused elsewhere
+    double topo_tiny_max, topo_rmax, topo_end_err;  // cheap steps (topo_track); unused elsewhere
 };
 
 // ---------------------------------------------------------------- Base.isapprox ----------
@@ -738,10 +738,10 @@ RT_HD __forceinline__ bool walk_still_skip(const DMesh &m, const Walk &w, const 
     return !tie && t_first;
 }
 
-// ------------------------------------------------------------ two-phase march: cheap step -
-// The two-phase march (k_march<..., TOPO> + k_emit) splits a walk step into the DECISION — which cell the
+// ------------------------------------------------------------------------- cheap step -
+// The cheap step (k_march<..., TOPO>) splits a walk step into the DECISION — which cell the
 // reference emits next, entered and left through which edges — and the ARITHMETIC of the record (exit point,
-// length), which k_emit evaluates later for all records in parallel with the reference's formulas.  The decision
+// length), which the march evaluates one record behind, off the dependent chain, with the reference's formulas.  The decision
 // needs no point at all: with s_i the signed distances of the predicted cell's vertices from the track line,
 //   * the line leaves T' through the edge whose end points lie on opposite sides (|s_i| >= d_vertex: certificate 1
 //     of walk_step, unchanged);

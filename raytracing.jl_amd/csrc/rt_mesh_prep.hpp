@@ -65,7 +65,7 @@ struct WalkRecHost {
 };
 static_assert(sizeof(WalkRecHost) == 80, "WalkRec layout");
 
-// Topological walk record for (cell T', entry edge e) — the "cheap step" of the two-phase march (rt_device.hpp,
+// Topological walk record for (cell T', entry edge e) — the "cheap step" of the march (rt_device.hpp,
 // `topo_step`): what a lane needs to decide, from the signed distances of the cell's vertices to the track line alone,
 // that the reference emits its next segment in T' with entry on the shared edge and exit on one other edge — without
 // computing any point.  32 B = two 16-B loads.  Must match rt::TopoRec.
@@ -107,7 +107,7 @@ inline double bf16_value(uint16_t h) {
 struct Prep {
     std::vector<WalkRecHost> wrec;  // [3*n_cells]
     std::vector<int32_t> adjr;      // [3*n_cells] record index reached across edge k of cell c, -1 on the boundary
-    std::vector<TopoRecHost> trec;  // [3*n_cells] cheap-step records of the two-phase march
+    std::vector<TopoRecHost> trec;  // [3*n_cells] cheap-step records
     std::vector<EdgeABCHost> etab;  // [3*n_cells] general forms of the cells' edges
     bool topo_ok = false;           // some record can take the cheap step
     double topo_tiny_max = 0.0;     // the cheap step's certificates hold for tiny_step <= this
@@ -508,7 +508,7 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
     }
     if (P.n_records_walk == 0) { P.eps_min = 0.0; if (P.walk_ok) { P.walk_ok = false; if (P.note.empty()) P.note = "no cell passes the walk certificates"; } }
 
-    // ---- cheap-step ("topological") records of the two-phase march.  rt_device.hpp `topo_step` states what the
+    // ---- cheap-step ("topological") records.  rt_device.hpp `topo_step` states what the
     //      lane checks; here are the constants, each a sufficient bound with room to spare:
     //  With s_i the signed (scaled, |s| <= distance) distances of v0, v1, v2 from the track line, D = |s0| + |s1|,
     //  m = min(|s0|, |s1|): the entry point has barycentric coordinates (1-u, u, 0), u = |s0| / D, in T'.

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     // that their 17 pointers do not occupy scalar registers across the loop.
     const RT_K DSplit *spk = (const RT_K DSplit *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, sp));
     (void)sp;
-    static_assert(!TOPO || (MODE == kStage && !SPLIT && !LDSREC), "two-phase march: staged whole tracks only");
+    static_assert(!TOPO || (MODE == kStage && !SPLIT && !LDSREC), "cheap steps: staged whole tracks only");
     constexpr bool FUSE = WAVES > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     asm volatile("" : "+v"(mh.d_vertex), "+v"(mh.l_min), "+v"(mh.wrec));
     NextRec nr;
     load_next(mh, -1, nr);
-    // two-phase march: per-lane state of the cheap step
+    // per-lane state of the cheap step
     TopoTrack tt = topo_track(TOPO && m.walk_ok, m.d_vertex, prm.topo_tiny_max, prm.topo_rmax, prm.topo_end_err, prm.tiny_step, t.cs[u], t.sn[u]);
     TopoState ts;
     ts.pred = -1; ts.last = 0; ts.sa = ts.sb = 0.0;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         }
         px = lqx; py = lqy; element = wk.T;  // valid when res == kWalkEmit
         if (TOPO && res == kWalkEmit) {
-            // per-call statistic: records of exact walk steps in a two-phase call (the cheap steps made the rest)
+            // per-call statistic: records of exact walk steps in a call with cheap steps (which made the rest)
             const unsigned long long act = __ballot(1);
             if (lane == __ffsll((long long)act) - 1)
                 atomicAdd(*(unsigned long long *const RT_K *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() +
@@ -1162,7 +1162,7 @@ struct rt_mesh {
     DevBuf<rt::FanEntry> fan;
     DevBuf<rt::WalkRec> wrec;
     DevBuf<int32_t> adjr;
-    DevBuf<rt::TopoRec> trec;   // two-phase march: cheap-step records and the cells' edge general forms
+    DevBuf<rt::TopoRec> trec;   // cheap-step records and the cells' edge general forms
     DevBuf<rt::EdgeABC> etab;
     DevBuf<rt::DGeo> geo;
     rt::DMesh d{};
@@ -1235,7 +1235,7 @@ struct rt_tracks {
     int32_t azim_min = 1, azim_max = 0;  // range of azim_idx (checked against n_azim_2 by rt_segmentize)
     int64_t n_generic_records = 0;       // rt_last_stats
     bool force_unsplit = false;  // a track reached MAX_ITER segments in split mode: this track set marches whole from now on
-    int32_t last_topo = 0;  // 1: the last call ran the two-phase march
+    int32_t last_topo = 0;  // 1: the last call marched with cheap steps
     int64_t n_exact_walk_records = 0;  // ... and this many of its records came from exact walk steps
     int32_t last_march_waves = 0, last_split = 0, last_widek = 0;  // which instantiation of the march the last call launched
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds

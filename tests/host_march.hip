@@ -66,8 +66,8 @@ int64_t g_reasons[8];
 
 // counters: [0] walk emits, [1] walk skips (incl. creep passes), [2] generic emits, [3] generic iterations in total,
 // [4] generic iterations taken although a prediction existed (a certificate refused)
-// `tt0.on`: two-phase march — cheap steps (topo_step) wherever their certificates hold, the record's arithmetic as
-// k_emit evaluates it (edge_exit_point with the cell's edge table, p = previous q, ℓ = ‖p − q‖); cnt[5] cheap emits,
+// `tt0.on`: cheap steps (topo_step) wherever their certificates hold, the record's arithmetic as the march evaluates it
+// (edge_exit_point with the cell's edge table, p = previous q, ℓ = ‖p − q‖); cnt[5] cheap emits,
 // cnt[6] cheap refusals (mid-track), cnt[7] restarts with exact steps only (iteration bound reached the cap).
 void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, double phi, double cs, double sn, double tA,
                  double tB, double tC, double track_ell, double tiny, int k, double rtol, int64_t iter_cap,

@@ -1,4 +1,4 @@
-"""Development check of the two-phase march (option "topo"): every output of a call with topo=1 against topo=0 — offsets, status
+"""Development check of the cheap steps (option "topo"): every output of a call with topo=1 against topo=0 — offsets, status
 and the six record arrays bit for bit, volumes to 1e-12 — plus device timings of both.
 usage (GPU box): python tools/topo_check.py [mesh nφ δ [name=value ...]]"""
 import os
