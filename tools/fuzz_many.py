@@ -2,7 +2,7 @@
 of every run printed (rt_mesh_info / rt_last_stats).  Same cases as tools/fuzz_cpu.py (every mesh class of
 tests/meshgen.py, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on with exact steps only, off, on with cheap steps, and the
 library's defaults (pieces for small batches).
-usage (GPU box): python tools/fuzz_many.py [first_seed] [count]"""
+usage (GPU box): [FUZZ_TINY=1] [FUZZ_SHUFFLE=1] python tools/fuzz_many.py [first_seed] [count]"""
 import os
 import sys
 import time
@@ -29,7 +29,13 @@ for seed in range(first, first + count):
     kind, model, n_azim, delta, k = fuzz_cpu.case(seed)
     if n_azim >= 1024:  # keep a GPU run short: the CPU fuzzer covers the finest quadratures
         n_azim = 256
-    tg = rt.TrackGenerator(model, n_azim, delta)
+    if os.environ.get("FUZZ_SHUFFLE"):  # cells with their three nodes in random order (as tools/fuzz_cpu.py)
+        rs = np.random.default_rng(seed + 77)
+        cells = np.asarray(model.cell_node_ids).copy()
+        for c in range(len(cells)):
+            cells[c] = cells[c][rs.permutation(3)]
+        model = rt.DiscreteModel(model.node_coordinates, cells)
+    tg = rt.TrackGenerator(model, n_azim, delta, tiny_step=fuzz_cpu.tiny_of(seed) if os.environ.get("FUZZ_TINY") else 1e-8)
     rt.trace(tg)
     om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
     ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi, tiny_step=tg.tiny_step,
