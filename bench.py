@@ -114,6 +114,8 @@ def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=Non
     dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
     run_steps(rt, dt, tg, aq, warmup)
     total, el = run_steps(rt, dt, tg, aq, steps)
+    dm.set_option("timing", 1)
+    dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
     tm = dt.timing()
     out = {"workload": wl["name"], "tracks": int(tg.n_total_tracks), "segments": int(total), "steps": steps,
            "ms_per_step": el / steps * 1e3, "value": total * steps / el, "unit": "segments/s",
@@ -159,6 +161,46 @@ def two_in_flight(tg, aq, dmesh, dt, steps, segments_per_step):
                 "note": "two independent batches overlapped on two streams; not the headline value"}
     except Exception as e:  # pragma: no cover
         return {"error": repr(e)}
+
+
+def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
+    """a consumer that stays on the GPU and walks the cyclic tracks — one MOC transport sweep (rt_sweep) over the
+    device-resident records, from the compact CSR records and from the march's staging rows directly.  With the latter a
+    device-resident caller sets option "compact" = 0 and its step is march + offsets scan + sweep: no compaction.  Outside `value`."""
+    nc = dmesh.n_cells
+    sig = np.linspace(0.2, 1.6, nc * G).reshape(nc, G)
+    src = np.linspace(0.0, 1.0, nc * G).reshape(nc, G)
+    dt.sweep_set_links(tg)
+    out = {"groups": G, "note": "one transport sweep = every track forward and backward, per segment and group: τ = Σt·ℓ, "
+                                "Δ = (ψ − q/Σt)(−expm1(−τ)), ψ −= Δ, φ[cell] += w·Δ; boundary fluxes handed on through "
+                                "next_track_fwd/bwd + dir_next_track_* (Vacuum: 0); f64"}
+    seg = lambda: dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    for name, compact in (("compact", 1), ("staged", 0)):
+        dmesh.set_option("compact", compact)
+        seg()
+        r = dt.sweep(G, sig, src, None, None, input=name, fetch=False)
+        ms = min(dt.sweep(G, input=name, fetch=False)["ms"] for _ in range(5))
+        row_bytes = 20.0 if name == "staged" else 12.0  # per segment, direction and pass over a slab of groups
+        nbytes = total * 2.0 * r["passes"] * row_bytes
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            seg()
+            dt.sweep(G, input=name, fetch=False)
+        step_ms = (time.perf_counter() - t0) / steps * 1e3
+        out[name] = {"sweep_ms": ms, "passes": r["passes"], "groups_per_pass": r["groups_per_pass"], "bytes_per_segment": 2.0 * r["passes"] * row_bytes,
+                     "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "segment_group_updates_per_s": total * 2.0 * G / (ms * 1e-3),
+                     "ms_per_step_segmentize_plus_sweep": step_ms}
+    dmesh.set_option("compact", 0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        seg()
+    out["ms_per_step_without_compaction"] = (time.perf_counter() - t0) / steps * 1e3
+    dmesh.set_option("compact", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        seg()
+    out["ms_per_step_with_compaction"] = (time.perf_counter() - t0) / steps * 1e3
+    return out
 
 
 def cpu_baseline(tg):
@@ -316,16 +358,27 @@ def _main(real_stdout):
         local_total = step()
     drain()
     sync()
-    kern = {"march": 0.0, "compact": 0.0, "scan": 0.0, "volumes": 0.0, "plan": 0.0, "total": 0.0}
+    # ---- the timed region: K steps, no HIP events between the kernels (each costs ≈4 µs of stream time)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         local_total = step()
+    drain()
+    sync()
+    elapsed = time.perf_counter() - t0
+    # ---- the same K steps again with the library's HIP events on (option "timing"): per-kernel durations, measured live on
+    #      the stream the kernels are launched on — what `roofline` and `kernel_ms` report; never part of `value`
+    kern = {"march": 0.0, "compact": 0.0, "scan": 0.0, "volumes": 0.0, "plan": 0.0, "total": 0.0}
+    dmesh.set_option("timing", 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
         tm = dt.timing()  # HIP events recorded on the launch stream inside rt_segmentize
         for k in kern:
             kern[k] += tm[k]
     drain()
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_with_events = time.perf_counter() - t0
+    dmesh.set_option("timing", 0)
     n_failed, _, _ = dt.failed()  # tracks on which the reference itself would have thrown (never fatal here:
     #                               a rank that exits alone would deadlock the others)
     stats = dt.stats()
@@ -403,6 +456,12 @@ def _main(real_stdout):
                "fetch_GBs": 44.0 * local_total / (fetch_ms * 1e-3) / 1e9 if fetch_ms > 0 else 0.0,
                "note": "one call as the shim sees it: rt_mesh_create (once per mesh), rt_tracks_create (H2D of the track arrays), "
                        "rt_segmentize, rt_fetch_segments_pinned (D2H of the 44-B records over PCIe) — never part of `value`"}
+    downstream_sweep = None
+    if rank == 0 and not args.no_extras and not dist_on:
+        try:
+            downstream_sweep = sweep_bench(rt, tg, aq, dmesh, dt, local_total, max(3, args.steps // 2))
+        except Exception as e:  # pragma: no cover
+            downstream_sweep = {"error": repr(e)}
     downstream = None
     if rank == 0 and not args.no_extras and not dist_on:
         # a consumer that stays on the GPU: Segment.τ for 7 energy groups from the device-resident records
@@ -485,6 +544,8 @@ def _main(real_stdout):
             },
             "kernels": per_kernel,
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},
+            "kernel_ms_note": "from a second pass of the same K steps with the library's HIP events on (option \"timing\"); "
+                              "that pass took %.4f ms per step" % (elapsed_with_events / args.steps * 1e3),
         }
         if rehearsal:
             out["rehearsal"] = "RT_BENCH_REHEARSAL=1: all ranks on GPU 0, collectives over gloo on host copies — a functional run, its timings mean nothing"
@@ -501,6 +562,8 @@ def _main(real_stdout):
             out["config5_single_gpu"] = config5
         if downstream is not None:
             out["downstream_tau"] = downstream
+        if downstream_sweep is not None:
+            out["downstream_sweep"] = downstream_sweep
         if world == 1 and not dist_on and not args.no_concurrent:
             out["two_batches_in_flight"] = two_in_flight(tg, aq, dmesh, dt, args.steps, local_total)
         if world == 1 and not args.no_cpu_baseline:

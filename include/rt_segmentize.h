@@ -184,10 +184,53 @@ int32_t rt_fill_tau(rt_tracks *tracks, const double *sigma_t, int32_t n_groups, 
 int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
 
 /*
+ * A transport sweep over the cyclic tracks, on the device — the consumer the reference's layout exists
+ * for: "for track in tg.tracks_by_uid, for segment in track.segments" (README.md:127-135) with Segment.τ as its storage
+ * (src/segment.jl:14,28), the tracks chained into closed loops by next_track_fwd / next_track_bwd and dir_next_track_fwd /
+ * dir_next_track_bwd (src/track.jl:42-77; walked like this in demo/makie.jl:103-133).
+ *
+ * rt_sweep_set_links: the linking that trace! / next_tracks produced (src/trackgenerator.jl:231-348), in uid order, exactly
+ * the arrays rt_trace returns: 1-based uids of next_track_fwd / next_track_bwd, dir_next_track_* (0 Forward, 1 Backward),
+ * bc_fwd / bc_bwd (0 Vacuum, 1 Reflective, 2 Periodic).
+ *
+ * rt_sweep: one method-of-characteristics sweep over the records of the last rt_segmentize.  Every track u is traversed
+ * forward (its segments in march order, starting from psi_in[0][u][:]) and backward (reversed, from psi_in[1][u][:]); along
+ * a segment of length ℓ in cell e, for every group g,
+ *     τ = sigma_t[e][g]·ℓ,   Δ = (ψ − source[e][g] / sigma_t[e][g]) · (−expm1(−τ)),   ψ ← ψ − Δ,   φ[e][g] += w[u]·Δ
+ * i.e. ψ_out = ψ_in·e^{−τ} + (q/Σt)(1 − e^{−τ}); a cell with sigma_t = 0 leaves ψ unchanged.  The flux a track ends with is
+ * handed to the entry of the linked track, in the linked direction, as that entry's incoming flux for the NEXT sweep — 0
+ * behind a Vacuum boundary — so repeated calls with psi_in = NULL iterate on the device (Jacobi over the boundary fluxes).
+ *   n_groups            G >= 1; changing it resets the boundary fluxes to 0
+ *   sigma_t, source     [n_cells * G] total cross section and source per cell and group; NULL, NULL: those of the previous
+ *                       call (source alone may be NULL: zero source)
+ *   track_weight        [n_tracks] w[u]; NULL: the previous call's, or δs[azim_idx[u]] — the weight fill_volumes gives a
+ *                       segment (src/trackgenerator.jl:379-382) — if none was ever given
+ *   psi_in              [2][n_tracks][G] incoming boundary flux; NULL: what the previous sweep handed on (0 at first)
+ *   input               1: the compact CSR records (ℓ and element, 12 B per segment and direction); 2: the march's staging
+ *                       rows directly (q and cell, 20 B; p = previous q and ℓ = ‖p − q‖ rebuilt with the Segment
+ *                       constructor's expression, bit-identical) — what makes rt_set_option(mesh, "compact", 0) a complete
+ *                       step: march + offsets scan + sweep, no compaction; 0: the staging rows when the last call left
+ *                       them (whole-track single-pass calls do), else the compact records
+ *   ms                  (may be NULL) HIP-event duration of the sweep's kernels
+ * rt_sweep_fetch copies out (any may be NULL) phi[n_cells * G], psi_out[2][n_tracks][G] (the flux every traversal ended with)
+ * and psi_next[2][n_tracks][G] (the boundary flux of the next sweep).  rt_sweep_info: the device pointers of those three
+ * (ptrs_dev[3], may be NULL) and info[4] = {input used (1 / 2), groups per pass (0: global atomics), passes, n_groups}.
+ * Results agree with a sequential evaluation to rounding: device expm1 and the order of the tallies' additions differ.
+ */
+int32_t rt_sweep_set_links(rt_tracks *tracks, const int64_t *next_fwd, const int64_t *next_bwd, const int8_t *dir_fwd,
+                           const int8_t *dir_bwd, const int8_t *bc_fwd, const int8_t *bc_bwd);
+int32_t rt_sweep(rt_tracks *tracks, int32_t n_groups, const double *sigma_t, const double *source,
+                 const double *track_weight, const double *psi_in, int32_t input, double *ms);
+int32_t rt_sweep_fetch(rt_tracks *tracks, double *phi, double *psi_out, double *psi_next);
+int32_t rt_sweep_info(rt_tracks *tracks, void **ptrs_dev, int32_t *info);
+
+/*
  * HIP-event timings (milliseconds) of the last rt_segmentize on this handle, measured on
  * the stream the kernels ran on: ms[0] whole call (device side), ms[1] plan (track
  * binning), ms[2] march (the dominant kernel), ms[3] offsets scan, ms[4] compaction /
  * fill, ms[5] volumes.  Unused slots are 0.  n = capacity of ms (>= 6).
+ * The events are recorded only while rt_set_option(mesh, "timing", 1) is in force (default 0: every event
+ * record costs ≈4 µs of stream time between two kernels); without it all slots are 0.
  */
 int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
 
@@ -197,7 +240,13 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
  * the call launched, stats[5] 1 if it marched track pieces (split mode; 2: only the longest waves), stats[6] 1 for the wide-k instantiation,
  * stats[7] bytes of device memory this handle holds (inputs, staging pools, tables, results), stats[8] records decided by
  * cheap steps (a subset of the walk step's: the decision from the vertices' signed distances to the track line alone,
- * option "topo"; 0 when the call did not use them).
+ * option "topo"; 0 when the call did not use them); stats[9..17] cheap steps REFUSED in the call, by the certificate term
+ * that failed (a refusal may fail several): 9 no predicted record, 10 node-scan window (extras > k), 11 |s2| < d_vertex,
+ * 12 entry edge not crossed, 13 m < E·D + g1 (isolation / border margin), 14 D < k2, 15 Dx < k2 (rounding of the entry / exit
+ * point), 16 D·c1 < dtf (bound on tiny steps), 17 |s_v| < lc·lcf (chord length / order guard) — DESIGN.md §2; stats[18] tracks
+ * whose Σℓ check (src/track.jl:171) lies within summation-order noise (64 ulp·n) of its rtol threshold: their status could
+ * differ under Julia's pairwise / @simd `sum`; stats[19] tracks marched again with exact steps because the cheap steps'
+ * iteration bound reached the iteration cap.
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 
@@ -243,6 +292,9 @@ int32_t rt_multi_fetch_volumes(rt_multi *multi, double *volumes);
  * device pointers of the global px, py, qx, qy, ell (f64) and element (i32) arrays on device_ids[i], valid until the
  * next rt_multi_allgather / rt_multi_destroy; *ms (may be NULL) the wall time of the copies. */
 int32_t rt_multi_allgather(rt_multi *multi, void **ptrs_dev, double *ms);
+/* Achieved rate of the last rt_multi_allgather per (destination i, source j) pair, GBs[i * n_devices + j] in GB/s of
+ * 44-B records (0 where nothing was copied): every pair runs on its own stream, i.e. over its own xGMI link. */
+int32_t rt_multi_link_rates(rt_multi *multi, double *GBs);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side rows around the hot path: they run on the CPU, like in the
@@ -282,7 +334,15 @@ int32_t rt_msh_fetch(rt_msh *msh, double *x, double *y, int32_t *cell_nodes, int
                      int32_t *node_cells_data, double *bb);
 void rt_msh_free(rt_msh *msh);
 
-/* Tunables (name/value); unknown names return RT_ERR_INVALID.  See DESIGN.md. */
+/* Tunables (name/value); unknown names return RT_ERR_INVALID.  See DESIGN.md.  The ones a caller may want:
+ *   "timing"   1: record HIP events for rt_last_timing (default 0)
+ *   "compact"  0: rt_segmentize stops after march + offsets scan — offsets, status and volumes are final, the 44-B records
+ *                 stay in the march's staging rows (20 B/segment) and are only produced when somebody asks for them
+ *                 (rt_fetch_segments*, rt_device_pointers, rt_fill_tau); rt_sweep reads the staged rows directly (default 1)
+ *   "topo"     0: exact walk steps only, 1: cheap steps where >= 90 % of the walkable records carry a cheap certificate
+ *                 (default), 2: forced — wherever a record carries one, and waves never hand back to exact steps
+ *   "walk"     0: literal step only (find_element + intersections every iteration)
+ *   "iter_cap" guard on the reference's unbounded `continue` paths (default 4,000,000 iterations per track) */
 int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -20,6 +20,7 @@ SYMBOLS = (
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
+    "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_multi_link_rates",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
     "rt_multi_failed_tracks", "rt_multi_fetch_offsets", "rt_multi_fetch_segments", "rt_multi_fetch_volumes", "rt_multi_allgather",
     "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
@@ -133,6 +134,17 @@ def lib():
         L.rt_fill_tau.argtypes = [_vp, _dp, C.c_int32, C.POINTER(_vp), _dp]
         L.rt_fetch_tau.restype = C.c_int32
         L.rt_fetch_tau.argtypes = [_vp, _dp]
+        _bp8 = C.POINTER(C.c_int8)
+        L.rt_sweep_set_links.restype = C.c_int32
+        L.rt_sweep_set_links.argtypes = [_vp, _lp, _lp, _bp8, _bp8, _bp8, _bp8]
+        L.rt_sweep.restype = C.c_int32
+        L.rt_sweep.argtypes = [_vp, C.c_int32, _dp, _dp, _dp, _dp, C.c_int32, _dp]
+        L.rt_sweep_fetch.restype = C.c_int32
+        L.rt_sweep_fetch.argtypes = [_vp, _dp, _dp, _dp]
+        L.rt_sweep_info.restype = C.c_int32
+        L.rt_sweep_info.argtypes = [_vp, C.POINTER(_vp), _ip]
+        L.rt_multi_link_rates.restype = C.c_int32
+        L.rt_multi_link_rates.argtypes = [_vp, _dp]
         L.rt_multi_create.restype = _vp
         L.rt_multi_create.argtypes = [_ip, C.c_int32, _dp, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, _dp, C.c_int64] + [_dp] * 9 + [_ip]
         L.rt_multi_destroy.argtypes = [_vp]
@@ -353,15 +365,65 @@ class DeviceTracks:
             _check(lib().rt_fetch_tau(self._h, tau.ctypes.data_as(_dp)))
         return tau, (ptr.value or 0), ms.value
 
+    def sweep_set_links(self, tg):
+        """``rt_sweep_set_links`` with the link arrays ``trace`` left in the TrackGenerator (``tg`` must hold this handle's
+        tracks, in uid order) — or pass a dict with next_fwd, next_bwd, dir_fwd, dir_bwd, bc_fwd, bc_bwd."""
+        if isinstance(tg, dict):
+            d = tg
+        else:
+            d = dict(next_fwd=tg.next_fwd_uid, next_bwd=tg.next_bwd_uid, dir_fwd=tg.dir_next_fwd, dir_bwd=tg.dir_next_bwd,
+                     bc_fwd=tg.bc_fwd, bc_bwd=tg.bc_bwd)
+        nf = np.ascontiguousarray(d["next_fwd"], np.int64); nb = np.ascontiguousarray(d["next_bwd"], np.int64)
+        b8 = [np.ascontiguousarray(d[k], np.int8) for k in ("dir_fwd", "dir_bwd", "bc_fwd", "bc_bwd")]
+        if any(len(a) != self.n for a in [nf, nb] + b8):
+            raise ValueError("link arrays must have one entry per track")
+        p8 = C.POINTER(C.c_int8)
+        _check(lib().rt_sweep_set_links(self._h, nf.ctypes.data_as(_lp), nb.ctypes.data_as(_lp), *[a.ctypes.data_as(p8) for a in b8]))
+
+    SWEEP_INPUT = {"auto": 0, "compact": 1, "staged": 2}
+
+    def sweep(self, n_groups, sigma_t=None, source=None, track_weight=None, psi_in=None, input="auto", fetch=True):
+        """``rt_sweep``: one transport sweep over the cyclic tracks on the device.  ``sigma_t`` / ``source``: [n_cells, G];
+        ``track_weight``: [n_tracks]; ``psi_in``: [2, n_tracks, G] (None: what the previous sweep handed on).  Returns a dict
+        with ``ms``, ``input`` ("compact" / "staged"), ``groups_per_pass``, ``passes`` and, with ``fetch``, ``phi`` [n_cells, G],
+        ``psi_out`` and ``psi_next`` [2, n_tracks, G]."""
+        G = int(n_groups)
+
+        def arr(a, shape):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, np.float64)
+            if a.size != int(np.prod(shape)):
+                raise ValueError("expected an array of shape %r" % (shape,))
+            return a, a.ctypes.data_as(_dp)
+
+        st, stp = arr(sigma_t, (self.dmesh.n_cells, G)); q, qp = arr(source, (self.dmesh.n_cells, G))
+        w, wp = arr(track_weight, (self.n,)); pi, pip = arr(psi_in, (2, self.n, G))
+        ms = C.c_double(0.0)
+        _check(lib().rt_sweep(self._h, G, stp, qp, wp, pip, self.SWEEP_INPUT[input], C.byref(ms)))
+        info = (C.c_int32 * 4)()
+        _check(lib().rt_sweep_info(self._h, None, info))
+        out = dict(ms=ms.value, input={1: "compact", 2: "staged"}[int(info[0])], groups_per_pass=int(info[1]), passes=int(info[2]))
+        if fetch:
+            out["phi"] = np.empty((self.dmesh.n_cells, G)); out["psi_out"] = np.empty((2, self.n, G)); out["psi_next"] = np.empty((2, self.n, G))
+            _check(lib().rt_sweep_fetch(self._h, *[out[k].ctypes.data_as(_dp) for k in ("phi", "psi_out", "psi_next")]))
+        return out
+
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
-        v = (C.c_int64 * 9)()
-        _check(lib().rt_last_stats(self._h, v, 9))
+        v = (C.c_int64 * 20)()
+        _check(lib().rt_last_stats(self._h, v, 20))
         return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
                     chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]), device_bytes=int(v[7]),
-                    cheap_records=int(v[8]))
+                    cheap_records=int(v[8]), cheap_refusals={k: int(v[9 + i]) for i, k in enumerate(self.REFUSAL_TERMS)},
+                    tracks_near_rtol=int(v[18]), tracks_restarted=int(v[19]))
+
+    # the nine terms of the cheap step's certificate (rt_device.hpp, topo_certified), in rt_last_stats' order
+    REFUSAL_TERMS = ("no_record", "scan_window", "vertex_clearance", "entry_not_crossed", "isolation_margin", "entry_rounding",
+                     "exit_rounding", "tiny_step_bound", "chord_order")
 
     def timing(self):
+        """``rt_last_timing`` — all zeros unless the mesh option ``"timing"`` is 1 (HIP events cost stream time)."""
         ms = getattr(self, "_ms_buf", None)
         if ms is None:
             ms = self._ms_buf = (C.c_double * 8)()
@@ -437,6 +499,12 @@ class MultiDevice:
     def fetch_volumes(self):
         v = np.zeros(self.n_cells, np.float64)
         _check(lib().rt_multi_fetch_volumes(self._h, v.ctypes.data_as(_dp)))
+        return v
+
+    def link_rates(self):
+        """``rt_multi_link_rates``: GB/s of the last all-gather per (destination, source) pair."""
+        v = np.zeros((self.n_devices, self.n_devices))
+        _check(lib().rt_multi_link_rates(self._h, v.ctypes.data_as(_dp)))
         return v
 
     def allgather(self):

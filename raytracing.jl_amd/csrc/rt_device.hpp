@@ -127,6 +127,8 @@ struct DParams {
     int32_t n_azim_2;
     int64_t iter_cap;
     double topo_tiny_max, topo_rmax, topo_end_err;  // cheap steps (topo_track); unused elsewhere
+    int32_t topo_force;  // 1: option "topo" = 2 — a wave that is refused often does NOT hand back to exact steps
+    int32_t pad_;
 };
 
 // ---------------------------------------------------------------- Base.isapprox ----------
@@ -830,6 +832,20 @@ RT_HD __forceinline__ bool topo_certified(const TopoTrack &tt, const TopoState &
     kf = kf < (float)kTopoKcap ? kf : (float)kTopoKcap;  // (D·c1 >= dtf: never more than kTopoKcap; also absorbs a NaN)
     kub = (int32_t)kf + 4;
     return ok != 0;
+}
+// The nine terms of topo_certified as a bit mask of the ones that FAIL (bit order = order in the expression above):
+// 0 no predicted record, 1 scan window (extras > k), 2 |s2| < d_vertex, 3 entry edge not crossed, 4 m < E·D + g1,
+// 5 D < k2, 6 Dx < k2, 7 D·c1 < dtf, 8 |s_v| < lc·lcf.  Statistics only (cold path of k_march, tests).
+RT_HD __forceinline__ uint32_t topo_refusal_terms(const TopoTrack &tt, const TopoState &ts, const TopoGeo &g, uint64_t hdr, uint32_t c01,
+                                                  uint32_t c23, int kk) {
+    const double a0 = fabs(g.s0), a1 = fabs(g.s1), a2 = fabs(g.s2);
+    const double D = a0 + a1, m = a0 < a1 ? a0 : a1;
+    const double sv = g.exit1 ? a1 : a0, Dx = a2 + sv;
+    const double g1 = bf16_lo(c01), k2 = bf16_hi(c01), dtf = bf16_lo(c23), lc = bf16_hi(c23);
+    return (uint32_t)!(ts.pred >= 0) | (uint32_t)!(rec_extras(hdr) <= kk) << 1 | (uint32_t)!(a2 >= tt.dv) << 2 |
+           (uint32_t)!((g.s0 > 0) != (g.s1 > 0)) << 3 | (uint32_t)!(m >= __builtin_fma(rec_eps(hdr), D, g1)) << 4 |
+           (uint32_t)!(D >= k2) << 5 | (uint32_t)!(Dx >= k2) << 6 | (uint32_t)!(D * tt.c1 >= dtf) << 7 |
+           (uint32_t)!(sv >= lc * tt.lcf) << 8;
 }
 // kTopoEmit: on to the successor (pred = -1 when there is none with a certificate: exact steps from `last`);
 // kTopoEnd: the exit edge lies on the border and the track ends for sure after this record

@@ -123,6 +123,13 @@ __device__ __forceinline__ int64_t stage_slot(int32_t chunk, int row, int lane) 
 }
 
 enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
+// The control block of a call (device, copied to pinned host memory by the scan's last block): words 0..15 failure summary /
+// statistics, 16 total segments, 18..19 pool cursor + overflow flag, 20 ticket of the scan's "last block" step, 21 tracks
+// that reached MAX_ITER segments in split mode, 22..26 development statistics (RT_STATS), and
+constexpr int kCtlWords = 64;
+constexpr int kCtlRefusal = 32;   // 32..40: cheap-step refusals by certificate term (order of topo_certified)
+constexpr int kCtlRestarts = 41;  // tracks marched again with exact steps after cheap steps (their fused volumes were counted twice)
+constexpr int kCtlNearRtol = 42;  // tracks whose Σℓ check (src/track.jl:171) sits within summation-order noise of its threshold
 // generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
 // C3 — a lane that escalates waits for the rest of its wave — 8..32 equal)
 constexpr int kCreepLocal = 16;
@@ -150,6 +157,15 @@ struct DSplit {
     RT_G int32_t *p_valid, *p_rel;    // after k_resolve: records kept from the piece / their offset inside the track's run
     int32_t n_vwaves;
 };
+
+// The Σℓ check `isapprox(track.ℓ, sum(ℓ.(segments)); rtol)` (src/track.jl:171) is decided here — and in the oracle — with a
+// left-to-right sum; Julia's `sum` reassociates (pairwise blocks, @simd lanes), so its Σℓ can differ by a few ulp·n.  A
+// track whose |ℓ − Σℓ| lies within 64·ulp·n·max(ℓ, Σℓ) of the threshold rtol·max(ℓ, Σℓ) could get the other status there:
+// such tracks are counted (rt_last_stats) so that a caller knows when this cannot be pinned.
+__device__ __forceinline__ bool sum_check_is_marginal(double ell, double sum, double rtol, int n) {
+    const double big = fabs(ell) > fabs(sum) ? fabs(ell) : fabs(sum);
+    return fabs(fabs(ell - sum) - rtol * big) <= 64.0 * 1.1102230246251565e-16 * (double)(n > 1 ? n : 1) * big;
+}
 
 template <bool WIDEK>
 __global__ __launch_bounds__(64) void k_seed(DMesh m, DTracks t, DParams prm, DSplit sp) {
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256) void k_resolve(DTracks t, DParams prm, DSplit 
         k = fl >> 16;  // the piece whose seed this one met
     }
     if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
+    if (sum_check_is_marginal(t.ell[u], sum, prm.rtol, total)) atomicAdd(&fail_info[kCtlNearRtol], 1ull);
     {   // records of overrun pieces were marched (and, with fused volumes, accumulated) but are not kept
         int32_t all = 0;
         for (int kk2 = 0; kk2 < P; ++kk2) all += sp.p_count[(int64_t)(base + kk2) * 64 + lane];
@@ -280,6 +297,14 @@ struct MarchArgsLayout {
 __device__ __forceinline__ const RT_K DStage *march_stage_args() {
     const RT_K char *ka = (const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr();
     return (const RT_K DStage *)(ka + offsetof(MarchArgsLayout, stg));
+}
+
+// the call's control block / parameters, read from the argument segment in cold branches (not held across the loop)
+__device__ __forceinline__ unsigned long long *march_ctl() {
+    return *(unsigned long long *const RT_K *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, fail_info));
+}
+__device__ __forceinline__ const RT_K DParams *march_prm_args() {
+    return (const RT_K DParams *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, prm));
 }
 
 // WIDEK: k > kMaxK (the knn fallback of find_element serves its node list in batches); a separate instantiation, so that
@@ -540,6 +565,15 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                         else if (i >= kMaxIter) fl = (fl & ~kFlCheap) | kFlWait;
                     } else if (cheap) {
                         fl = (fl & ~kFlCheap) | (ok ? kFlRestart : kFlMat);  // refused: the exact step decides this record
+                        // per-call statistic (rt_last_stats): which certificate term refused — a cold branch (every refusal
+                        // costs its wave an exact step anyway); one atomic per term and wave
+                        const uint32_t bad = ok ? 0u : topo_refusal_terms(tt, ts, g, c_hdr, c_c01, c_c23, kk);
+                        unsigned long long *ctl = march_ctl();
+                        const int first = __ffsll((long long)__ballot(1)) - 1;
+                        for (int b = 0; b < 9; ++b) {
+                            const unsigned long long mb = __ballot((bad >> b) & 1u);
+                            if (mb && lane == first) atomicAdd(ctl + kCtlRefusal + b, (unsigned long long)__popcll(mb));
+                        }
                     }
                     c_hdr = n_hdr; c_x2 = n_x2; c_y2 = n_y2; c_c01 = n_c01; c_c23 = n_c23;
                     pe_A = eA; pe_B = eB; pe_C = eC; p_cell = g.cell;
@@ -550,8 +584,12 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             // walk step's certificates but not the cheap step's: every refusal is an exact pass the other lanes wait for)
             // goes on with exact steps only, i.e. as the march without cheap steps.
             if (__builtin_expect(tt.on && n_cheap_ref >= 16 && 8 * n_cheap_ref > n_cheap_it, 0)) {
-                tt.on = false;
-                if (fl & kFlCheap) fl = (fl & ~kFlCheap) | kFlMat;
+                if (march_prm_args()->topo_force) {  // option "topo" = 2: every record that carries a cheap certificate uses it
+                    n_cheap_ref = 0; n_cheap_it = 0;
+                } else {
+                    tt.on = false;
+                    if (fl & kFlCheap) fl = (fl & ~kFlCheap) | kFlMat;
+                }
             }
             const bool any_cheap = __ballot((fl & kFlCheap) != 0) != 0;
             if ((fl & kFlDone) || i >= kMaxIter) break;
@@ -559,6 +597,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             if (__builtin_expect((fl & kFlRestart) || ((fl & kFlUsed) && it >= cap), 0)) {
                 // the bound reached the iteration cap: this track is marched again from its start with exact steps only
                 asm volatile("" ::: "memory");
+                // its cheap records have already been added to the fused volumes: the host recomputes them from the records
+                atomicAdd(march_ctl() + kCtlRestarts, 1ull);
                 tt.on = false; fl = 0; n_generic = 0;
                 i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
                 xpx = t.px[u] + sx; xpy = t.py[u] + sy;
@@ -804,6 +844,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     } else if (MODE != kFill) {
         // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol)
         if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
+        if (sum_check_is_marginal(t.ell[u], sum_ell, prm.rtol, i)) atomicAdd(march_ctl() + kCtlNearRtol, 1ull);
         counts[u] = i;
         status[u] = st;
         {
@@ -965,7 +1006,7 @@ constexpr int kScanTile = kScanBlock * kScanPer;
 __global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells, int32_t first_chunk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // [1]: first failing uid, an atomicMin target; [18]: pool cursor (low word; chunks below first_chunk are reserved) + overflow flag
-    if (i < 32) ctl[i] = i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk : 0ull);
+    if (i < kCtlWords) ctl[i] = i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk : 0ull);
     if (i < n_cells) volumes[i] = 0.0;
 }
 
@@ -1025,7 +1066,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
     if (host_copy) {
         __syncthreads();
         __threadfence();
-        if (threadIdx.x < 32) host_copy[threadIdx.x] = __builtin_nontemporal_load(&ctl[threadIdx.x]);
+        if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __builtin_nontemporal_load(&ctl[threadIdx.x]);
     }
 }
 
@@ -1143,6 +1184,176 @@ __global__ __launch_bounds__(256) void k_fill_tau(const double *__restrict__ ell
     }
 }
 
+// ---- transport sweep over the cyclic tracks ------------------------------------------------------
+// The consumer the reference's Track/Segment layout exists for (README.md:127-135: "for track in tg.tracks_by_uid, for
+// segment in track.segments: segment.ℓ, segment.element"; Segment.τ is its per-segment storage, src/segment.jl:14,28; the
+// tracks form closed loops through next_track_fwd / next_track_bwd and dir_next_track_*, src/track.jl:42-77, walked as in
+// demo/makie.jl:103-133): one method-of-characteristics sweep.  Every track is traversed forward (segments in march order)
+// and backward (reversed); along a segment of length ℓ in cell e, for every energy group g,
+//     τ = Σt[e][g]·ℓ,   Δ = (ψ − q[e][g]/Σt[e][g]) · (−expm1(−τ)),   ψ ← ψ − Δ,   φ[e][g] += w_track · Δ
+// (ψ_out = ψ_in·e^{−τ} + (q/Σt)(1 − e^{−τ}) in its cancellation-free form); ψ starts from the track's incoming boundary
+// flux and ends as its outgoing flux, which k_sweep_link hands to the linked track's entry for the next sweep (0 behind a
+// Vacuum boundary).  One lane per track, the march's own lane mapping — so the STAGED variant reads the march's staging
+// rows directly (20 B per segment, each row of a wave is four full 128-B lines; p = previous q, ℓ = ‖p − q‖ with the
+// Segment constructor's expression, bit-identical to the compact records') and a device-resident consumer never needs the
+// compaction; the other variant reads ℓ and the cell id of the compact CSR records.  The per-cell tallies are accumulated
+// like fill_volumes: ds_add_f64 into an LDS-private copy of φ for GP groups at a time (the 160 KB of LDS hold 4 groups
+// of the pincell mesh), flushed once per workgroup; meshes whose copy does not fit tally with global atomics.
+struct DSweep {
+    DStage stg;                       // STAGED: the march's staging rows
+    const RT_G double *ell;           // compact records
+    const RT_G int32_t *element;
+    const RT_G int64_t *offsets;      // CSR offsets per uid
+    const RT_G int32_t *counts;       // records per uid
+    const RT_G int32_t *perm;         // march slot -> uid
+    const RT_G int32_t *azim;         // default weight: delta_s[azim[u] - 1], as fill_volumes weighs a segment
+    const RT_G double *delta_s;
+    const RT_G double *w;             // explicit per-track weight (or null)
+    const RT_G double *xs;            // [n_cells * G][2]: Σt, q / Σt
+    const RT_G double *psi_in;        // [2][n][G] incoming boundary flux: forward (at track.p), backward (at track.q)
+    RT_G double *psi_out;             // [2][n][G] outgoing flux at the other end
+    RT_G double *phi;                 // [n_cells * G] tallies
+    int64_t n;
+    int32_t n_waves, n_cells, G, g0, ng, use_lds;
+};
+
+template <bool STAGED, int GP>
+__global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sweep_smem[];
+    double *hist = reinterpret_cast<double *>(sweep_smem);  // [n_cells * GP] when use_lds
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, W = blockDim.x >> 6;
+    if (a.use_lds) {
+        for (int c = threadIdx.x; c < a.n_cells * GP; c += blockDim.x) hist[c] = 0.0;
+        __syncthreads();
+    }
+    // a sweep wave = (march wave, direction): the two directions of the same 64 tracks sit next to each other in a workgroup
+    const int64_t sw = (int64_t)blockIdx.x * W + wib;
+    const int64_t mw = sw >> 1;
+    const int dir = (int)(sw & 1);
+    if (mw < a.n_waves) {
+        const int64_t slot = mw * 64 + lane;
+        const bool have = slot < a.n;
+        const int32_t u = have ? a.perm[slot] : 0;
+        const int32_t cnt = have ? a.counts[u] : 0;
+        int32_t maxcnt = cnt;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int32_t v = __shfl_xor(maxcnt, o, 64);
+            maxcnt = v > maxcnt ? v : maxcnt;
+        }
+        const double w = !have ? 0.0 : (a.w ? a.w[u] : a.delta_s[a.azim[u] - 1]);
+        const int64_t off = (!STAGED && have) ? a.offsets[u] : 0;
+        const int64_t pbase = ((int64_t)dir * a.n + u) * a.G + a.g0;
+        double psi[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) psi[g] = (have && g < a.ng) ? a.psi_in[pbase + g] : 0.0;
+        const RT_G int32_t *ctab = a.stg.ctab + mw * kMaxChunks;
+        // one segment: attenuation and tally for the GP groups of this pass
+        auto segment = [&](const int32_t e, const double ell, const bool act) {
+            const RT_G double *x = a.xs + ((int64_t)(act ? e : 0) * a.G + a.g0) * 2;
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                if (g < a.ng) {  // (uniform)
+                    const double st = x[2 * g], qs = x[2 * g + 1];
+                    const double tau = st * ell;
+                    const double ex = -expm1(-tau);
+                    const double d = (psi[g] - qs) * ex;
+                    if (act) {
+                        psi[g] = psi[g] - d;
+                        if (a.use_lds) atomicAdd(&hist[e * GP + g], w * d);
+                        else unsafeAtomicAdd((double *)&a.phi[(int64_t)e * a.G + a.g0 + g], w * d);
+                    }
+                }
+            }
+        };
+        if (STAGED) {
+            // row r of this wave: chunk ctab[r >> 5] (wave-uniform), slot (row, lane) inside it; q and ±cell of every record,
+            // p only for marked records (cell < 0: first record of a track, records of the generic step)
+            struct Row { double qx, qy; int32_t el; };
+            auto load_row = [&](const int r, const bool on) -> Row {
+                Row R{0.0, 0.0, 1};
+                if (on) {
+                    const int64_t sl = stage_slot(ctab[r >> kChunkLog2], r & (kChunkRows - 1), lane);
+                    R.qx = a.stg.qx[sl]; R.qy = a.stg.qy[sl]; R.el = a.stg.element[sl];
+                }
+                return R;
+            };
+            if (dir == 0) {
+                Row nxt = load_row(0, 0 < cnt);
+                double lqx = 0.0, lqy = 0.0;
+                for (int i = 0; i < maxcnt; ++i) {
+                    const Row cur = nxt;
+                    const bool act = i < cnt;
+                    nxt = load_row(i + 1, i + 1 < cnt);  // in flight while this row is evaluated
+                    double px = lqx, py = lqy;
+                    if (act && cur.el < 0) {
+                        const int64_t sl = stage_slot(ctab[i >> kChunkLog2], i & (kChunkRows - 1), lane);
+                        px = a.stg.px[sl]; py = a.stg.py[sl];
+                    }
+                    const double ell = norm2(px - cur.qx, py - cur.qy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
+                    segment((cur.el < 0 ? -cur.el : cur.el) - 1, ell, act);
+                    lqx = cur.qx; lqy = cur.qy;
+                }
+            } else {
+                // reversed order (demo/makie.jl:103: "the segments are stored in reverse order for backward tracks"): rows
+                // maxcnt-1 .. 0 in lockstep, a lane joins at its own last row; p of row i is q of row i - 1
+                Row nxt = load_row(maxcnt - 1, maxcnt - 1 < cnt);
+                for (int i = maxcnt - 1; i >= 0; --i) {
+                    const Row cur = nxt;
+                    const bool act = i < cnt;
+                    nxt = load_row(i - 1, i >= 1 && i - 1 < cnt);
+                    double px = nxt.qx, py = nxt.qy;
+                    if (act && cur.el < 0) {
+                        const int64_t sl = stage_slot(ctab[i >> kChunkLog2], i & (kChunkRows - 1), lane);
+                        px = a.stg.px[sl]; py = a.stg.py[sl];
+                    }
+                    const double ell = norm2(px - cur.qx, py - cur.qy);
+                    segment((cur.el < 0 ? -cur.el : cur.el) - 1, ell, act);
+                }
+            }
+        } else {
+            auto load_rec = [&](const int r, const bool on, double &ell, int32_t &el) {
+                ell = 0.0; el = 1;
+                if (on) { ell = a.ell[off + r]; el = a.element[off + r]; }
+            };
+            double ell_n; int32_t el_n;
+            const int r0 = dir == 0 ? 0 : maxcnt - 1, step = dir == 0 ? 1 : -1;
+            load_rec(r0, r0 < cnt, ell_n, el_n);
+            for (int t = 0, i = r0; t < maxcnt; ++t, i += step) {
+                const double ell = ell_n; const int32_t el = el_n;
+                const bool act = i < cnt;
+                const int j = i + step;
+                load_rec(j, j >= 0 && j < cnt, ell_n, el_n);
+                segment(el - 1, ell, act);
+            }
+        }
+        if (have)
+#pragma unroll
+            for (int g = 0; g < GP; ++g)
+                if (g < a.ng) a.psi_out[pbase + g] = psi[g];
+    }
+    if (a.use_lds) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < a.n_cells * GP; c += blockDim.x) {
+            const double v = hist[c];
+            const int cell = c / GP, g = c - cell * GP;
+            if (v != 0.0 && g < a.ng) unsafeAtomicAdd((double *)&a.phi[(int64_t)cell * a.G + a.g0 + g], v);
+        }
+    }
+}
+
+// The boundary flux of the next sweep: entry (direction d', track v) receives the outgoing flux of the (direction, track)
+// linked to it through next_track_fwd / next_track_bwd and dir_next_track_* (src/track.jl:42-77; the gather map is built on
+// the host from rt_trace's link arrays), 0 behind a Vacuum boundary or where nothing is linked.
+__global__ __launch_bounds__(256) void k_sweep_link(const int32_t *__restrict__ src_of, const double *__restrict__ psi_out,
+                                                    double *__restrict__ psi_in, int64_t n2, int32_t G, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (entry slot, group)
+    if (i >= n2 * G) return;
+    const int64_t slot = i / G;
+    const int32_t g = (int32_t)(i - slot * G);
+    const int32_t sc = src_of[slot];  // source track * 2 + source direction, -1: none
+    psi_in[i] = sc < 0 ? 0.0 : psi_out[((int64_t)(sc & 1) * n + (sc >> 1)) * G + g];
+}
+
 __global__ void k_scale_volumes(double *__restrict__ vol, int32_t n_cells, double n_azim_2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_cells) vol[i] = vol[i] / n_azim_2;  // volumes ./= n_azim_2, src/trackgenerator.jl:386
@@ -1175,7 +1386,12 @@ struct rt_mesh {
     int split = -1;         // track splitting (see DSplit), read by rt_tracks_create: -1 auto (only batches that leave the chip
                             // underfilled), 0 off, > 0 pieces of about `split` expected segments
     int n_cus = 256;
-    int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it
+    int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
+    int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
+    int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
+                           // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is
+                           // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
+    int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
     double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0;
     int64_t n_records_topo = 0;
@@ -1184,6 +1400,8 @@ struct rt_mesh {
     int lds_records = 0;   // experiment: 1 = eight-wave workgroups with all walk records in LDS (meshes that fit), 2 = the same shape from L2
     int hybrid_pct = 55;   // ... those whose expected segment count exceeds this percentage of the batch's longest
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
+    int compact = 1;       // 0: rt_segmentize stops after march + scan (offsets, status, volumes); the 44-B records are produced on
+                           // demand (rt_fetch_segments*, rt_device_pointers, rt_fill_tau), and rt_sweep reads the staged rows directly
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int64_t test_out_records = 0;   // tests only: capacity of the output arrays on a handle's first call (forces the re-compaction path)
     int test_volumes_fallback = 0;  // tests only: take the split mode's volumes recomputation path unconditionally
@@ -1214,7 +1432,7 @@ struct rt_tracks {
 #ifdef RT_TIMING
     DevBuf<unsigned long long> dbg;
 #endif
-    unsigned long long *h_ctl = nullptr;  // pinned: [0..31] init image, [32..63] read-back
+    unsigned long long *h_ctl = nullptr;  // pinned: [0..63] init image, [64..127] read-back
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
     DevBuf<double> tau, sigma_t;  // rt_fill_tau
     int32_t tau_groups = 0;
@@ -1243,6 +1461,23 @@ struct rt_tracks {
     size_t pin_cap = 0;                                                     // records
     hipEvent_t ev[8] = {};
     double ms[8] = {};
+    // what the compaction of the last single-pass call needs (it may run later, on demand: option "compact" = 0)
+    struct CompactPlan {
+        rt::DStage stg{}, stg_pieces{};
+        rt::DTracks d_whole{};
+        rt::DSplit sp{};
+        const int32_t *corder = nullptr;
+        int64_t n_whole_waves = 0;
+        bool split = false, split_all = false, staged = false;  // staged: the last call left staged rows (single-pass mode)
+    } cplan;
+    bool compacted = false;  // the six record arrays hold the last call's records
+    // rt_sweep: the gather map of the cyclic linking, per-track weights, cross sections, boundary fluxes, tallies
+    DevBuf<int32_t> sw_src;
+    DevBuf<double> sw_w, sw_xs, sw_psi_in, sw_psi_out, sw_phi;
+    bool sw_links = false, sw_has_w = false, sw_has_xs = false, sw_done = false;
+    int32_t sw_groups = 0, sw_last_input = 0, sw_last_gp = 0, sw_last_passes = 0;
+    int64_t refusals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // cheap-step refusals of the last call by certificate term
+    int64_t n_near_rtol = 0, n_restarts = 0;
     int64_t n_failed = 0, first_failed_uid = 0;
     int32_t first_failed_status = 0;
 };
@@ -1372,6 +1607,42 @@ void free_mesh(rt_mesh *m) {
 
 void pin_release_to_cache(rt_tracks *t);  // defined with rt_fetch_segments_pinned
 
+// The six record arrays of a handle, sized for `tot` records, as the kernels see them.
+int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out) {
+    using rt::as_global;
+    const size_t cap = (size_t)(tot > 0 ? tot : 1);
+    RT_HIP(t->spx.reserve(cap)); RT_HIP(t->spy.reserve(cap)); RT_HIP(t->sqx.reserve(cap));
+    RT_HIP(t->sqy.reserve(cap)); RT_HIP(t->sell.reserve(cap)); RT_HIP(t->element.reserve(cap));
+    out.px = as_global(t->spx.p); out.py = as_global(t->spy.p); out.qx = as_global(t->sqx.p);
+    out.qy = as_global(t->sqy.p); out.ell = as_global(t->sell.p); out.element = as_global(t->element.p);
+    out.cap = (int64_t)std::min({t->spx.cap, t->spy.cap, t->sqx.cap, t->sqy.cap, t->sell.cap, t->element.cap});
+    return RT_SUCCESS;
+}
+
+// Staged rows -> compact CSR records (k_compact3) for the plan of the last single-pass call.
+void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s) {
+    const rt_tracks::CompactPlan &c = t->cplan;
+    if (t->n > 0 && !c.split_all && c.n_whole_waves > 0)
+        hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)c.n_whole_waves), dim3(256), 0, s, c.d_whole,
+                           (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg, out, c.sp, c.corder);
+    if (t->n > 0 && c.split)
+        hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
+                           (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg_pieces, out, c.sp, (const int32_t *)nullptr);
+}
+
+// Option "compact" = 0 leaves the records staged; whoever needs the 44-B records (fetch, device pointers, τ) gets them here.
+int ensure_compacted(rt_tracks *t) {
+    if (t->compacted) return RT_SUCCESS;
+    if (!t->cplan.staged) { set_error("the last rt_segmentize left no staged records"); return RT_ERR_NOT_SEGMENTIZED; }
+    rt::DOut out{};
+    if (int rc = reserve_records(t, t->total, out)) return rc;
+    launch_compaction(t, out, t->mesh->stream);
+    RT_HIP(hipStreamSynchronize(t->mesh->stream));
+    RT_HIP(hipGetLastError());
+    t->compacted = true;
+    return RT_SUCCESS;
+}
+
 void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->perm_whole.release(); t->corder.release();
@@ -1386,6 +1657,7 @@ void free_tracks(rt_tracks *t) {
     t->volumes.release(); t->volumes_prev.release(); t->delta_s.release(); t->tau.release(); t->sigma_t.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
     t->gelement.release(); t->ctab.release(); t->cowner.release();
+    t->sw_src.release(); t->sw_w.release(); t->sw_xs.release(); t->sw_psi_in.release(); t->sw_psi_out.release(); t->sw_phi.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
     t->s_el.release(); t->s_eq.release(); t->p_count.release(); t->p_flags.release(); t->p_valid.release(); t->p_rel.release();
     t->s_px.release(); t->s_py.release(); t->s_qx.release(); t->s_qy.release(); t->s_ell.release(); t->p_sum.release();
@@ -1487,6 +1759,8 @@ static rt_mesh *mesh_create_impl(int32_t device, const double *x, const double *
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->n_cus = cus;
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) m->lds_per_block = lds;
     }
     if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipStreamCreate failed");
@@ -1538,8 +1812,12 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "single_pass")) { mesh->single_pass = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "split")) { mesh->split = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "compact")) { mesh->compact = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
-    if (!strcmp(name, "topo")) { mesh->topo = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
+    if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
     if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
@@ -1737,6 +2015,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     rt::DParams prm;
     prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
     prm.topo_tiny_max = m->topo_tiny_max; prm.topo_rmax = m->topo_rmax; prm.topo_end_err = m->topo_end_err;
+    prm.topo_force = m->topo == 2 ? 1 : 0; prm.pad_ = 0;
 
     const int64_t n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
     const int64_t n_waves = (n + 63) / 64;
@@ -1744,16 +2023,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     RT_HIP(t->status.reserve(n + 1));
     RT_HIP(t->offsets.reserve(n + 1));
     RT_HIP(t->tile_sums.reserve(n_tiles + 1));
-    RT_HIP(t->ctl.reserve(32));
+    RT_HIP(t->ctl.reserve(rt::kCtlWords));
     if (!t->h_ctl) {
-        RT_HIP(hipHostMalloc((void **)&t->h_ctl, 64 * sizeof(unsigned long long), hipHostMallocDefault));
-        for (int i = 0; i < 64; ++i) t->h_ctl[i] = 0;
+        RT_HIP(hipHostMalloc((void **)&t->h_ctl, 2 * rt::kCtlWords * sizeof(unsigned long long), hipHostMallocDefault));
+        for (int i = 0; i < 2 * rt::kCtlWords; ++i) t->h_ctl[i] = 0;
         t->h_ctl[1] = ~0ull;  // first failing uid: atomicMin target
     }
     unsigned long long *const d_fail = t->ctl.p;
     int64_t *const d_total = reinterpret_cast<int64_t *>(t->ctl.p + 16);
     int32_t *const d_cursor = reinterpret_cast<int32_t *>(t->ctl.p + 18);
-    unsigned long long *const h_res = t->h_ctl + 32;
+    unsigned long long *const h_res = t->h_ctl + rt::kCtlWords;
     unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tile_sums writes it)
     RT_HIP(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
     std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
@@ -1777,13 +2056,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     const size_t hist_bytes_ = (size_t)m->n_cells * sizeof(double);
     const int fuse_waves_ = (3 * (hist_bytes_ + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || (n + 63) / 64 > 3072) ? 4 : 6;
     const bool fuse_ = m->volumes_mode == 2 && m->fuse_volumes && 2 * (hist_bytes_ + fuse_waves_ * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 && !widek_;
-    const bool plan_ok = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit;
+    // Option "compact" = 0: stop after march + scan (a device-resident consumer, rt_sweep, reads the staged rows); the separate
+    // volumes pass needs the compact records, so a call that cannot fuse fill_volumes compacts anyway.  Whole tracks only.
+    const bool do_compact = m->compact || !fuse_ || !m->single_pass;
+    const bool plan_ok = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit && do_compact;
     const bool hybrid = plan_ok && t->hybrid && fuse_;
     const bool split = plan_ok && (!t->hybrid || hybrid);  // pieces are marched in this call
     // Cheap steps (k_march<..., TOPO>): whole-track batches on meshes with cheap-step records, the usual k, fill_volumes fused.
     const bool topo = m->single_pass && m->topo && m->topo_available && m->d.walk_ok && !split && !hybrid && !widek_ && n > 0 &&
                       fuse_ && tiny_step > 0 && tiny_step <= m->topo_tiny_max && m->lds_records == 0 &&
-                      10 * m->n_records_topo >= 9 * m->n_records_walk;
+                      (m->topo == 2 || 10 * m->n_records_topo >= 9 * m->n_records_walk);
     t->last_topo = topo ? 1 : 0;
     if (split) {
         sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
@@ -1818,15 +2100,14 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         }
         return RT_SUCCESS;
     };
-    auto reserve_out = [&](int64_t tot) -> int {
-        const size_t cap = (size_t)(tot > 0 ? tot : 1);
-        RT_HIP(t->spx.reserve(cap)); RT_HIP(t->spy.reserve(cap)); RT_HIP(t->sqx.reserve(cap));
-        RT_HIP(t->sqy.reserve(cap)); RT_HIP(t->sell.reserve(cap)); RT_HIP(t->element.reserve(cap));
-        out.px = as_global(t->spx.p); out.py = as_global(t->spy.p); out.qx = as_global(t->sqx.p);
-        out.qy = as_global(t->sqy.p); out.ell = as_global(t->sell.p); out.element = as_global(t->element.p);
-        out.cap = (int64_t)std::min({t->spx.cap, t->spy.cap, t->sqx.cap, t->sqy.cap, t->sell.cap, t->element.cap});
+    auto reserve_out = [&](int64_t tot) -> int { return reserve_records(t, tot, out); };
+    // HIP events between the kernels (rt_last_timing) only on request: each costs ≈4 µs of stream time
+    auto rec = [&](int i) -> int {
+        if (m->timing) RT_HIP(hipEventRecord(t->ev[i], s));
         return RT_SUCCESS;
     };
+    t->compacted = false;
+    t->cplan = rt_tracks::CompactPlan{};
     // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
     bool fused_volumes_this_call = false;
     bool volumes_pass = true;  // false: fill_volumes rode along with the march and the scan, no ev[6]
@@ -1867,7 +2148,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         return RT_SUCCESS;
     };
     t->last_split = 0;
-    if (!m->single_pass) RT_HIP(hipEventRecord(t->ev[0], s));  // single pass: the call is timed from ev[1], after the 2-µs prologue
+    if (!m->single_pass) { if (int rc = rec(0)) return rc; }  // single pass: the call is timed from ev[1], after the 2-µs prologue
     if (!m->single_pass) RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
     if (m->single_pass) {
         // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
@@ -1905,8 +2186,9 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             // whose total exceeds it the host grows the arrays and compacts again (the staged rows are still there).
             const int64_t est_records = t->total_last > 0 ? t->total_last + t->total_last / 32 + 4096
                                                           : (int64_t)(1.08 * m->kappa * t->sum_ell) + 2 * n + 4096;
-            if (int rc = reserve_out(std::min<int64_t>(m->test_out_records > 0 && t->total_last == 0 ? m->test_out_records : est_records,
-                                                       t->pool_chunks * rt::kChunkRows * 64))) return rc;
+            if (do_compact)
+                if (int rc = reserve_out(std::min<int64_t>(m->test_out_records > 0 && t->total_last == 0 ? m->test_out_records : est_records,
+                                                           t->pool_chunks * rt::kChunkRows * 64))) return rc;
             stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
             stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
@@ -1922,13 +2204,18 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             if (hybrid) stg_pieces.ctab = stg.ctab + n_whole_waves * rt::kMaxChunks;
             rt::DTracks d_whole = t->d;
             if (hybrid) { d_whole.perm = as_global(t->perm_whole.p); d_whole.n = t->n_whole; }
+            {
+                rt_tracks::CompactPlan &c = t->cplan;
+                c.stg = stg; c.stg_pieces = stg_pieces; c.d_whole = d_whole; c.sp = sp; c.corder = corder;
+                c.n_whole_waves = n_whole_waves; c.split = split; c.split_all = split_all; c.staged = false;
+            }
             // Everything one attempt puts on the stream(s), as one function.  (Capturing it once into a HIP graph and replaying it
             // was tried: the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on
             // events that were only ever recorded inside a graph — DESIGN.md §4.)
             auto enqueue_attempt = [&]() -> int {
-                hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, 32) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
+                hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
                                    t->volumes.p, m->n_cells, stg.static0 ? (int32_t)n_whole_waves : 0);
-                RT_HIP(hipEventRecord(t->ev[1], s));
+                if (int rc = rec(1)) return rc;
                 if (n > 0 && split) {
                     hipStream_t ps = s;  // the stream the pieces march on
                     if (hybrid) {
@@ -1972,40 +2259,30 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     if (rc) return rc;
                     if (hybrid) RT_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
                 }
-                RT_HIP(hipEventRecord(t->ev[2], s));
+                if (int rc = rec(2)) return rc;
                 if (int rc = scan_counts(true, fuse)) return rc;
-                RT_HIP(hipEventRecord(t->ev[3], s));  // every event record costs ≈4 µs of stream time: none is recorded twice
-                if (n > 0 && !split_all && n_whole_waves > 0)
-                    hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_whole_waves), dim3(256), 0, s, d_whole,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp, corder);
-                if (n > 0 && split)
-                    hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp, (const int32_t *)nullptr);
-                RT_HIP(hipEventRecord(t->ev[5], s));
+                if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
+                if (do_compact) launch_compaction(t, out, s);
+                if (int rc = rec(5)) return rc;
                 if (int rc = launch_volumes()) return rc;
                 volumes_pass = !(fuse && n > 0);
-                if (volumes_pass) RT_HIP(hipEventRecord(t->ev[6], s));
+                if (volumes_pass) { if (int rc = rec(6)) return rc; }
 
                 return RT_SUCCESS;
             };
             if (int rc_enq = enqueue_attempt()) return rc_enq;
             int32_t cur[4] = {0, 0, 0, 0};
-            if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
             RT_HIP(wait_stream(s));
             memcpy(fi, h_res, sizeof(fi));
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
-            if (!cur[1] && total > out.cap) {
+            if (do_compact && !cur[1] && total > out.cap) {
                 // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
                 if (int rc = reserve_out(total + total / 32 + 4096)) return rc;
-                if (n > 0 && !split_all && n_whole_waves > 0)
-                    hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)n_whole_waves), dim3(256), 0, s, d_whole,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg, out, sp, corder);
-                if (n > 0 && split)
-                    hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
-                                       (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, stg_pieces, out, sp, (const int32_t *)nullptr);
+                launch_compaction(t, out, s);
                 if (!fused_volumes_this_call && m->volumes_mode == 2) {  // the separate volumes pass read truncated records
                     RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
                     if (int rc = launch_volumes()) return rc;
@@ -2020,47 +2297,63 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 if (int rc = launch_volumes()) return rc;
                 RT_HIP(hipStreamSynchronize(s));
             }
+            if (!cur[1] && topo && fuse && h_res[rt::kCtlRestarts] != 0) {
+                // a track whose iteration bound reached the cap was marched again with exact steps: its cheap records had
+                // already been added to the fused volumes — recompute them from the records
+                if (!do_compact) {
+                    if (int rc = reserve_out(total)) return rc;
+                    launch_compaction(t, out, s);
+                }
+                fused_volumes_this_call = false;
+                RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+                if (int rc = launch_volumes()) return rc;
+                RT_HIP(hipStreamSynchronize(s));
+                t->compacted = true;
+            }
             if (!cur[1] && split && h_res[21] != 0) {
                 t->force_unsplit = true;
                 return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
             }
-            if (!cur[1]) break;
+            if (!cur[1]) { t->cplan.staged = true; if (do_compact) t->compacted = true; break; }
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
         }
     } else {
-        RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, 32 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-        RT_HIP(hipEventRecord(t->ev[1], s));
+        RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        if (int rc = rec(1)) return rc;
         if (n > 0) {
             if (int rc = widek ? march.template operator()<rt::kCount, 1, false, true>(grid, sizeof(int32_t))
                                : march.template operator()<rt::kCount, 1, false, false>(grid, sizeof(int32_t))) return rc;
         }
-        RT_HIP(hipEventRecord(t->ev[2], s));
+        if (int rc = rec(2)) return rc;
         if (int rc = scan_counts(false, false)) return rc;
-        RT_HIP(hipEventRecord(t->ev[3], s));
-        RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        if (int rc = rec(3)) return rc;
+        RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if (m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);  // (the count march is the longer half of this mode)
         RT_HIP(hipStreamSynchronize(s));
         memcpy(fi, h_res, sizeof(fi));
         memcpy(&total, h_res + 16, sizeof(total));
         if (int rc = reserve_out(total)) return rc;
-        RT_HIP(hipEventRecord(t->ev[4], s));
+        if (int rc = rec(4)) return rc;
         if (n > 0) {
             march_offsets = t->offsets.p;
             if (int rc = widek ? march.template operator()<rt::kFill, 1, false, true>(grid, sizeof(int32_t))
                                : march.template operator()<rt::kFill, 1, false, false>(grid, sizeof(int32_t))) return rc;
         }
-        RT_HIP(hipEventRecord(t->ev[5], s));
+        if (int rc = rec(5)) return rc;
         if (int rc = launch_volumes()) return rc;
-        RT_HIP(hipEventRecord(t->ev[6], s));
+        if (int rc = rec(6)) return rc;
         RT_HIP(hipStreamSynchronize(s));
+        t->compacted = true;
     }
     RT_HIP(hipGetLastError());
-    RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 1 : 0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
-    RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
-    RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan (+ volumes ./= n_azim_2 when fused)
-    RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 3 : 4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
-    if (volumes_pass) { RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f; }   // volumes as its own pass
+    if (m->timing) {
+        RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 1 : 0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
+        RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
+        RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan (+ volumes ./= n_azim_2 when fused)
+        RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 3 : 4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
+        if (volumes_pass) { RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f; }   // volumes as its own pass
+    }
 #ifdef RT_TIMING
     if (const char *path = getenv("RT_TIMING_DUMP")) {
         if (t->dbg.p) {
@@ -2084,6 +2377,9 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     t->total_last = total;
     t->n_generic_records = (int64_t)fi[15];
     t->n_exact_walk_records = topo ? (int64_t)fi[14] : 0;
+    for (int b = 0; b < 9; ++b) t->refusals[b] = m->single_pass ? (int64_t)h_res[rt::kCtlRefusal + b] : 0;
+    t->n_near_rtol = (int64_t)h_res[rt::kCtlNearRtol];
+    t->n_restarts = m->single_pass ? (int64_t)h_res[rt::kCtlRestarts] : 0;
     t->n_failed = (int64_t)fi[0];
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
     t->first_failed_status = 0;
@@ -2119,6 +2415,7 @@ int32_t rt_fetch_segments(rt_tracks *t, double *px, double *py, double *qx, doub
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
     RT_HIP(hipSetDevice(t->mesh->device));
+    if (int rc = ensure_compacted(t)) return rc;
     const size_t nb = sizeof(double) * (size_t)t->total;
     if (t->total == 0) return RT_SUCCESS;
     if (px) RT_HIP(hipMemcpy(px, t->spx.p, nb, hipMemcpyDeviceToHost));
@@ -2159,6 +2456,7 @@ int32_t rt_fetch_segments_pinned(rt_tracks *t, void **host_ptrs) {
     if (!t || !host_ptrs) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
     RT_HIP(hipSetDevice(t->mesh->device));
+    if (int rc = ensure_compacted(t)) return rc;
     const size_t n = (size_t)t->total;
     if (n > t->pin_cap) {
         pin_release_to_cache(t);
@@ -2194,16 +2492,17 @@ int32_t rt_fetch_volumes(rt_tracks *t, double *volumes) {
 
 int32_t rt_fill_tau(rt_tracks *t, const double *sigma_t, int32_t n_groups, void **tau_dev, double *ms) {
     if (!t || !sigma_t || n_groups <= 0) { set_error("rt_fill_tau: bad arguments"); return RT_ERR_INVALID; }
+    if (n_groups > 1024) { set_error("rt_fill_tau: at most 1024 groups"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
     rt_mesh *m = t->mesh;
     RT_HIP(hipSetDevice(m->device));
+    if (int rc = ensure_compacted(t)) return rc;
     hipStream_t s = m->stream;
     const size_t n = (size_t)t->total * (size_t)n_groups;
+    t->tau_groups = 0;  // (set again once the kernel has been enqueued: a failure below leaves no τ to fetch)
     RT_HIP(t->tau.reserve(n > 0 ? n : 1));
     if (int rc = upload(t->sigma_t, sigma_t, (size_t)m->n_cells * n_groups, s)) return rc;
-    t->tau_groups = n_groups;
     RT_HIP(hipEventRecord(t->ev[0], s));
-    if (n_groups > 1024) { set_error("rt_fill_tau: at most 1024 groups"); return RT_ERR_INVALID; }
     if (n > 0) {
         const unsigned blocks = (unsigned)((t->total + rt::kTauSegs - 1) / rt::kTauSegs);
         const uint32_t inv = n_groups == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)n_groups) + 1u;  // ≥ 2^32 / G; 0 = one group
@@ -2213,6 +2512,7 @@ int32_t rt_fill_tau(rt_tracks *t, const double *sigma_t, int32_t n_groups, void 
     RT_HIP(hipEventRecord(t->ev[7], s));
     RT_HIP(hipStreamSynchronize(s));
     RT_HIP(hipGetLastError());
+    t->tau_groups = n_groups;
     if (ms) { float f = 0; RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[7])); *ms = f; }
     if (tau_dev) *tau_dev = t->tau.p;
     return RT_SUCCESS;
@@ -2227,9 +2527,169 @@ int32_t rt_fetch_tau(rt_tracks *t, double *tau) {
     return RT_SUCCESS;
 }
 
+// ---- rt_sweep -----------------------------------------------------------------------------------------------------
+static int32_t sweep_set_links_impl(rt_tracks *t, const int64_t *next_fwd, const int64_t *next_bwd, const int8_t *dir_fwd,
+                                    const int8_t *dir_bwd, const int8_t *bc_fwd, const int8_t *bc_bwd) {
+    if (!t || (t->n > 0 && (!next_fwd || !next_bwd || !dir_fwd || !dir_bwd || !bc_fwd || !bc_bwd))) { set_error("rt_sweep_set_links: null argument"); return RT_ERR_INVALID; }
+    const int64_t n = t->n;
+    if (n >= (1ll << 30)) { set_error("rt_sweep_set_links: too many tracks"); return RT_ERR_INVALID; }
+    // gather map: entry slot (direction d', track v) <- source (track u, direction d), written in the order a sequential
+    // sweep hands fluxes on (uid ascending, forward before backward): the last writer wins where links are not one-to-one
+    std::vector<int32_t> src((size_t)std::max<int64_t>(1, 2 * n), -1);
+    for (int64_t u = 0; u < n; ++u)
+        for (int d = 0; d < 2; ++d) {
+            const int64_t v = (d == 0 ? next_fwd[u] : next_bwd[u]) - 1;  // 1-based uids, as trace! links them
+            const int dn = d == 0 ? dir_fwd[u] : dir_bwd[u];             // 0 Forward, 1 Backward (src/track.jl:11-14)
+            const int bc = d == 0 ? bc_fwd[u] : bc_bwd[u];               // 0 Vacuum (src/boundary.jl:12-16)
+            if (v < 0 || v >= n || (dn != 0 && dn != 1) || bc < 0 || bc > 2) {
+                set_error("rt_sweep_set_links: track %lld has a bad link (next uid %lld, dir %d, bc %d)", (long long)(u + 1), (long long)(v + 1), dn, bc);
+                return RT_ERR_INVALID;
+            }
+            src[(size_t)dn * n + v] = bc == 0 ? -1 : (int32_t)(u * 2 + d);
+        }
+    RT_HIP(hipSetDevice(t->mesh->device));
+    if (int rc = upload(t->sw_src, src.data(), src.size(), t->mesh->stream)) return rc;
+    RT_HIP(hipStreamSynchronize(t->mesh->stream));
+    t->sw_links = true;
+    return RT_SUCCESS;
+}
+
+static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const double *source, const double *track_weight,
+                          const double *psi_in, int32_t input, double *ms) {
+    if (!t || G <= 0 || G > 4096 || input < 0 || input > 2) { set_error("rt_sweep: bad arguments"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (!t->sw_links) { set_error("rt_sweep: rt_sweep_set_links has not run"); return RT_ERR_INVALID; }
+    rt_mesh *m = t->mesh;
+    RT_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int64_t n = t->n;
+    const size_t npsi = (size_t)std::max<int64_t>(1, 2 * n * G), nphi = (size_t)m->n_cells * G;
+    if (G != t->sw_groups) {  // a new group structure: no cross sections, zero boundary flux
+        t->sw_has_xs = false; t->sw_done = false;
+        RT_HIP(t->sw_psi_in.reserve(npsi)); RT_HIP(t->sw_psi_out.reserve(npsi)); RT_HIP(t->sw_phi.reserve(nphi));
+        RT_HIP(hipMemsetAsync(t->sw_psi_in.p, 0, npsi * sizeof(double), s));
+        t->sw_groups = G;
+    }
+    if (sigma_t) {
+        std::vector<double> xs(2 * nphi);
+        for (size_t i = 0; i < nphi; ++i) {
+            const double st = sigma_t[i], q = source ? source[i] : 0.0;
+            xs[2 * i] = st;
+            xs[2 * i + 1] = st > 0.0 ? q / st : 0.0;  // (a void cell: no attenuation, no source term)
+        }
+        if (int rc = upload(t->sw_xs, xs.data(), xs.size(), s)) return rc;
+        RT_HIP(hipStreamSynchronize(s));  // the host vector dies here
+        t->sw_has_xs = true;
+    } else if (source) { set_error("rt_sweep: source given without sigma_t"); return RT_ERR_INVALID; }
+    if (!t->sw_has_xs) { set_error("rt_sweep: no cross sections yet (sigma_t is NULL)"); return RT_ERR_INVALID; }
+    if (track_weight) {
+        if (int rc = upload(t->sw_w, track_weight, (size_t)n, s)) return rc;
+        t->sw_has_w = true;
+    }
+    if (psi_in && n > 0) RT_HIP(hipMemcpyAsync(t->sw_psi_in.p, psi_in, (size_t)(2 * n * G) * sizeof(double), hipMemcpyHostToDevice, s));
+    // which records: the march's staging rows (whole-track single-pass calls leave them behind) or the compact CSR arrays
+    const bool staged_ok = t->cplan.staged && !t->cplan.split && t->cplan.n_whole_waves == (n + 63) / 64;
+    if (input == 2 && !staged_ok) { set_error("rt_sweep: the last rt_segmentize left no whole-track staging rows (track pieces or two-pass mode)"); return RT_ERR_INVALID; }
+    const bool staged = input == 2 || (input == 0 && staged_ok);
+    if (!staged)
+        if (int rc = ensure_compacted(t)) return rc;
+    using rt::as_global;
+    rt::DSweep a{};
+    a.stg = t->cplan.stg;
+    a.ell = as_global((const double *)t->sell.p); a.element = as_global((const int32_t *)t->element.p);
+    a.offsets = as_global((const int64_t *)t->offsets.p); a.counts = as_global((const int32_t *)t->counts.p);
+    a.perm = as_global((const int32_t *)t->perm.p); a.azim = as_global((const int32_t *)t->azim.p);
+    a.delta_s = as_global((const double *)t->delta_s.p);
+    a.w = t->sw_has_w ? as_global((const double *)t->sw_w.p) : nullptr;
+    a.xs = as_global((const double *)t->sw_xs.p);
+    a.psi_in = as_global((const double *)t->sw_psi_in.p); a.psi_out = as_global(t->sw_psi_out.p); a.phi = as_global(t->sw_phi.p);
+    a.n = n; a.n_waves = (int32_t)((n + 63) / 64); a.n_cells = m->n_cells; a.G = G;
+    // groups per pass: as many as an LDS-private copy of their tallies allows (4, 2 or 1); none fits: global atomics
+    const size_t lds_cap = (size_t)std::min(m->lds_per_block, 160 * 1024) - 1024;
+    int gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
+    if (m->sweep_gp == 1 || m->sweep_gp == 2 || m->sweep_gp == 4) gp = m->sweep_gp;
+    while (gp > 1 && (size_t)m->n_cells * gp * sizeof(double) > lds_cap) gp >>= 1;
+    a.use_lds = (size_t)m->n_cells * gp * sizeof(double) <= lds_cap ? 1 : 0;
+    if (!a.use_lds) gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
+    const size_t smem = a.use_lds ? (size_t)m->n_cells * gp * sizeof(double) : 0;
+    int W = smem > 79 * 1024 ? 16 : 8;  // one workgroup per CU: sixteen waves; else two or more workgroups of eight
+    if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
+    const unsigned blocks = (unsigned)((2 * (int64_t)a.n_waves + W - 1) / W);
+    RT_HIP(hipEventRecord(t->ev[0], s));
+    RT_HIP(hipMemsetAsync(t->sw_phi.p, 0, nphi * sizeof(double), s));
+    int passes = 0;
+    auto launch = [&]<bool STAGED, int GP>() -> int {
+        if (smem > 48 * 1024)
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        for (int g0 = 0; g0 < G; g0 += GP) {
+            a.g0 = g0; a.ng = std::min(GP, G - g0);
+            hipLaunchKernelGGL((rt::k_sweep<STAGED, GP>), dim3(blocks), dim3(64 * W), smem, s, a);
+            ++passes;
+        }
+        return RT_SUCCESS;
+    };
+    if (n > 0) {
+        int rc;
+        if (staged) rc = gp == 4 ? launch.template operator()<true, 4>() : (gp == 2 ? launch.template operator()<true, 2>() : launch.template operator()<true, 1>());
+        else rc = gp == 4 ? launch.template operator()<false, 4>() : (gp == 2 ? launch.template operator()<false, 2>() : launch.template operator()<false, 1>());
+        if (rc) return rc;
+        const int64_t nl = 2 * n * G;
+        hipLaunchKernelGGL(rt::k_sweep_link, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, (const int32_t *)t->sw_src.p,
+                           (const double *)t->sw_psi_out.p, t->sw_psi_in.p, 2 * n, G, n);
+    }
+    RT_HIP(hipEventRecord(t->ev[7], s));
+    RT_HIP(wait_stream(s));
+    RT_HIP(hipGetLastError());
+    if (ms) { float f = 0; RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[7])); *ms = f; }
+    t->sw_done = true;
+    t->sw_last_input = staged ? 2 : 1; t->sw_last_gp = a.use_lds ? gp : 0; t->sw_last_passes = passes;
+    return RT_SUCCESS;
+}
+
+int32_t rt_sweep_set_links(rt_tracks *t, const int64_t *next_fwd, const int64_t *next_bwd, const int8_t *dir_fwd,
+                           const int8_t *dir_bwd, const int8_t *bc_fwd, const int8_t *bc_bwd) {
+    try {
+        return sweep_set_links_impl(t, next_fwd, next_bwd, dir_fwd, dir_bwd, bc_fwd, bc_bwd);
+    } catch (const std::exception &e) {
+        set_error("rt_sweep_set_links: %s", e.what());
+        return RT_ERR_INVALID;
+    }
+}
+
+int32_t rt_sweep(rt_tracks *t, int32_t n_groups, const double *sigma_t, const double *source, const double *track_weight,
+                 const double *psi_in, int32_t input, double *ms) {
+    try {
+        return sweep_impl(t, n_groups, sigma_t, source, track_weight, psi_in, input, ms);
+    } catch (const std::exception &e) {
+        set_error("rt_sweep: %s", e.what());
+        return RT_ERR_INVALID;
+    }
+}
+
+int32_t rt_sweep_fetch(rt_tracks *t, double *phi, double *psi_out, double *psi_next) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (!t->sw_done) { set_error("rt_sweep has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    RT_HIP(hipSetDevice(t->mesh->device));
+    const size_t npsi = (size_t)(2 * t->n * t->sw_groups), nphi = (size_t)t->mesh->n_cells * t->sw_groups;
+    if (phi) RT_HIP(hipMemcpy(phi, t->sw_phi.p, nphi * sizeof(double), hipMemcpyDeviceToHost));
+    if (psi_out && npsi) RT_HIP(hipMemcpy(psi_out, t->sw_psi_out.p, npsi * sizeof(double), hipMemcpyDeviceToHost));
+    if (psi_next && npsi) RT_HIP(hipMemcpy(psi_next, t->sw_psi_in.p, npsi * sizeof(double), hipMemcpyDeviceToHost));
+    return RT_SUCCESS;
+}
+
+int32_t rt_sweep_info(rt_tracks *t, void **ptrs_dev, int32_t *info) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (!t->sw_done) { set_error("rt_sweep has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (ptrs_dev) { ptrs_dev[0] = t->sw_phi.p; ptrs_dev[1] = t->sw_psi_out.p; ptrs_dev[2] = t->sw_psi_in.p; }
+    if (info) { info[0] = t->sw_last_input; info[1] = t->sw_last_gp; info[2] = t->sw_last_passes; info[3] = t->sw_groups; }
+    return RT_SUCCESS;
+}
+
 int32_t rt_device_pointers(rt_tracks *t, void **p) {
     if (!t || !p) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    RT_HIP(hipSetDevice(t->mesh->device));
+    if (int rc = ensure_compacted(t)) return rc;
     p[0] = t->offsets.p; p[1] = t->status.p; p[2] = t->spx.p; p[3] = t->spy.p; p[4] = t->sqx.p;
     p[5] = t->sqy.p; p[6] = t->sell.p; p[7] = t->element.p; p[8] = t->volumes.p;
     return RT_SUCCESS;
@@ -2261,6 +2721,9 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 5) stats[5] = t->last_split;  // 0 whole tracks, 1 pieces, 2 hybrid (pieces for the longest waves only)
     if (n > 6) stats[6] = t->last_widek;
     if (n > 8) stats[8] = t->last_topo ? t->total - t->n_generic_records - t->n_exact_walk_records : 0;  // records made by cheap steps
+    for (int b = 0; b < 9 && 9 + b < n; ++b) stats[9 + b] = t->refusals[b];
+    if (n > 18) stats[18] = t->n_near_rtol;
+    if (n > 19) stats[19] = t->n_restarts;
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
         stats[7] = b(t->px) + b(t->py) + b(t->phi) + b(t->cs) + b(t->sn) + b(t->A) + b(t->B) + b(t->C) + b(t->ell) + b(t->azim) + b(t->perm) +

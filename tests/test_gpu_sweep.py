@@ -1,0 +1,139 @@
+"""rt_sweep — the device-side consumer that walks the cyclic tracks — against a sequential numpy sweep
+over the ORACLE's records (tests/sweep_ref.py).  Both inputs are covered: the compact CSR records and the march's staging
+rows read directly (option "compact" = 0: march + scan + sweep, no compaction).  Tolerance 1e-12 relative to the largest
+value of each array: the device's expm1 and numpy's differ in the last ulp, and the tallies add in a different order."""
+import numpy as np
+import pytest
+
+import sweep_ref
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def _close(a, b, what):
+    scale = max(float(np.abs(b).max()), 1e-300)
+    err = float(np.abs(a - b).max()) / scale
+    assert err <= RTOL, (what, err)
+    return err
+
+
+def _problem(rt, tg, G, seed):
+    rng = np.random.default_rng(seed)
+    nc = tg.mesh.num_cells
+    sigma_t = rng.uniform(0.05, 3.0, (nc, G))
+    source = rng.uniform(0.0, 2.0, (nc, G))
+    aq = tg.azimuthal_quadrature
+    weight = aq.delta_s[tg.azim_idx - 1] * aq.omega_a[tg.azim_idx - 1]
+    psi_in = rng.uniform(0.0, 1.5, (2, tg.n_total_tracks, G))
+    return sigma_t, source, weight, psi_in
+
+
+def _links(tg):
+    return (tg.next_fwd_uid, tg.next_bwd_uid, tg.dir_next_fwd, tg.dir_next_bwd, tg.bc_fwd, tg.bc_bwd)
+
+
+def _bcs(rt, kind):
+    B = rt.BoundaryConditions
+    if kind == "reflective":
+        return B(top=rt.Reflective, bottom=rt.Reflective, left=rt.Reflective, right=rt.Reflective)
+    if kind == "periodic":
+        return B(top=rt.Periodic, bottom=rt.Periodic, left=rt.Periodic, right=rt.Periodic)
+    if kind == "vacuum":
+        return B(top=rt.Vacuum, bottom=rt.Vacuum, left=rt.Vacuum, right=rt.Vacuum)
+    return B(top=rt.Vacuum, bottom=rt.Reflective, left=rt.Periodic, right=rt.Periodic)  # mixed
+
+
+def _device(rt, tg, compact, **opts):
+    from raytracing_jl_amd import _capi
+
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("compact", compact)
+    for k, v in opts.items():
+        dm.set_option(k, v)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    dt.sweep_set_links(tg)
+    return dm, dt
+
+
+CASES = [("pincell.json", 32, 5e-3, "reflective", 7), ("pincell.json", 32, 5e-3, "vacuum", 2), ("pincell.json", 32, 5e-3, "periodic", 1),
+         ("bwr_like.msh", 16, 0.02, "reflective", 7), ("bwr_like.msh", 16, 0.02, "mixed", 3)]
+
+
+@pytest.mark.parametrize("mesh,n_azim,delta,bc,G", CASES)
+def test_sweep_matches_sequential_sweep_over_oracle_records(rt, orc, mesh, n_azim, delta, bc, G):
+    path = rt.data_path(mesh)
+    model = rt.GmshDiscreteModel(path) if mesh.endswith(".msh") else rt.DiscreteModelFromFile(path)
+    tg = rt.TrackGenerator(model, n_azim, delta, bcs=_bcs(rt, bc))
+    rt.trace(tg)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                        tiny_step=tg.tiny_step, n_threads=0)
+    sigma_t, source, weight, psi_in = _problem(rt, tg, G, 7)
+    phi1, out1 = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, weight, psi_in)
+    nxt1 = sweep_ref.link(out1, *_links(tg))
+    phi2, out2 = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, weight, nxt1)  # second iteration
+    if bc == "vacuum":
+        assert not nxt1.any()
+    for compact, inp in ((1, "compact"), (0, "staged"), (1, "staged"), (0, "compact")):
+        dm, dt = _device(rt, tg, compact)
+        r = dt.sweep(G, sigma_t, source, weight, psi_in, input=inp)
+        assert r["input"] == inp
+        e = [_close(r["phi"], phi1, "phi"), _close(r["psi_out"], out1, "psi_out"), _close(r["psi_next"], nxt1, "psi_next")]
+        r2 = dt.sweep(G)  # everything from the device: cross sections, weights, the boundary flux handed on
+        e += [_close(r2["phi"], phi2, "phi, 2nd sweep"), _close(r2["psi_out"], out2, "psi_out, 2nd sweep")]
+        if compact == 0:
+            # the records were never compacted for the sweep; asking for them now produces them, equal to the oracle's
+            s = dt.fetch_segments()
+            assert np.array_equal(s["element"], ref["element"]) and all(np.array_equal(s[k], ref[k]) for k in ("px", "py", "qx", "qy", "ell"))
+        print(f"{mesh} nφ={n_azim} {bc} G={G} compact={compact} input={inp}: {r['passes']} passes of {r['groups_per_pass']} groups, "
+              f"{r['ms']:.3f} ms, max rel err {max(e):.1e}")
+        dt.close(); dm.close()
+
+
+def test_sweep_default_weight_and_group_slabs(rt, orc, traced, oracle_run):
+    """Default weights are fill_volumes' δs[azim_idx]; 1, 2 and 4 groups per pass (and global atomics) give the same tallies."""
+    tg = traced(16, 1e-2)
+    ref = oracle_run(tg)
+    G = 5
+    sigma_t, source, _, psi_in = _problem(rt, tg, G, 11)
+    aq = tg.azimuthal_quadrature
+    phi, out = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, aq.delta_s[tg.azim_idx - 1], psi_in)
+    for gp in (0, 1, 2, 4):
+        for waves in (0, 4):
+            dm, dt = _device(rt, tg, 0, sweep_gp=gp, sweep_waves=waves)
+            r = dt.sweep(G, sigma_t, source, None, psi_in)
+            assert r["input"] == "staged" and (gp == 0 or r["groups_per_pass"] == gp)
+            _close(r["phi"], phi, f"phi gp={gp}"); _close(r["psi_out"], out, f"psi_out gp={gp}")
+            dt.close(); dm.close()
+
+
+def test_sweep_argument_errors(rt, traced):
+    from raytracing_jl_amd import _capi
+
+    tg = traced(8, 2e-2)
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    aq = tg.azimuthal_quadrature
+    sig = np.ones((tg.mesh.num_cells, 2))
+    with pytest.raises(_capi.RtError, match="rt_segmentize has not run"):
+        dt.sweep(2, sig)
+    dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)  # a small batch: marched in pieces by default
+    with pytest.raises(_capi.RtError, match="rt_sweep_set_links"):
+        dt.sweep(2, sig)
+    dt.sweep_set_links(tg)
+    with pytest.raises(_capi.RtError, match="cross sections"):
+        dt.sweep(2)
+    assert dt.stats()["split"] == 1
+    with pytest.raises(_capi.RtError, match="staging rows"):
+        dt.sweep(2, sig, input="staged")
+    assert dt.sweep(2, sig)["input"] == "compact"
+    bad = dict(next_fwd=tg.next_fwd_uid.copy(), next_bwd=tg.next_bwd_uid, dir_fwd=tg.dir_next_fwd, dir_bwd=tg.dir_next_bwd,
+               bc_fwd=tg.bc_fwd, bc_bwd=tg.bc_bwd)
+    bad["next_fwd"][3] = tg.n_total_tracks + 1
+    with pytest.raises(_capi.RtError, match="bad link"):
+        dt.sweep_set_links(bad)
+    dt.close(); dm.close()

@@ -79,7 +79,15 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
     _same(off, ref, "walk off")
     _same(cheap, ref, "walk on, cheap steps")
     _same(_run(rt, tg, True, split=-1, cheap=1), ref, "walk on, default splitting")
+    # forced cheap steps (option "topo" = 2): no 90 % gate, no hand-back of often-refused waves — every record that carries
+    # a cheap certificate is decided by it, on every mesh class
+    forced = _run(rt, tg, True, cheap=2)
+    _same(forced, ref, "walk on, cheap steps forced")
     info = on["info"]
+    if info["records_cheap"] > 0 and info["walk_enabled"] and tg.tiny_step <= info["cheap_tiny_max"]:
+        assert forced["stats"]["cheap_records"] >= cheap["stats"]["cheap_records"], (forced["stats"], cheap["stats"])
+        assert forced["stats"]["cheap_records"] > 0 or ref["total"] < 200, (info, forced["stats"])
+    assert all(v >= 0 for v in forced["stats"]["cheap_refusals"].values())
     assert off["info"]["walk_enabled"] == 0 and off["stats"]["walk_records"] == 0
     assert on["stats"]["cheap_records"] == 0 and off["stats"]["cheap_records"] == 0
     assert cheap["stats"]["cheap_records"] <= cheap["stats"]["walk_records"] == on["stats"]["walk_records"]
@@ -102,4 +110,6 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
     print(f"{kind} seed {seed}: {model.num_cells} cells nφ={n_azim} {ref['total']} segments | regime: walk on, "
           f"{info['records_walk']}/{info['records']} records walkable, eps ≤ {info['eps_max']:.1e}, fragile {info['cells_fragile']}, "
           f"{frac:.1%} of the records by the walk step, {cheap['stats']['cheap_records'] / max(ref['total'], 1):.1%} by cheap steps "
-          f"({info['records_cheap']} records) | {int(np.count_nonzero(ref['status']))} tracks on which the reference throws")
+          f"({info['records_cheap']} records; forced: {forced['stats']['cheap_records'] / max(ref['total'], 1):.1%}, refusals "
+          f"{ {k: v for k, v in forced['stats']['cheap_refusals'].items() if v} }) | "
+          f"{int(np.count_nonzero(ref['status']))} tracks on which the reference throws")

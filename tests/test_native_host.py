@@ -125,3 +125,25 @@ def test_native_msh_errors(capi, tmp_path):
     bad.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n")
     with pytest.raises(capi.RtError, match="4.1"):
         capi.native_load_msh(str(bad))
+
+
+def test_native_msh_with_more_entity_blocks_than_nodes(rt, capi, tmp_path):
+    """gmsh writes a block for every entity, also those without nodes ("1 1 0 0": a curve with no interior node), so a coarse
+    mesh has more entity blocks than nodes — a 5-node, 4-triangle square with 9 blocks loads like it does in the Python reader."""
+    msh = tmp_path / "coarse.msh"
+    msh.write_text(
+        "$MeshFormat\n4.1 0 8\n$EndMeshFormat\n"
+        "$Nodes\n9 5 1 5\n"
+        "0 1 0 1\n1\n0 0 0\n0 2 0 1\n2\n1 0 0\n0 3 0 1\n3\n1 1 0\n0 4 0 1\n4\n0 1 0\n"
+        "1 1 0 0\n1 2 0 0\n1 3 0 0\n1 4 0 0\n"
+        "2 1 0 1\n5\n0.5 0.5 0\n"
+        "$EndNodes\n"
+        "$Elements\n5 8 1 8\n"
+        "1 1 1 1\n1 1 2\n1 2 1 1\n2 2 3\n1 3 1 1\n3 3 4\n1 4 1 1\n4 4 1\n"
+        "2 1 2 4\n5 1 2 5\n6 2 3 5\n7 3 4 5\n8 4 1 5\n"
+        "$EndElements\n")
+    x, y, cells, ptrs, data, bb = capi.native_load_msh(str(msh))
+    py = rt.Mesh(rt.GmshDiscreteModel(str(msh)))
+    assert len(x) == 5 and len(cells) == 4
+    assert np.array_equal(x, py.x) and np.array_equal(y, py.y) and np.array_equal(cells, py.cell_nodes)
+    assert np.array_equal(ptrs, py.node_cells_ptrs) and np.array_equal(data, py.node_cells_data)

@@ -1,0 +1,40 @@
+"""The sequential sweep that checks rt_sweep (tests/sweep_ref.py), on the CPU: properties a transport sweep must have,
+evaluated over the oracle's records — so the checker itself is pinned before the GPU tests lean on it."""
+import numpy as np
+
+import sweep_ref
+
+
+def test_flat_source_equilibrium_and_pure_absorber(rt, traced, oracle_run):
+    tg = traced(8, 2e-2)
+    ref = oracle_run(tg)
+    nc, n, G = tg.mesh.num_cells, tg.n_total_tracks, 3
+    rng = np.random.default_rng(3)
+    sigma_t = rng.uniform(0.1, 2.0, (nc, G))
+    w = np.ones(n)
+    # ψ = q/Σt everywhere is the fixed point: nothing is attenuated, nothing is tallied
+    level = np.array([0.5, 1.0, 2.0])
+    phi, out = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, sigma_t * level, w, np.broadcast_to(level, (2, n, G)))
+    assert np.allclose(out, level, rtol=1e-13) and np.abs(phi).max() < 1e-12
+    # no source, one group, uniform Σt: ψ_out = ψ_in·exp(−Σt·Σℓ) and the tally is what was absorbed
+    st = np.full((nc, 1), 0.7)
+    psi_in = rng.uniform(0.5, 1.5, (2, n, 1))
+    phi, out = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], st, np.zeros((nc, 1)), w, psi_in)
+    sum_ell = np.add.reduceat(ref["ell"], ref["offsets"][:-1])
+    assert np.allclose(out[:, :, 0], psi_in[:, :, 0] * np.exp(-0.7 * sum_ell), rtol=1e-12)
+    assert np.isclose(phi.sum(), (psi_in - out).sum(), rtol=1e-12)
+
+
+def test_linking_is_a_permutation_for_reflective_and_zero_for_vacuum(rt, pincell):
+    for kind, bcs in (("reflective", rt.BoundaryConditions(top=rt.Reflective, bottom=rt.Reflective, left=rt.Reflective, right=rt.Reflective)),
+                      ("periodic", rt.BoundaryConditions(top=rt.Periodic, bottom=rt.Periodic, left=rt.Periodic, right=rt.Periodic)),
+                      ("vacuum", rt.BoundaryConditions(top=rt.Vacuum, bottom=rt.Vacuum, left=rt.Vacuum, right=rt.Vacuum))):
+        tg = rt.TrackGenerator(pincell, 8, 2e-2, bcs=bcs)
+        rt.trace(tg)
+        n = tg.n_total_tracks
+        out = np.arange(1, 2 * n + 1, dtype=np.float64).reshape(2, n, 1)
+        nxt = sweep_ref.link(out, tg.next_fwd_uid, tg.next_bwd_uid, tg.dir_next_fwd, tg.dir_next_bwd, tg.bc_fwd, tg.bc_bwd)
+        if kind == "vacuum":
+            assert not nxt.any()
+        else:  # every entry receives exactly one outgoing flux (the tracks form closed cycles, src/track.jl:36-38)
+            assert np.array_equal(np.sort(nxt.ravel()), out.ravel())

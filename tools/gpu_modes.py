@@ -13,6 +13,7 @@ model = rt.GmshDiscreteModel(rt.data_path(mesh)) if mesh.endswith(".msh") else r
 tg = rt.TrackGenerator(model, na, d); rt.trace(tg)
 aq = tg.azimuthal_quadrature
 dm = _capi.DeviceMesh(tg.mesh, 0)
+dm.set_option("timing", 1)  # HIP events between the kernels (off by default)
 dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
 names = [o.split("=")[0] for o in opts]
 vals = [[int(v) for v in o.split("=")[1].split(",")] for o in opts]

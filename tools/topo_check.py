@@ -28,6 +28,7 @@ res = {}
 for topo in (0, 1):
     dm = _capi.DeviceMesh(tg.mesh, 0)
     dm.set_option("topo", topo)
+    dm.set_option("timing", 1)
     for n, v in extra:
         dm.set_option(n, int(v))
     dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
