@@ -1215,19 +1215,29 @@ struct DSweep {
     RT_G double *phi;                 // [n_cells * G] tallies
     int64_t n;
     int32_t n_waves, n_cells, G, g0, ng, use_lds;
+    int32_t debug;  // development: bit 0 skip the tallies
 };
 
-template <bool STAGED, int GP>
+// Software pipeline (the row addresses do not depend on data, unlike the march's): in iteration t the rows of step t + 2 and
+// the cross sections of step t + 1 are in flight while step t is evaluated; every load is unconditional (clamped indices,
+// results masked) so that no wait is forced by a branch, and the one rare load inside a branch — the staged entry point of a
+// marked record — is issued BEFORE the iteration's prefetches: gfx950 returns loads in order, so waiting for it leaves the
+// prefetches in flight.  The wave's chunk ids sit in registers (lane j holds chunk j) and are read with v_readlane.
+template <bool STAGED, int GP, bool LDS>
 __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sweep_smem[];
-    double *hist = reinterpret_cast<double *>(sweep_smem);  // [n_cells * GP] when use_lds
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, W = blockDim.x >> 6;
-    if (a.use_lds) {
+    double *hist = reinterpret_cast<double *>(sweep_smem);  // [n_cells * GP] when LDS
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and known to be
+    if (LDS) {
         for (int c = threadIdx.x; c < a.n_cells * GP; c += blockDim.x) hist[c] = 0.0;
         __syncthreads();
     }
-    // a sweep wave = (march wave, direction): the two directions of the same 64 tracks sit next to each other in a workgroup
-    const int64_t sw = (int64_t)blockIdx.x * W + wib;
+    // a sweep wave = (march wave, direction).  The march waves are ordered longest first and the sweep is bound by
+    // instruction issue, so the waves are dealt to the workgroups round-robin: wave k of workgroup b takes sweep wave
+    // k * gridDim + b — every workgroup gets the same mix of long and short tracks and all finish together (contiguous
+    // blocks of 16 sweep waves left the CU with the longest tracks working 1.6x longer than the average one).
+    const int64_t sw = (int64_t)wib * gridDim.x + blockIdx.x;
     const int64_t mw = sw >> 1;
     const int dir = (int)(sw & 1);
     if (mw < a.n_waves) {
@@ -1235,103 +1245,152 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
         const bool have = slot < a.n;
         const int32_t u = have ? a.perm[slot] : 0;
         const int32_t cnt = have ? a.counts[u] : 0;
-        int32_t maxcnt = cnt;
+        int32_t mc = cnt;
         for (int o = 32; o > 0; o >>= 1) {
-            const int32_t v = __shfl_xor(maxcnt, o, 64);
-            maxcnt = v > maxcnt ? v : maxcnt;
+            const int32_t v = __shfl_xor(mc, o, 64);
+            mc = v > mc ? v : mc;
         }
+        const int maxcnt = __builtin_amdgcn_readfirstlane(mc);
         const double w = !have ? 0.0 : (a.w ? a.w[u] : a.delta_s[a.azim[u] - 1]);
         const int64_t off = (!STAGED && have) ? a.offsets[u] : 0;
         const int64_t pbase = ((int64_t)dir * a.n + u) * a.G + a.g0;
+        const int ng = a.ng;
         double psi[GP];
 #pragma unroll
-        for (int g = 0; g < GP; ++g) psi[g] = (have && g < a.ng) ? a.psi_in[pbase + g] : 0.0;
-        const RT_G int32_t *ctab = a.stg.ctab + mw * kMaxChunks;
-        // one segment: attenuation and tally for the GP groups of this pass
-        auto segment = [&](const int32_t e, const double ell, const bool act) {
-            const RT_G double *x = a.xs + ((int64_t)(act ? e : 0) * a.G + a.g0) * 2;
+        for (int g = 0; g < GP; ++g) psi[g] = (have && g < ng) ? a.psi_in[pbase + g] : 0.0;
+        // step t visits row r(t): 0, 1, ... forward; maxcnt-1, ..., 0 backward (demo/makie.jl:103: "the segments are stored in
+        // reverse order for backward tracks"), all lanes in lockstep — a lane is active while r(t) < its count.  Steps beyond
+        // the end are clamped to the last one (prefetches only).
+        auto row_of = [&](const int t) -> int {
+            const int tc = t < maxcnt ? t : maxcnt - 1;
+            return dir ? maxcnt - 1 - tc : tc;
+        };
+        // cross sections of GP groups of cell `e` (a padded group repeats the last real one; its result is never used)
+        auto load_xs = [&](const int32_t e, double (&st)[GP], double (&qs)[GP]) {
+            const RT_G double *x = a.xs + ((int64_t)e * a.G + a.g0) * 2;
 #pragma unroll
             for (int g = 0; g < GP; ++g) {
-                if (g < a.ng) {  // (uniform)
-                    const double st = x[2 * g], qs = x[2 * g + 1];
-                    const double tau = st * ell;
-                    const double ex = -expm1(-tau);
-                    const double d = (psi[g] - qs) * ex;
-                    if (act) {
-                        psi[g] = psi[g] - d;
-                        if (a.use_lds) atomicAdd(&hist[e * GP + g], w * d);
-                        else unsafeAtomicAdd((double *)&a.phi[(int64_t)e * a.G + a.g0 + g], w * d);
-                    }
-                }
+                const int gi = g < ng ? g : ng - 1;
+                st[g] = x[2 * gi]; qs[g] = x[2 * gi + 1];
             }
         };
-        if (STAGED) {
-            // row r of this wave: chunk ctab[r >> 5] (wave-uniform), slot (row, lane) inside it; q and ±cell of every record,
-            // p only for marked records (cell < 0: first record of a track, records of the generic step)
-            struct Row { double qx, qy; int32_t el; };
-            auto load_row = [&](const int r, const bool on) -> Row {
-                Row R{0.0, 0.0, 1};
-                if (on) {
-                    const int64_t sl = stage_slot(ctab[r >> kChunkLog2], r & (kChunkRows - 1), lane);
-                    R.qx = a.stg.qx[sl]; R.qy = a.stg.qy[sl]; R.el = a.stg.element[sl];
-                }
-                return R;
-            };
-            if (dir == 0) {
-                Row nxt = load_row(0, 0 < cnt);
-                double lqx = 0.0, lqy = 0.0;
-                for (int i = 0; i < maxcnt; ++i) {
-                    const Row cur = nxt;
-                    const bool act = i < cnt;
-                    nxt = load_row(i + 1, i + 1 < cnt);  // in flight while this row is evaluated
-                    double px = lqx, py = lqy;
-                    if (act && cur.el < 0) {
-                        const int64_t sl = stage_slot(ctab[i >> kChunkLog2], i & (kChunkRows - 1), lane);
-                        px = a.stg.px[sl]; py = a.stg.py[sl];
+        // one segment: attenuation and tally for the GP groups of this pass
+        auto segment = [&](const int32_t e, const double ell, const bool act, const double (&st)[GP], const double (&qs)[GP]) {
+            double wd[GP];
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const double tau = st[g] * ell;
+                const double ex = -expm1(-tau);
+                const double d = (psi[g] - qs[g]) * ex;
+                psi[g] = act ? psi[g] - d : psi[g];
+                wd[g] = w * d;
+            }
+            // Neighbouring lanes are neighbouring parallel tracks: at the same row most of them are in the same cell, and
+            // atomics of one wave instruction to one address are served one lane at a time (measured: the tallies were 40 %
+            // of the sweep).  Lanes of an aligned group of 2, 4, 8, 16 with equal cells are therefore summed first — four DPP
+            // row shifts, no LDS traffic — and only the lanes left over add to the tally.
+            bool mine = act;
+            if (!(a.debug & 2)) {
+                const int32_t key = act ? e : -1 - lane;  // (an inactive lane matches nobody)
+                // lane l with (l mod 2n) == 0 takes over lane l + n (row_shl:n reads lane l + n of the 16-lane row)
+                auto fold = [&]<int NSH>() {
+                    const int32_t key_up = __builtin_amdgcn_update_dpp(-1, key, 0x100 + NSH, 0xf, 0xf, false);
+                    const int32_t key_dn = __builtin_amdgcn_update_dpp(-1, key, 0x110 + NSH, 0xf, 0xf, false);
+                    const bool take = ((lane & (2 * NSH - 1)) == 0) && key_up == key;
+                    const bool given = ((lane & (2 * NSH - 1)) == NSH) && key_dn == key;
+#pragma unroll
+                    for (int g = 0; g < GP; ++g) {
+                        const uint64_t bits = __builtin_bit_cast(uint64_t, wd[g]);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)bits, 0x100 + NSH, 0xf, 0xf, false);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)(bits >> 32), 0x100 + NSH, 0xf, 0xf, false);
+                        const double up = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+                        wd[g] = __builtin_fma(up, take ? 1.0 : 0.0, wd[g]);  // (one instruction; the values are finite)
                     }
-                    const double ell = norm2(px - cur.qx, py - cur.qy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
-                    segment((cur.el < 0 ? -cur.el : cur.el) - 1, ell, act);
-                    lqx = cur.qx; lqy = cur.qy;
+                    mine = mine && !given;
+                };
+                fold.template operator()<1>(); fold.template operator()<2>(); fold.template operator()<4>(); fold.template operator()<8>();
+            }
+            if (mine && !(a.debug & 1)) {
+#pragma unroll
+                for (int g = 0; g < GP; ++g)
+                    if (g < ng) {  // (uniform)
+                        if (LDS) atomicAdd(&hist[e * GP + g], wd[g]);
+                        else unsafeAtomicAdd((double *)&a.phi[(int64_t)e * a.G + a.g0 + g], wd[g]);
+                    }
+            }
+        };
+        if (maxcnt > 0) {
+            if (STAGED) {
+                // the wave's chunk ids: lane j holds chunks j, j + 64, ... (kMaxChunks = 313: five registers cover MAX_ITER rows)
+                const RT_G int32_t *ctab = a.stg.ctab + mw * kMaxChunks;
+                const int nchunks = (maxcnt + kChunkRows - 1) >> kChunkLog2;
+                int32_t cv[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) cv[k] = (k * 64 + lane < nchunks) ? ctab[k * 64 + lane] : 0;
+                // (v_readlane reads a lane whether or not it is active: call this in wave-uniform control flow only — inside a
+                //  divergent branch the selected register of an inactive holder lane is stale)
+                auto chunk_of = [&](const int r) -> int32_t {
+                    const int j = r >> kChunkLog2;
+                    const int32_t v = j < 64 ? cv[0] : (j < 128 ? cv[1] : (j < 192 ? cv[2] : (j < 256 ? cv[3] : cv[4])));
+                    return __builtin_amdgcn_readlane(v, j & 63);
+                };
+                struct Row { double qx, qy; int32_t el; };
+                auto slot_of = [&](const int r) -> int64_t { return stage_slot(chunk_of(r), r & (kChunkRows - 1), lane); };
+                auto load_row = [&](const int r) -> Row {
+                    const int64_t sl = slot_of(r);
+                    return Row{a.stg.qx[sl], a.stg.qy[sl], a.stg.element[sl]};
+                };
+                auto cell_of = [&](const Row &R, const int r) -> int32_t { return r < cnt ? (R.el < 0 ? -R.el : R.el) - 1 : 0; };
+                Row R0 = load_row(row_of(0)), R1 = load_row(row_of(1));
+                double st0[GP], qs0[GP];
+                load_xs(cell_of(R0, row_of(0)), st0, qs0);
+                double lqx = 0.0, lqy = 0.0;  // forward: q of the previous row
+                for (int t = 0; t < maxcnt; ++t) {
+                    const int r = row_of(t);
+                    const bool act = r < cnt;
+                    // entry point: staged for marked records (cell < 0: first record of a track, records of the generic step),
+                    // else the previous record's exit point — forward the row before, backward the NEXT step's row
+                    double px = dir ? R1.qx : lqx, py = dir ? R1.qy : lqy;
+                    const int64_t sl0 = slot_of(r);  // (outside the branch: see chunk_of)
+                    if (act && R0.el < 0) { px = a.stg.px[sl0]; py = a.stg.py[sl0]; }
+                    const Row R2 = load_row(row_of(t + 2));
+                    double st1[GP], qs1[GP];
+                    load_xs(cell_of(R1, row_of(t + 1)), st1, qs1);
+                    const double ell = norm2(px - R0.qx, py - R0.qy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
+                    segment(cell_of(R0, r), ell, act, st0, qs0);
+                    lqx = R0.qx; lqy = R0.qy;
+                    R0 = R1; R1 = R2;
+#pragma unroll
+                    for (int g = 0; g < GP; ++g) { st0[g] = st1[g]; qs0[g] = qs1[g]; }
                 }
             } else {
-                // reversed order (demo/makie.jl:103: "the segments are stored in reverse order for backward tracks"): rows
-                // maxcnt-1 .. 0 in lockstep, a lane joins at its own last row; p of row i is q of row i - 1
-                Row nxt = load_row(maxcnt - 1, maxcnt - 1 < cnt);
-                for (int i = maxcnt - 1; i >= 0; --i) {
-                    const Row cur = nxt;
-                    const bool act = i < cnt;
-                    nxt = load_row(i - 1, i >= 1 && i - 1 < cnt);
-                    double px = nxt.qx, py = nxt.qy;
-                    if (act && cur.el < 0) {
-                        const int64_t sl = stage_slot(ctab[i >> kChunkLog2], i & (kChunkRows - 1), lane);
-                        px = a.stg.px[sl]; py = a.stg.py[sl];
-                    }
-                    const double ell = norm2(px - cur.qx, py - cur.qy);
-                    segment((cur.el < 0 ? -cur.el : cur.el) - 1, ell, act);
+                struct Rec { double ell; int32_t el; };
+                auto load_rec = [&](const int r) -> Rec {
+                    const int rc = r < cnt ? r : (cnt > 0 ? cnt - 1 : 0);  // (a lane's own records only; masked where r >= cnt)
+                    return Rec{a.ell[off + rc], a.element[off + rc]};
+                };
+                auto cell_of = [&](const Rec &R, const int r) -> int32_t { return r < cnt ? R.el - 1 : 0; };
+                Rec R0 = load_rec(row_of(0)), R1 = load_rec(row_of(1));
+                double st0[GP], qs0[GP];
+                load_xs(cell_of(R0, row_of(0)), st0, qs0);
+                for (int t = 0; t < maxcnt; ++t) {
+                    const int r = row_of(t);
+                    const Rec R2 = load_rec(row_of(t + 2));
+                    double st1[GP], qs1[GP];
+                    load_xs(cell_of(R1, row_of(t + 1)), st1, qs1);
+                    segment(cell_of(R0, r), R0.ell, r < cnt, st0, qs0);
+                    R0 = R1; R1 = R2;
+#pragma unroll
+                    for (int g = 0; g < GP; ++g) { st0[g] = st1[g]; qs0[g] = qs1[g]; }
                 }
-            }
-        } else {
-            auto load_rec = [&](const int r, const bool on, double &ell, int32_t &el) {
-                ell = 0.0; el = 1;
-                if (on) { ell = a.ell[off + r]; el = a.element[off + r]; }
-            };
-            double ell_n; int32_t el_n;
-            const int r0 = dir == 0 ? 0 : maxcnt - 1, step = dir == 0 ? 1 : -1;
-            load_rec(r0, r0 < cnt, ell_n, el_n);
-            for (int t = 0, i = r0; t < maxcnt; ++t, i += step) {
-                const double ell = ell_n; const int32_t el = el_n;
-                const bool act = i < cnt;
-                const int j = i + step;
-                load_rec(j, j >= 0 && j < cnt, ell_n, el_n);
-                segment(el - 1, ell, act);
             }
         }
         if (have)
 #pragma unroll
             for (int g = 0; g < GP; ++g)
-                if (g < a.ng) a.psi_out[pbase + g] = psi[g];
+                if (g < ng) a.psi_out[pbase + g] = psi[g];
     }
-    if (a.use_lds) {
+    if (LDS) {
         __syncthreads();
         for (int c = threadIdx.x; c < a.n_cells * GP; c += blockDim.x) {
             const double v = hist[c];
@@ -1388,6 +1447,7 @@ struct rt_mesh {
     int n_cus = 256;
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
+    int sweep_debug = 0;
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
                            // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is
                            // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
@@ -1815,6 +1875,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "compact")) { mesh->compact = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }
@@ -2603,7 +2664,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     a.w = t->sw_has_w ? as_global((const double *)t->sw_w.p) : nullptr;
     a.xs = as_global((const double *)t->sw_xs.p);
     a.psi_in = as_global((const double *)t->sw_psi_in.p); a.psi_out = as_global(t->sw_psi_out.p); a.phi = as_global(t->sw_phi.p);
-    a.n = n; a.n_waves = (int32_t)((n + 63) / 64); a.n_cells = m->n_cells; a.G = G;
+    a.n = n; a.n_waves = (int32_t)((n + 63) / 64); a.n_cells = m->n_cells; a.G = G; a.debug = m->sweep_debug;
     // groups per pass: as many as an LDS-private copy of their tallies allows (4, 2 or 1); none fits: global atomics
     const size_t lds_cap = (size_t)std::min(m->lds_per_block, 160 * 1024) - 1024;
     int gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
@@ -2611,6 +2672,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     while (gp > 1 && (size_t)m->n_cells * gp * sizeof(double) > lds_cap) gp >>= 1;
     a.use_lds = (size_t)m->n_cells * gp * sizeof(double) <= lds_cap ? 1 : 0;
     if (!a.use_lds) gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
+    if (m->sweep_gp >= 8) a.use_lds = 0;  // experiment: tallies straight to HBM (measured 4x slower at C3: 2.1 ms against 0.48)
     const size_t smem = a.use_lds ? (size_t)m->n_cells * gp * sizeof(double) : 0;
     int W = smem > 79 * 1024 ? 16 : 8;  // one workgroup per CU: sixteen waves; else two or more workgroups of eight
     if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
@@ -2618,20 +2680,23 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     RT_HIP(hipEventRecord(t->ev[0], s));
     RT_HIP(hipMemsetAsync(t->sw_phi.p, 0, nphi * sizeof(double), s));
     int passes = 0;
-    auto launch = [&]<bool STAGED, int GP>() -> int {
+    auto launch = [&]<bool STAGED, int GP, bool LDS>() -> int {
         if (smem > 48 * 1024)
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         for (int g0 = 0; g0 < G; g0 += GP) {
             a.g0 = g0; a.ng = std::min(GP, G - g0);
-            hipLaunchKernelGGL((rt::k_sweep<STAGED, GP>), dim3(blocks), dim3(64 * W), smem, s, a);
+            hipLaunchKernelGGL((rt::k_sweep<STAGED, GP, LDS>), dim3(blocks), dim3(64 * W), smem, s, a);
             ++passes;
         }
         return RT_SUCCESS;
     };
+    auto launch_gp = [&]<bool STAGED, bool LDS>() -> int {
+        return gp == 4 ? launch.template operator()<STAGED, 4, LDS>() : (gp == 2 ? launch.template operator()<STAGED, 2, LDS>() : launch.template operator()<STAGED, 1, LDS>());
+    };
     if (n > 0) {
         int rc;
-        if (staged) rc = gp == 4 ? launch.template operator()<true, 4>() : (gp == 2 ? launch.template operator()<true, 2>() : launch.template operator()<true, 1>());
-        else rc = gp == 4 ? launch.template operator()<false, 4>() : (gp == 2 ? launch.template operator()<false, 2>() : launch.template operator()<false, 1>());
+        if (staged) rc = a.use_lds ? launch_gp.template operator()<true, true>() : launch_gp.template operator()<true, false>();
+        else rc = a.use_lds ? launch_gp.template operator()<false, true>() : launch_gp.template operator()<false, false>();
         if (rc) return rc;
         const int64_t nl = 2 * n * G;
         hipLaunchKernelGGL(rt::k_sweep_link, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, (const int32_t *)t->sw_src.p,
