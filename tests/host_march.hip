@@ -296,4 +296,29 @@ int32_t hostmarch_prep(const double *x, const double *y, int32_t n_nodes, const 
     return 0;
 }
 
+// bf16_up / bf16_value of the preprocessing (the cheap step's four per-record constants are stored as bfloat16 rounded UP).
+void hostmarch_bf16(const double *v, int64_t n, uint16_t *pattern, double *value) {
+    for (int64_t i = 0; i < n; ++i) { pattern[i] = rtprep::bf16_up(v[i]); value[i] = rtprep::bf16_value(pattern[i]); }
+}
+
+// The cheap-step records of a mesh as the device decodes them (rt_device.hpp: rec_extras, rec_eps, bf16_lo / bf16_hi):
+// per record extras (15: no cheap step), E = 2^(code - 20), g1, k2, dtf, lc; scalars[6] = tiny_max, rmax, end_err, l_min,
+// d_vertex, walk_ok && topo_ok.
+int32_t hostmarch_topo(const double *x, const double *y, int32_t n_nodes, const int32_t *cell_nodes, int32_t n_cells,
+                       const double *bb, int32_t *extras, double *E, double *g1, double *k2, double *dtf, double *lc,
+                       double *scalars) {
+    std::vector<int32_t> cn(3 * (size_t)n_cells);
+    for (size_t i = 0; i < cn.size(); ++i) cn[i] = cell_nodes[i] - 1;
+    rtprep::Prep P = rtprep::prepare(x, y, n_nodes, cn.data(), n_cells, bb);
+    for (size_t r = 0; r < (size_t)3 * n_cells; ++r) {
+        const rt::TopoRec &T = reinterpret_cast<const rt::TopoRec *>(P.trec.data())[r];
+        extras[r] = rt::rec_extras(T.hdr);
+        E[r] = rt::rec_eps(T.hdr);
+        g1[r] = rt::bf16_lo(T.c01); k2[r] = rt::bf16_hi(T.c01); dtf[r] = rt::bf16_lo(T.c23); lc[r] = rt::bf16_hi(T.c23);
+    }
+    scalars[0] = P.topo_tiny_max; scalars[1] = P.topo_rmax; scalars[2] = P.topo_end_err; scalars[3] = P.l_min;
+    scalars[4] = P.d_vertex; scalars[5] = (P.walk_ok && P.topo_ok) ? 1.0 : 0.0;
+    return 0;
+}
+
 }  // extern "C"

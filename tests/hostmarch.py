@@ -38,6 +38,9 @@ def lib():
         L.hostmarch_fetch.argtypes = [_lp, _ip] + [_dp] * 5 + [_ip, _lp]
         L.hostmarch_prep.restype = C.c_int32
         L.hostmarch_prep.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip, _ip, _ip, _dp, C.c_char_p, C.c_int32]
+        L.hostmarch_bf16.argtypes = [_dp, C.c_int64, C.POINTER(C.c_uint16), _dp]
+        L.hostmarch_topo.restype = C.c_int32
+        L.hostmarch_topo.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip] + [_dp] * 6
         _lib = L
     return _lib
 
@@ -103,3 +106,28 @@ def prep(mesh):
                          p(info, _dp), note, 256)
     return dict(extras=extras.reshape(nc, 3), epscode=code.reshape(nc, 3), cls=cls,
                 info={k2: float(info[i]) for i, k2 in enumerate(INFO)}, note=note.value.decode())
+
+
+def bf16_up(v):
+    """(pattern, value) of rtprep::bf16_up for every entry of ``v``: the smallest bfloat16 >= v (v > 0)."""
+    v = _f(v)
+    pat, val = np.zeros(len(v), np.uint16), np.zeros(len(v))
+    lib().hostmarch_bf16(v.ctypes.data_as(_dp), len(v), pat.ctypes.data_as(C.POINTER(C.c_uint16)), val.ctypes.data_as(_dp))
+    return pat, val
+
+
+def topo_records(mesh):
+    """The cheap-step records of ``mesh`` as the device decodes them: dict of [n_cells, 3] arrays extras, E, g1, k2, dtf, lc +
+    the scalars tiny_max, rmax, end_err, l_min, d_vertex, on."""
+    x, y = _f(mesh.x), _f(mesh.y)
+    cn = _i(np.asarray(mesh.cell_nodes).reshape(-1))
+    bb = _f(mesh.bb)
+    nc = len(cn) // 3
+    extras = np.zeros(3 * nc, np.int32)
+    arr = [np.zeros(3 * nc) for _ in range(5)]
+    sc = np.zeros(6)
+    p = lambda a, t: a.ctypes.data_as(t)
+    lib().hostmarch_topo(p(x, _dp), p(y, _dp), len(x), p(cn, _ip), nc, p(bb, _dp), p(extras, _ip), *[p(a, _dp) for a in arr], p(sc, _dp))
+    out = dict(extras=extras.reshape(nc, 3), **{k: a.reshape(nc, 3) for k, a in zip(("E", "g1", "k2", "dtf", "lc"), arr)})
+    out.update(tiny_max=sc[0], rmax=sc[1], end_err=sc[2], l_min=sc[3], d_vertex=sc[4], on=bool(sc[5]))
+    return out

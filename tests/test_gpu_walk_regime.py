@@ -14,7 +14,12 @@ pytestmark = pytest.mark.gpu
 
 FIELDS = ("px", "py", "qx", "qy", "ell")
 CASES = [("lattice", s) for s in range(20)] + [("lattice_far", s) for s in range(6)] + [("sliver", s) for s in range(10)] + \
-        [("sliver_fine", s) for s in range(10)] + [("random", s) for s in range(5)] + [("cluster", s) for s in range(5)]
+        [("sliver_fine", s) for s in range(10)] + [("random", s) for s in range(5)] + [("cluster", s) for s in range(5)] + \
+        [("near_vertex", s) for s in range(6)] + [("aligned", s) for s in range(6)] + [("lattice_mid", s) for s in range(4)] + \
+        [("steep", s) for s in range(4)]
+# the last four classes aim at the thresholds of the certificates (tests/meshgen.py): nodes on / next to track lines, lattice rows
+# within 1e-7 … 3e-3 rad of a track direction, lattices 10 – 60 units from the origin, hand-made tracks within 1e-5 … 1e-8 of
+# ϕ = 0, π/2, π
 
 
 def _make(rt, kind, seed):
@@ -30,6 +35,15 @@ def _make(rt, kind, seed):
         return meshgen.sliver_model(rt, 1300 + seed, 8 + 2 * seed, 8 + 2 * seed, gap=(1e-5, 1e-6, 1e-7)[seed % 3], x0=-3.25, y0=2.5), 1.0
     if kind == "random":
         return meshgen.random_model(rt, 1400 + seed, 150 + 300 * seed), 1.0
+    if kind == "near_vertex":
+        return meshgen.near_vertex_model(rt, 1600 + seed, 200 + 150 * seed, (8, 16, 32, 4, 64)[seed % 5], 0.008), 1.0
+    if kind == "aligned":
+        return meshgen.aligned_model(rt, 1700 + seed, 8 + 3 * seed, (8, 16, 32, 4, 64)[seed % 5], 0.008), 1.0
+    if kind == "lattice_mid":
+        return meshgen.lattice_model(rt, 1800 + seed, 12 + 4 * seed, 12 + 4 * seed, jitter=0.3, x0=(10.0, 30.0, -60.0, 30.0)[seed], y0=(5.0, -40.0, 25.0, 30.0)[seed]), 1.0
+    if kind == "steep":
+        return (meshgen.lattice_model(rt, 1900 + seed, 10 + 4 * seed, 10 + 4 * seed, jitter=(0.0, 0.2)[seed % 2]) if seed < 2 else
+                meshgen.random_model(rt, 1900 + seed, 200 * seed)), 1.0
     return meshgen.random_model(rt, 1500 + seed, 300 + 250 * seed, cluster=True), 1.0
 
 
@@ -69,6 +83,8 @@ def test_walk_on_off_checker(rt, orc, kind, seed):
     n_azim = (8, 16, 32, 4, 64)[seed % 5]
     tg = rt.TrackGenerator(model, n_azim, 0.008 * scale)
     rt.trace(tg)
+    if kind == "steep":
+        meshgen.steep_tracks(rt, tg, seed)
     om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
     ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
                         tiny_step=tg.tiny_step, iter_cap=4000000, n_threads=0)

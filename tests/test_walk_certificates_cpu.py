@@ -29,9 +29,11 @@ def _same(r, ref, what):
         assert np.array_equal(r[k], ref[k]), (k, what)
 
 
-def _both_modes(rt, orc, model, n_azim, delta, k=5):
+def _both_modes(rt, orc, model, n_azim, delta, k=5, steep_seed=None):
     tg = rt.TrackGenerator(model, n_azim, delta)
     rt.trace(tg)
+    if steep_seed is not None:
+        meshgen.steep_tracks(rt, tg, steep_seed)
     ref = _oracle(orc, tg, k=k)
     on = hm.run(tg, k=k, walk=True)
     off = hm.run(tg, k=k, walk=False)
@@ -57,10 +59,20 @@ def test_pincell_walk_on_off_checker(rt, orc, pincell, n_azim, delta):
 
 
 CASES = [("lattice", s) for s in range(4)] + [("lattice_far", s) for s in range(2)] + [("sliver", s) for s in range(4)] + \
-        [("sliver_fine", s) for s in range(4)] + [("random", s) for s in range(3)] + [("cluster", s) for s in range(3)]
+        [("sliver_fine", s) for s in range(4)] + [("random", s) for s in range(3)] + [("cluster", s) for s in range(3)] + \
+        [("near_vertex", s) for s in range(3)] + [("aligned", s) for s in range(3)] + [("lattice_mid", s) for s in range(2)] + \
+        [("steep", s) for s in range(2)]  # the last four: aimed at the certificates' thresholds (tests/meshgen.py)
 
 
 def _make(rt, kind, seed):
+    if kind == "near_vertex":
+        return meshgen.near_vertex_model(rt, 160 + seed, 250 + 200 * seed, (8, 16, 32, 4)[seed % 4], 0.01), 1.0
+    if kind == "aligned":
+        return meshgen.aligned_model(rt, 170 + seed, 9 + 4 * seed, (8, 16, 32, 4)[seed % 4], 0.01), 1.0
+    if kind == "lattice_mid":
+        return meshgen.lattice_model(rt, 180 + seed, 14, 14, jitter=0.3, x0=(10.0, 30.0)[seed], y0=(5.0, -40.0)[seed]), 1.0
+    if kind == "steep":
+        return (meshgen.lattice_model(rt, 190 + seed, 12, 12, jitter=0.2) if seed == 0 else meshgen.random_model(rt, 190 + seed, 300)), 1.0
     if kind == "lattice":
         return meshgen.lattice_model(rt, 100 + seed, 10 + 3 * seed, 10 + 3 * seed, jitter=(0.1, 0.25, 0.4, 0.3)[seed]), 1.0
     if kind == "lattice_far":
@@ -78,7 +90,7 @@ def _make(rt, kind, seed):
 def test_mesh_classes_walk_on_off_checker(rt, orc, kind, seed):
     model, scale = _make(rt, kind, seed)
     n_azim = (8, 16, 32, 4)[seed % 4]
-    tg, ref, on = _both_modes(rt, orc, model, n_azim, 0.01 * scale)
+    tg, ref, on = _both_modes(rt, orc, model, n_azim, 0.01 * scale, steep_seed=seed if kind == "steep" else None)
     s, info = on["stats"], on["info"]
     assert info["walk_ok"] == 1, "one bad cell must not switch the walk step off mesh-wide"
     assert s["walk_emits"] > 0
@@ -218,3 +230,88 @@ def test_cheap_steps_iteration_bound(rt, orc, pincell, iter_cap):
     if iter_cap == 100000:
         assert s["cheap_restarts"] == 0
     print(f"iter_cap={iter_cap}: restarts {s['cheap_restarts']}, cheap emits {s['cheap_emits']}, failing {np.count_nonzero(ref['status'])}")
+
+
+def test_bf16_up_is_an_upper_bound_and_monotone():
+    """The cheap step's per-record constants g1, k2, dtf, lc are stored as bfloat16 rounded UP (rt_mesh_prep.hpp, bf16_up): the
+    decoded value must never be below the double it came from, must be within one bfloat16 ulp (2^-7 relative) of it, and
+    rounding must preserve order."""
+    rng = np.random.default_rng(1)
+    v = np.concatenate([10.0 ** rng.uniform(-300, 38, 500000), rng.uniform(0, 4, 400000), 2.0 ** rng.integers(-120, 120, 50000),
+                        np.nextafter(2.0 ** rng.integers(-120, 120, 50000).astype(np.float64), np.inf)])
+    pat, val = hm.bf16_up(v)
+    fin = pat < 0x7F80
+    assert np.all(val[fin] >= v[fin]), "bf16_up must round up"
+    big = v > 1e-37  # (normal range of bfloat16 / float)
+    assert np.all(val[fin & big] <= v[fin & big] * (1 + 2.0 ** -7))
+    assert np.all(v[~fin] > 3.38e38), "only values beyond the bfloat16 range may map to inf"
+    o = np.argsort(v)
+    assert np.all(np.diff(val[o][fin[o]]) >= 0), "monotone"
+    assert np.all(np.diff(pat[o].astype(np.int64)) >= 0)
+    # exactly representable values map to themselves
+    exact = (np.arange(128, 256, dtype=np.float64) / 128.0)[None, :] * (2.0 ** np.arange(-20, 20, dtype=np.float64))[:, None]
+    _, ve = hm.bf16_up(exact.ravel())
+    assert np.array_equal(ve, exact.ravel())
+    assert hm.bf16_up(np.array([0.0, -1.0]))[0].tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("kind,seed", [("lattice", 1), ("sliver", 2), ("random", 1), ("cluster", 2), ("near_vertex", 1), ("aligned", 2),
+                                       ("lattice_mid", 0), ("lattice_mid", 1), ("sliver_fine", 1)])
+def test_cheap_step_constants_dominate_their_derivation(rt, kind, seed):
+    """Every per-record constant of the cheap step, as the device decodes it, is at least the expression DESIGN.md §2 derives it
+    from, recomputed here in numpy from the mesh alone (independent of rt_mesh_prep.hpp's arithmetic): g1 >= g·√eps·dtf,
+    k2 >= κ0·l_max·g / (0.3·√eps), dtf >= 1.5·|dT| + 0.375·|dT'|, lc >= (l_min + 1.2·√eps·h_min) / (2·tan(γ/2)),
+    E >= isolation margin (the walk record's) + 0.375·√eps + g·tiny_max, and a record whose g·δ_add exceeds 0.075·√eps has none."""
+    model, _ = _make(rt, kind, seed)
+    mesh = rt.Mesh(model)
+    T = hm.topo_records(mesh)
+    P = hm.prep(mesh)
+    tol, ulp = 1.4901161193847656e-8, 1.1102230246251565e-16
+    x, y = np.asarray(mesh.x), np.asarray(mesh.y)
+    cn = np.asarray(mesh.cell_nodes).reshape(-1, 3) - 1
+    bb = np.asarray(mesh.bb)
+    corner = np.hypot(max(abs(bb[0]), abs(bb[2])), max(abs(bb[1]), abs(bb[3])))
+    vx, vy = x[cn], y[cn]
+    area2 = np.abs((vx[:, 1] - vx[:, 0]) * (vy[:, 2] - vy[:, 0]) - (vx[:, 2] - vx[:, 0]) * (vy[:, 1] - vy[:, 0]))
+    elen = np.hypot(vx - np.roll(vx, -1, axis=1), vy - np.roll(vy, -1, axis=1))
+    lmax = elen.max(axis=1)
+    hmin = area2 / lmax
+    g = 1.0 / hmin
+    # neighbour across every edge
+    owner = {}
+    for c in range(len(cn)):
+        for e in range(3):
+            owner.setdefault(tuple(sorted((cn[c, e], cn[c, (e + 1) % 3]))), []).append(c)
+    kappa0, dadd = 20 * ulp * corner, 3 * 4096 * ulp * corner
+    assert T["tiny_max"] >= max(1e-6 * lmax.max(), 4e-8) * (1 - 1e-15)
+    n_on = 0
+    for c in range(len(cn)):
+        for e in range(3):
+            if T["extras"][c, e] >= 15:
+                continue
+            n_on += 1
+            nb = [u for u in owner[tuple(sorted((cn[c, e], cn[c, (e + 1) % 3])))] if u != c]
+            assert len(nb) == 1, "a cheap record needs exactly one cell behind its entry edge"
+            assert g[c] * dadd <= 0.075 * tol * (1 + 1e-12)
+            dtf = 1.5 * area2[nb[0]] + 0.375 * area2[c]
+            assert T["dtf"][c, e] >= dtf
+            assert T["g1"][c, e] >= g[c] * tol * dtf
+            assert T["k2"][c, e] >= kappa0 * lmax[c] * g[c] / (0.3 * tol)
+            i0, i1, i2 = e, (e + 1) % 3, (e + 2) % 3
+
+            def half_tan(iv, ia, ib):
+                ux, uy, wx, wy = vx[c, ia] - vx[c, iv], vy[c, ia] - vy[c, iv], vx[c, ib] - vx[c, iv], vy[c, ib] - vy[c, iv]
+                return np.tan(0.5 * np.arctan2(abs(ux * wy - uy * wx), ux * wx + uy * wy))
+            cv = 2.0 * min(half_tan(i0, i1, i2), half_tan(i1, i2, i0))
+            assert T["lc"][c, e] >= (T["l_min"] + 1.2 * tol * hmin[c]) / cv
+            iso = 2.0 ** (P["epscode"][c, e] - 20.0)  # the walk record's isolation margin
+            assert P["epscode"][c, e] >= 0
+            assert T["E"][c, e] >= iso + 0.375 * tol + g[c] * T["tiny_max"]
+            # border clearance: along the reference's path inboundary(xp, tiny) stays false (every side of the box)
+            for q, (b0, b1, b2) in enumerate(((vx[c, i0] - bb[0], vx[c, i1] - bb[0], vx[c, i2] - bb[0]), (bb[2] - vx[c, i0], bb[2] - vx[c, i1], bb[2] - vx[c, i2]),
+                                              (vy[c, i0] - bb[1], vy[c, i1] - bb[1], vy[c, i2] - bb[1]), (bb[3] - vy[c, i0], bb[3] - vy[c, i1], bb[3] - vy[c, i2]))):
+                assert b0 + b1 > 0
+                assert T["E"][c, e] >= (T["tiny_max"] + 0.375 * tol * abs(b2)) / (b0 + b1)
+    print(f"{kind} seed {seed}: {len(cn)} cells, {n_on} cheap records checked, tiny_max {T['tiny_max']:.1e}")
+    if kind in ("lattice", "near_vertex", "aligned"):
+        assert n_on > len(cn)

@@ -1,7 +1,9 @@
 """Many seeded meshes / quadratures / k through the HIP path (C ABI) against the checker, bit for bit, with the regime
 of every run printed (rt_mesh_info / rt_last_stats).  Same cases as tools/fuzz_cpu.py (every mesh class of
-tests/meshgen.py, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on with exact steps only, off, on with cheap steps, and the
-library's defaults (pieces for small batches).
+tests/meshgen.py incl. the threshold-aimed ones, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on with exact steps only, off,
+on with cheap steps as the library gates them, on with cheap steps FORCED (option "topo" = 2: no 90 % gate, no hand-back of
+often-refused waves — every record that carries a cheap certificate is decided by it), and the library's defaults (pieces for
+small batches).  Prints the share of cheap steps and the refusals by certificate term per mesh class.
 usage (GPU box): [FUZZ_TINY=1] [FUZZ_SHUFFLE=1] python tools/fuzz_many.py [first_seed] [count]"""
 import os
 import sys
@@ -25,6 +27,7 @@ FIELDS = ("px", "py", "qx", "qy", "ell")
 bad = 0
 t0 = time.time()
 seg_total = walk_total = cheap_total = 0
+per = {}
 for seed in range(first, first + count):
     kind, model, n_azim, delta, k = fuzz_cpu.case(seed)
     if n_azim >= 1024:  # keep a GPU run short: the CPU fuzzer covers the finest quadratures
@@ -37,14 +40,17 @@ for seed in range(first, first + count):
         model = rt.DiscreteModel(model.node_coordinates, cells)
     tg = rt.TrackGenerator(model, n_azim, delta, tiny_step=fuzz_cpu.tiny_of(seed) if os.environ.get("FUZZ_TINY") else 1e-8)
     rt.trace(tg)
+    if kind == "steep":
+        import meshgen
+        meshgen.steep_tracks(rt, tg, seed)
     om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
     ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi, tiny_step=tg.tiny_step,
                         k=k, iter_cap=4000000, n_threads=0)
     aq = tg.azimuthal_quadrature
     vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
     regime = ""
-    cheap_n = 0
-    for opts in (dict(walk=1, split=0, topo=0), dict(walk=0, split=0), dict(walk=1, split=0, topo=1), dict(walk=1)):
+    cheap_n = forced_n = 0
+    for opts in (dict(walk=1, split=0, topo=0), dict(walk=0, split=0), dict(walk=1, split=0, topo=1), dict(walk=1, split=0, topo=2), dict(walk=1)):
         dm = _capi.DeviceMesh(tg.mesh, 0)
         for kk, v in opts.items():
             dm.set_option(kk, v)
@@ -61,6 +67,13 @@ for seed in range(first, first + count):
         if opts == dict(walk=1, split=0, topo=1):
             cheap_n = dt.stats()["cheap_records"]
             cheap_total += cheap_n
+        if opts == dict(walk=1, split=0, topo=2):
+            st2 = dt.stats()
+            forced_n = st2["cheap_records"]
+            a = per.setdefault(kind, dict(meshes=0, segs=0, cheap=0, forced=0, refusals=dict.fromkeys(_capi.DeviceTracks.REFUSAL_TERMS, 0)))
+            a["meshes"] += 1; a["segs"] += total; a["cheap"] += cheap_n; a["forced"] += forced_n
+            for kk2, v in st2["cheap_refusals"].items():
+                a["refusals"][kk2] += v
         if opts == dict(walk=1, split=0, topo=0):
             info, stats = dm.info(), dt.stats()
             regime = "walk %s, %d/%d records walkable, eps<=%.1e, %d of %d records by the walk step" % (
@@ -69,9 +82,14 @@ for seed in range(first, first + count):
             walk_total += stats["walk_records"]
         dt.close()
         dm.close()
-    print("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | %s, %d by cheap steps  [%.0f s]" %
+    print("seed %d %-11s cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | %s, %d by cheap steps, %d when forced  [%.0f s]" %
           (seed, kind, model.num_cells, n_azim, k, tg.n_total_tracks, int(ref["total"]), int(np.count_nonzero(ref["status"])), regime,
-           cheap_n, time.time() - t0), flush=True)
-print("done: %d meshes x 4 modes, %d mismatches, %d segments, %.1f %% of them by the walk step, %.1f %% by cheap steps" %
-      (count, bad, seg_total, 100.0 * walk_total / max(seg_total, 1), 100.0 * cheap_total / max(seg_total, 1)))
+           cheap_n, forced_n, time.time() - t0), flush=True)
+for kind, a in sorted(per.items()):
+    print("class %-11s: %4d meshes, %10d segments, %5.1f %% by cheap steps as gated, %5.1f %% forced; refusals when forced: %s" %
+          (kind, a["meshes"], a["segs"], 100.0 * a["cheap"] / max(a["segs"], 1), 100.0 * a["forced"] / max(a["segs"], 1),
+           ", ".join("%s %d" % kv for kv in a["refusals"].items() if kv[1])))
+print("done: %d meshes x 5 modes, %d mismatches, %d segments, %.1f %% of them by the walk step, %.1f %% by cheap steps as gated, %.1f %% forced" %
+      (count, bad, seg_total, 100.0 * walk_total / max(seg_total, 1), 100.0 * cheap_total / max(seg_total, 1),
+       100.0 * sum(a["forced"] for a in per.values()) / max(seg_total, 1)))
 sys.exit(1 if bad else 0)
