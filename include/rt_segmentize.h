@@ -157,6 +157,11 @@ int32_t rt_fetch_volumes(rt_tracks *tracks, double *volumes);
  * The pointers stay valid until the next rt_segmentize, rt_fetch_segments_pinned or rt_tracks_destroy on
  * this handle. */
 int32_t rt_fetch_segments_pinned(rt_tracks *tracks, void **host_ptrs);
+/* Everything a host rebuilds track.segments from, in ONE call and one synchronisation: host_ptrs[8] receives seg_offsets
+ * (int64_t *, n_tracks + 1), status (int32_t *, n_tracks) and the six record arrays as rt_fetch_segments_pinned returns
+ * them — all page-locked and owned by the handle, same lifetime.  (rt_fetch_offsets into fresh pageable arrays costs two
+ * synchronous copies: 6 ms for 1.5 MB at 130 k tracks, as long as the 410 MB of records take through pinned buffers.) */
+int32_t rt_fetch_pinned(rt_tracks *tracks, void **host_ptrs);
 
 /*
  * Device-resident results for consumers that stay on the GPU (RCCL all-gather of shards,

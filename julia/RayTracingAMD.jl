@@ -45,18 +45,32 @@ function mesh_handle(mesh, device::Int)
     end
 end
 
+# Track-set handles that outlive their call (`materialize=false`: the SegmentsViews read the handle's pinned arrays) are
+# registered under their mesh handle: rt_tracks_destroy reads the rt_mesh behind it, so a mesh is only destroyed after
+# every track set made from it — in `release_mesh!` and in the atexit hook, which Julia runs BEFORE the finalizers.
+const LIVE_TRACKSETS = Dict{Ptr{Cvoid},Vector{Any}}()   # mesh handle => WeakRefs of TrackSetHandles
+
 function release_mesh!(mesh)
     lock(MESH_LOCK) do
         per = pop!(MESH_HANDLES, mesh, nothing)
         per === nothing && return
         for hm in values(per)
+            for w in pop!(LIVE_TRACKSETS, hm, Any[])
+                ts = w.value
+                ts === nothing || destroy!(ts)
+            end
             ccall((:rt_mesh_destroy, LIB), Cvoid, (Ptr{Cvoid},), hm)
         end
     end
     return nothing
 end
 
-__init__() = atexit(() -> foreach(release_mesh!, collect(keys(MESH_HANDLES))))
+function __init__()
+    atexit() do
+        foreach(release_multi!, collect(keys(MULTI_HANDLES)))
+        foreach(release_mesh!, collect(keys(MESH_HANDLES)))
+    end
+end
 
 """
     SegmentsView <: AbstractVector{Segment{Float64}}
@@ -86,14 +100,19 @@ end
 # keeps the last track-set handle of a generator alive while SegmentsViews of it exist
 mutable struct TrackSetHandle
     h::Ptr{Cvoid}
-    function TrackSetHandle(h)
+    function TrackSetHandle(h, hm)
         x = new(h)
-        finalizer(x) do y
-            y.h != C_NULL && ccall((:rt_tracks_destroy, LIB), Cvoid, (Ptr{Cvoid},), y.h)
-            y.h = C_NULL
+        lock(MESH_LOCK) do
+            push!(get!(() -> Any[], LIVE_TRACKSETS, hm), WeakRef(x))
         end
+        finalizer(destroy!, x)
         x
     end
+end
+function destroy!(y::TrackSetHandle)   # idempotent: release_mesh! / atexit may have been here before the finalizer
+    y.h != C_NULL && ccall((:rt_tracks_destroy, LIB), Cvoid, (Ptr{Cvoid},), y.h)
+    y.h = C_NULL
+    return nothing
 end
 
 """
@@ -143,17 +162,17 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
             error(replace(msg, "%d" => string(uid[])))
         end
         # ---- fetch SoA results and rebuild Vector{Segment} per track (5-arg ctor, src/segment.jl:23-29)
-        offs = Vector{Int64}(undef, n + 1); status = Vector{Int32}(undef, n)
-        ccall((:rt_fetch_offsets, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}), ht, offs, status)
-        # page-locked buffers owned by the handle: the 44 B/segment arrive at the PCIe rate instead of
-        # page-faulting into fresh Julia arrays (C3: 7 ms instead of 25-40 ms); read-only views, copied
-        # into the Segments below, gone with the handle
-        hp = Vector{Ptr{Cvoid}}(undef, 6)
-        rc = ccall((:rt_fetch_segments_pinned, LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ht, hp)
-        rc != 0 && error("rt_fetch_segments_pinned: " * lasterror())
-        spx = unsafe_wrap(Array, Ptr{Float64}(hp[1]), total); spy = unsafe_wrap(Array, Ptr{Float64}(hp[2]), total)
-        sqx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total)
-        sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total); sel = unsafe_wrap(Array, Ptr{Int32}(hp[6]), total)
+        # page-locked buffers owned by the handle, all eight arrays in one call and one synchronisation: the 44 B/segment
+        # arrive at the PCIe rate instead of page-faulting into fresh Julia arrays (C3: 7 ms instead of 25-40 ms), and the
+        # offsets / status no longer cost two synchronous copies of their own (6 ms); read-only views, copied into the
+        # Segments below, gone with the handle
+        hp = Vector{Ptr{Cvoid}}(undef, 8)
+        rc = ccall((:rt_fetch_pinned, LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ht, hp)
+        rc != 0 && error("rt_fetch_pinned: " * lasterror())
+        offs = unsafe_wrap(Array, Ptr{Int64}(hp[1]), n + 1)
+        spx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total); spy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total)
+        sqx = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[6]), total)
+        sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[7]), total); sel = unsafe_wrap(Array, Ptr{Int32}(hp[8]), total)
         if materialize
             # eager rebuild: real Vector{Segment}s, the reference's layout (src/segment.jl:23-33); one `τ` per segment
             Threads.@threads for u in 1:n
@@ -167,10 +186,10 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
                 end
             end
         else
-            keep = TrackSetHandle(ht)   # the pinned arrays live as long as a view does
+            keep = TrackSetHandle(ht, hm)   # the pinned arrays live as long as a view does
             ht = C_NULL
-            views = [SegmentsView(spx, spy, sqx, sqy, sℓ, sel, Int(offs[u]) + 1, Int(offs[u+1] - offs[u]),
-                                  Dict{Int,Vector{Float64}}(), keep) for u in 1:n]
+            first = [Int(offs[u]) + 1 for u in 1:n]; len = [Int(offs[u+1] - offs[u]) for u in 1:n]
+            views = [SegmentsView(spx, spy, sqx, sqy, sℓ, sel, first[u], len[u], Dict{Int,Vector{Float64}}(), keep) for u in 1:n]
             ccall((:rt_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), keep.h, t.volumes)
         end
         materialize && ccall((:rt_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ht, t.volumes)
@@ -187,11 +206,69 @@ end
 one per entry of `devices` (tracks are independent, src/trackgenerator.jl:362-364), every device marches its range, and the
 results come back as the arrays of an unsharded run (`rt_multi_*`; tests/c_abi_smoke.c makes the same calls from C).
 """
+# The rt_multi handle (N mesh replicas with their preprocessing + the uploaded uid ranges) is kept per TrackGenerator and
+# device list, like the single-GPU path keeps its rt_mesh: a second segmentize_amd_multi!(t) only marches.  It is rebuilt
+# when the tracks changed (another trace!: different count or Σℓ) and released by `release_multi!(t)` or at exit.
+const MULTI_HANDLES = IdDict{Any,Any}()   # t => (devices, n_tracks, Σℓ, handle)
+
+function release_multi!(t)
+    lock(MESH_LOCK) do
+        e = pop!(MULTI_HANDLES, t, nothing)
+        e === nothing || ccall((:rt_multi_destroy, LIB), Cvoid, (Ptr{Cvoid},), e[4])
+    end
+    return nothing
+end
+
 function segmentize_amd_multi!(t::TrackGenerator{Float64}; devices::Vector{Int}=[0], k::Int=5,
                                rtol::Real=Base.rtoldefault(Float64))
     tracks = t.tracks_by_uid
     !isassigned(tracks, 1) && error("Segmentation is intended after tracing. Please, " *
                                     "call `trace!` first!")
+    n = length(tracks)
+    hm = lock(MESH_LOCK) do
+        e = get(MULTI_HANDLES, t, nothing)
+        if e !== nothing && e[1] == devices && e[2] == n && e[3] == sum(tr.ℓ for tr in tracks)
+            return e[4]
+        end
+        e === nothing || (pop!(MULTI_HANDLES, t); ccall((:rt_multi_destroy, LIB), Cvoid, (Ptr{Cvoid},), e[4]))
+        h = multi_create(t, devices)
+        MULTI_HANDLES[t] = (copy(devices), n, sum(tr.ℓ for tr in tracks), h)
+        h
+    end
+    total = ccall((:rt_multi_segmentize, LIB), Int64, (Ptr{Cvoid}, Float64, Int32, Float64, Ptr{Float64}, Int32),
+                  hm, t.tiny_step, k, rtol, t.azimuthal_quadrature.δs, nazim2(t.azimuthal_quadrature))
+    total < 0 && error("rt_multi_segmentize: " * lasterror())
+    nfail = Ref{Int64}(0); uid = Ref{Int64}(0); st = Ref{Int32}(0)
+    ccall((:rt_multi_failed_tracks, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int32}), hm, nfail, uid, st)
+    if nfail[] > 0
+        msg = unsafe_string(ccall((:rt_status_message, LIB), Cstring, (Int32,), st[]))
+        error(replace(msg, "%d" => string(uid[])))
+    end
+    offs = Vector{Int64}(undef, n + 1); status = Vector{Int32}(undef, n)
+    ccall((:rt_multi_fetch_offsets, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}), hm, offs, status)
+    spx = Vector{Float64}(undef, total); spy = similar(spx); sqx = similar(spx); sqy = similar(spx); sℓ = similar(spx)
+    sel = Vector{Int32}(undef, total)
+    rc = ccall((:rt_multi_fetch_segments, LIB), Int32,
+               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+               hm, spx, spy, sqx, sqy, sℓ, sel)
+    rc != 0 && error("rt_multi_fetch_segments: " * lasterror())
+    Threads.@threads for u in 1:n
+        segs = tracks[u].segments
+        cnt = Int(offs[u+1] - offs[u])
+        resize!(segs, cnt)
+        base = Int(offs[u])
+        @inbounds for i in 1:cnt
+            s = base + i
+            segs[i] = Segment(Point2D(spx[s], spy[s]), Point2D(sqx[s], sqy[s]), sℓ[s], Float64[], sel[s])
+        end
+    end
+    ccall((:rt_multi_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), hm, t.volumes)
+    return t
+end
+
+# rt_multi_create for the generator's mesh and tracks (flattened as in segmentize_amd!)
+function multi_create(t::TrackGenerator{Float64}, devices::Vector{Int})
+    tracks = t.tracks_by_uid
     mesh = t.mesh
     coords = get_node_coordinates(get_grid(mesh.model))
     x = Float64[c[1] for c in coords]; y = Float64[c[2] for c in coords]
@@ -211,39 +288,7 @@ function segmentize_amd_multi!(t::TrackGenerator{Float64}; devices::Vector{Int}=
                ids, Int32(length(ids)), x, y, Int32(length(x)), cell_nodes, Int32(length(cell_nodes) ÷ 3), nc_ptrs, nc_data, bb,
                n, px, py, ϕ, cϕ, sϕ, A, B, C, ℓ, azim)
     hm == C_NULL && error("rt_multi_create: " * lasterror())
-    try
-        total = ccall((:rt_multi_segmentize, LIB), Int64, (Ptr{Cvoid}, Float64, Int32, Float64, Ptr{Float64}, Int32),
-                      hm, t.tiny_step, k, rtol, t.azimuthal_quadrature.δs, nazim2(t.azimuthal_quadrature))
-        total < 0 && error("rt_multi_segmentize: " * lasterror())
-        nfail = Ref{Int64}(0); uid = Ref{Int64}(0); st = Ref{Int32}(0)
-        ccall((:rt_multi_failed_tracks, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int32}), hm, nfail, uid, st)
-        if nfail[] > 0
-            msg = unsafe_string(ccall((:rt_status_message, LIB), Cstring, (Int32,), st[]))
-            error(replace(msg, "%d" => string(uid[])))
-        end
-        offs = Vector{Int64}(undef, n + 1); status = Vector{Int32}(undef, n)
-        ccall((:rt_multi_fetch_offsets, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}), hm, offs, status)
-        spx = Vector{Float64}(undef, total); spy = similar(spx); sqx = similar(spx); sqy = similar(spx); sℓ = similar(spx)
-        sel = Vector{Int32}(undef, total)
-        rc = ccall((:rt_multi_fetch_segments, LIB), Int32,
-                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-                   hm, spx, spy, sqx, sqy, sℓ, sel)
-        rc != 0 && error("rt_multi_fetch_segments: " * lasterror())
-        Threads.@threads for u in 1:n
-            segs = tracks[u].segments
-            cnt = Int(offs[u+1] - offs[u])
-            resize!(segs, cnt)
-            base = Int(offs[u])
-            @inbounds for i in 1:cnt
-                s = base + i
-                segs[i] = Segment(Point2D(spx[s], spy[s]), Point2D(sqx[s], sqy[s]), sℓ[s], Float64[], sel[s])
-            end
-        end
-        ccall((:rt_multi_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), hm, t.volumes)
-    finally
-        ccall((:rt_multi_destroy, LIB), Cvoid, (Ptr{Cvoid},), hm)
-    end
-    return t
+    return hm
 end
 
 # Opt-in replacement of the reference entry point:  RayTracingAMD.install!()

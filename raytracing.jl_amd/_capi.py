@@ -18,7 +18,7 @@ SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_status_message", "rt_device_count",
     "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_info", "rt_last_stats", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
-    "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_volumes", "rt_device_pointers",
+    "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
     "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_multi_link_rates",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
@@ -121,6 +121,8 @@ def lib():
     L.rt_fetch_segments.argtypes = [_vp, _dp, _dp, _dp, _dp, _dp, _ip]
     L.rt_fetch_segments_pinned.restype = C.c_int32
     L.rt_fetch_segments_pinned.argtypes = [_vp, C.POINTER(C.c_void_p)]
+    L.rt_fetch_pinned.restype = C.c_int32
+    L.rt_fetch_pinned.argtypes = [_vp, C.POINTER(C.c_void_p)]
     L.rt_fetch_volumes.restype = C.c_int32
     L.rt_fetch_volumes.argtypes = [_vp, _dp]
     L.rt_device_pointers.restype = C.c_int32
@@ -328,6 +330,28 @@ class DeviceTracks:
             out[k] = a
         self._pinned_views = out  # keep the handle alive as long as the views are reachable through it
         return out
+
+    def fetch_pinned(self):
+        """``rt_fetch_pinned``: (offsets, status, records dict) as read-only views of page-locked buffers owned by this handle —
+        one call, one synchronisation (valid until the next ``segmentize`` / pinned fetch / ``close`` of this handle)."""
+        n = self.total
+        ptrs = (C.c_void_p * 8)()
+        _check(lib().rt_fetch_pinned(self._h, ptrs))
+
+        def view(addr, ctype, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype)
+            a = np.ctypeslib.as_array((ctype * count).from_address(addr))
+            a.flags.writeable = False
+            return a
+
+        off = view(ptrs[0], C.c_int64, self.n + 1, np.int64)
+        st = view(ptrs[1], C.c_int32, self.n, np.int32)
+        out = {}
+        for i, k in enumerate(("px", "py", "qx", "qy", "ell", "element")):
+            out[k] = view(ptrs[2 + i], C.c_double if i < 5 else C.c_int32, n, np.float64 if i < 5 else np.int32)
+        self._pinned_views = (off, st, out)
+        return off, st, out
 
     def fetch_segments(self):
         n = self.total

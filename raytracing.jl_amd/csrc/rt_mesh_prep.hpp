@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -139,11 +140,49 @@ struct Prep {
 
 struct P2 { double x, y; };
 
+// The two expensive loops of `prepare` (polygon clipping per cell) are independent per cell: contiguous cell ranges on a few
+// host threads.  Results do not depend on the number of threads.  RT_PREP_THREADS overrides (1: serial).
+template <typename F>
+inline void parallel_cells(int32_t n_cells, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *env = std::getenv("RT_PREP_THREADS")) nt = (unsigned)std::max(1, atoi(env));
+    nt = std::max(1u, std::min({nt, 16u, (unsigned)(n_cells / 256 + 1)}));
+    if (nt == 1) { f(0, n_cells); return; }
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    int32_t done = 0;
+    try {
+        for (unsigned t = 0; t + 1 < nt; ++t) {
+            const int32_t c0 = (int32_t)((int64_t)n_cells * t / nt), c1 = (int32_t)((int64_t)n_cells * (t + 1) / nt);
+            th.emplace_back([=, &f]() { f(c0, c1); });
+            done = c1;
+        }
+    } catch (...) {  // no thread to be had: the caller's thread does the rest
+    }
+    f(done, n_cells);
+    for (auto &t : th) t.join();
+}
+
+// A convex polygon of a few vertices (a triangle clipped by at most three half-planes), without heap traffic: the
+// preprocessing clips ~10^5 – 10^6 of them.
+struct Poly {
+    P2 v[12];
+    int n = 0;
+    size_t size() const { return (size_t)n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+    void push_back(const P2 &p) { if (n < 12) v[n++] = p; }
+    void assign(const P2 *a, const P2 *b) { n = 0; for (; a != b; ++a) push_back(*a); }
+    const P2 &operator[](size_t i) const { return v[i]; }
+    const P2 *begin() const { return v; }
+    const P2 *end() const { return v + n; }
+    void swap(Poly &o) { Poly t = o; o = *this; *this = t; }
+};
+
 // Clip polygon by half-plane  n·p <= c  (Sutherland–Hodgman).
-inline void clip(std::vector<P2> &poly, double nx, double ny, double c) {
-    std::vector<P2> out;
+inline void clip(Poly &poly, double nx, double ny, double c) {
+    Poly out;
     const size_t n = poly.size();
-    out.reserve(n + 2);
     for (size_t i = 0; i < n; ++i) {
         const P2 a = poly[i], b = poly[(i + 1) % n];
         const double da = nx * a.x + ny * a.y - c, db = nx * b.x + ny * b.y - c;
@@ -311,7 +350,9 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
 
     // ---- extras bound: non-vertex nodes m that beat all three vertices somewhere in the
     //      (slightly inflated) cell:  |p-m|^2 < |p-v_i|^2  <=>  2 p·(v_i - m) < |v_i|^2 - |m|^2
-    for (int32_t c = 0; c < n_cells && P.walk_ok; ++c) {
+    if (P.walk_ok) parallel_cells(n_cells, [&](int32_t c_begin, int32_t c_end) {
+    Poly poly;
+    for (int32_t c = c_begin; c < c_end; ++c) {
         CellRecHost &R = P.rec[c];
         if (R.cls != 0) { R.extras = kExtrasNever; continue; }
         const double cx = (R.vx[0] + R.vx[1] + R.vx[2]) / 3, cy = (R.vy[0] + R.vy[1] + R.vy[2]) / 3;
@@ -326,7 +367,6 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         bucket_of(xmin - R.lmax, ymin - R.lmax, ix0, iy0);
         bucket_of(xmax + R.lmax, ymax + R.lmax, ix1, iy1);
         int extras = 0;
-        std::vector<P2> poly;
         for (int by = iy0; by <= iy1 && extras < kExtrasNever; ++by)
             for (int32_t s = P.gstart[by * gnx + ix0]; s < P.gstart[by * gnx + ix1 + 1] && extras < kExtrasNever; ++s) {
                 const int32_t m = P.gnode[s];
@@ -342,6 +382,7 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
             }
         R.extras = std::min(extras, kExtrasNever);
     }
+    });
 
     // ---- isolation margin per record.  Cell buckets: every cell is listed in the buckets its acceptance region's
     //      bounding box touches, so a query with T''s bounding box finds every cell whose region can reach T'.
@@ -380,10 +421,11 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                     }
             }
         }
-        std::vector<int32_t> stamp(n_cells, -1), cand;
-        std::vector<P2> acc, pa, pb;
         const double theta = 0.25 * kTol * 1.5;  // the record's region reaches this far (barycentric) beyond its entry edge
-        for (int32_t c = 0; c < n_cells; ++c) {
+        parallel_cells(n_cells, [&](int32_t c_begin, int32_t c_end) {
+        std::vector<int32_t> stamp(n_cells, -1), cand;
+        Poly acc, pa, pb;
+        for (int32_t c = c_begin; c < c_end; ++c) {
             const CellRecHost &R = P.rec[c];
             if (R.cls != 0 || R.extras >= kExtrasNever) continue;
             // a degenerate cell within the scan reach of this cell (its nodes can precede the cell's own in the node
@@ -423,10 +465,21 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                 mc[k] = mnx[k] * R.vx[i1] + mny[k] * R.vy[i1];
             }
             double need[3] = {0, 0, 0};
+            // only the part of a neighbour's acceptance region inside this cell (reaching theta beyond an entry edge) can raise
+            // a margin: a candidate whose scaled bounding box misses the cell's padded box is skipped before any clipping
+            const double rpad = 1e-6 * R.lmax + 1e-12 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1) + 1.0);
             for (int32_t u : cand) {
                 const CellRecHost &U = P.rec[u];
                 const double ux = (U.vx[0] + U.vx[1] + U.vx[2]) / 3, uy = (U.vy[0] + U.vy[1] + U.vy[2]) / 3;
                 const double s = accept_scale(U);
+                {
+                    double sx0 = INFINITY, sx1 = -INFINITY, sy0 = INFINITY, sy1 = -INFINITY;
+                    for (int k = 0; k < 3; ++k) {
+                        const double qx = ux + (U.vx[k] - ux) * s, qy = uy + (U.vy[k] - uy) * s;
+                        sx0 = std::min(sx0, qx); sx1 = std::max(sx1, qx); sy0 = std::min(sy0, qy); sy1 = std::max(sy1, qy);
+                    }
+                    if (sx0 > bx1 + rpad || sx1 < bx0 - rpad || sy0 > by1 + rpad || sy1 < by0 - rpad) continue;
+                }
                 for (int e = 0; e < 3; ++e) {
                     if (u == R.adj[e]) continue;  // the predecessor T of this record is evaluated exactly on the device
                     // rotated roles: entry edge (v_e, v_e+1) is opposite vertex e+2; exit edges opposite vertices e and e+1
@@ -450,6 +503,7 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
                 epscode[(size_t)3 * c + e] = (int8_t)code;
             }
         }
+        });
     }
 
     // ---- rotated walk records

@@ -1519,6 +1519,8 @@ struct rt_tracks {
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
     void *pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rt_fetch_segments_pinned
     size_t pin_cap = 0;                                                     // records
+    int64_t *pin_off = nullptr;  // rt_fetch_pinned: offsets[n + 1] and status[n], page-locked like the records
+    int32_t *pin_st = nullptr;
     hipEvent_t ev[8] = {};
     double ms[8] = {};
     // what the compaction of the last single-pass call needs (it may run later, on demand: option "compact" = 0)
@@ -1712,6 +1714,8 @@ void free_tracks(rt_tracks *t) {
     t->dbg.release();
 #endif
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
+    if (t->pin_off) (void)hipHostFree(t->pin_off);
+    if (t->pin_st) (void)hipHostFree(t->pin_st);
     pin_release_to_cache(t);
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->volumes_prev.release(); t->delta_s.release(); t->tau.release(); t->sigma_t.release();
@@ -2540,6 +2544,22 @@ int32_t rt_fetch_segments_pinned(rt_tracks *t, void **host_ptrs) {
         RT_HIP(hipMemcpyAsync(t->pin[a], src[a], n * (a < 5 ? sizeof(double) : sizeof(int32_t)), hipMemcpyDeviceToHost, s));
     RT_HIP(hipStreamSynchronize(s));
     for (int a = 0; a < 6; ++a) host_ptrs[a] = t->pin[a];
+    return RT_SUCCESS;
+}
+
+int32_t rt_fetch_pinned(rt_tracks *t, void **host_ptrs) {
+    if (!t || !host_ptrs) { set_error("null argument"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    RT_HIP(hipSetDevice(t->mesh->device));
+    if (!t->pin_off) RT_HIP(hipHostMalloc((void **)&t->pin_off, sizeof(int64_t) * (size_t)(t->n + 1), hipHostMallocDefault));
+    if (!t->pin_st) RT_HIP(hipHostMalloc((void **)&t->pin_st, sizeof(int32_t) * (size_t)std::max<int64_t>(t->n, 1), hipHostMallocDefault));
+    hipStream_t s = t->mesh->stream;
+    // (queued in front of the records' copies: one synchronisation for all eight arrays)
+    RT_HIP(hipMemcpyAsync(t->pin_off, t->offsets.p, sizeof(int64_t) * (size_t)(t->n + 1), hipMemcpyDeviceToHost, s));
+    if (t->n) RT_HIP(hipMemcpyAsync(t->pin_st, t->status.p, sizeof(int32_t) * (size_t)t->n, hipMemcpyDeviceToHost, s));
+    if (int32_t rc = rt_fetch_segments_pinned(t, host_ptrs + 2)) return rc;
+    host_ptrs[0] = t->pin_off;
+    host_ptrs[1] = t->pin_st;
     return RT_SUCCESS;
 }
 

@@ -69,8 +69,11 @@ def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, dev
     if n_failed and check:
         raise RuntimeError(_capi.status_message(st, uid))
     if fetch:
-        off, t.track_status = dt.fetch_offsets()
-        s = dt.fetch_segments_pinned() if fetch == "pinned" else dt.fetch_segments()
+        if fetch == "pinned":
+            off, t.track_status, s = dt.fetch_pinned()
+        else:
+            off, t.track_status = dt.fetch_offsets()
+            s = dt.fetch_segments()
         t.segments = SegmentStore(off, s["px"], s["py"], s["qx"], s["qy"], s["ell"], s["element"])
         t.volumes = dt.fetch_volumes()
     return t

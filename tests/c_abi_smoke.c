@@ -4,8 +4,8 @@
  * Makes the call sequence of the Julia shim (julia/RayTracingAMD.jl: segmentize_amd!) with the shim's argument
  * types: dlopen of the library by path (what Julia's `ccall((:sym, LIB), ...)` does), 1-based CSR `ptrs` as
  * Gridap's Table holds them, rt_mesh_create -> rt_tracks_create -> rt_segmentize -> rt_failed_tracks (+ the
- * "%d" -> uid substitution into rt_status_message's text) -> rt_fetch_offsets -> rt_fetch_segments_pinned ->
- * rt_fetch_volumes -> destroy.  Inputs come from the library's own host rows (rt_msh_load, rt_trace_counts,
+ * "%d" -> uid substitution into rt_status_message's text) -> rt_fetch_pinned (offsets, status and the six record arrays in
+ * page-locked buffers; cross-checked against rt_fetch_offsets) -> rt_fetch_volumes -> destroy.  Inputs come from the library's own host rows (rt_msh_load, rt_trace_counts,
  * rt_trace), so no Julia or Python is involved.  Prints one JSON line with order-sensitive checksums of every
  * result array; tests/test_gpu_c_abi.py compares them with the checker's arrays.
  *
@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     LOAD(rt_abi_version) LOAD(rt_last_error) LOAD(rt_status_message) LOAD(rt_device_count)
     LOAD(rt_mesh_create) LOAD(rt_mesh_destroy) LOAD(rt_mesh_info) LOAD(rt_tracks_create) LOAD(rt_tracks_destroy)
-    LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_volumes)
+    LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_pinned) LOAD(rt_fetch_volumes)
     LOAD(rt_multi_create) LOAD(rt_multi_destroy) LOAD(rt_multi_segmentize) LOAD(rt_multi_failed_tracks) LOAD(rt_multi_fetch_offsets)
     LOAD(rt_multi_fetch_segments) LOAD(rt_multi_fetch_volumes) LOAD(rt_multi_shards)
     LOAD(rt_msh_load) LOAD(rt_msh_sizes) LOAD(rt_msh_fetch) LOAD(rt_msh_free) LOAD(rt_trace_counts) LOAD(rt_trace)
@@ -124,8 +124,16 @@ int main(int argc, char **argv) {
     total = p_rt_segmentize(ht, 1e-8, 5, rtol, delta_s, n2);
     if (total < 0) { fprintf(stderr, "rt_segmentize: %s\n", p_rt_last_error()); return 1; }
     p_rt_failed_tracks(ht, &n_failed, &first_uid, &first_status);
+    /* offsets, status and the six record arrays in page-locked buffers of the handle: one call, one synchronisation */
+    void *hp8[8];
+    if (p_rt_fetch_pinned(ht, hp8)) { fprintf(stderr, "rt_fetch_pinned: %s\n", p_rt_last_error()); return 1; }
+    /* (and the older pair of calls gives the same bytes) */
     if (p_rt_fetch_offsets(ht, offs, status)) { fprintf(stderr, "rt_fetch_offsets: %s\n", p_rt_last_error()); return 1; }
-    if (p_rt_fetch_segments_pinned(ht, hp)) { fprintf(stderr, "rt_fetch_segments_pinned: %s\n", p_rt_last_error()); return 1; }
+    if (memcmp(offs, hp8[0], sizeof(int64_t) * ((size_t)n + 1)) || memcmp(status, hp8[1], sizeof(int32_t) * (size_t)n)) {
+        fprintf(stderr, "rt_fetch_pinned: offsets / status differ from rt_fetch_offsets\n");
+        return 1;
+    }
+    for (int a = 0; a < 6; ++a) hp[a] = hp8[2 + a];
     if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
     }
     char message[512] = "";
