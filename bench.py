@@ -384,6 +384,30 @@ def _main(real_stdout):
     stats = dt.stats()
     info = dmesh.info()
 
+    # ---- N > 1: the same K steps once more WITHOUT the volumes all-reduce — what the pipelined all-reduce still costs a step
+    #      (its launch and whatever of its latency the next march does not cover) is the difference; load balance per rank
+    per_rank = None
+    allreduce_exposed_ms = None
+    if dist_on:
+        dmesh.set_enqueue_hook(None)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        sync()
+        elapsed_no_allreduce = time.perf_counter() - t0
+        dmesh.set_enqueue_hook(pipe.hook)
+        mine = torch.tensor([float(local_total), float(hi - lo), elapsed / args.steps * 1e3, elapsed_no_allreduce / args.steps * 1e3,
+                             kern["march"] / args.steps], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        allr = torch.stack(allr).cpu().numpy()
+        per_rank = {"segments": [int(v) for v in allr[:, 0]], "tracks": [int(v) for v in allr[:, 1]],
+                    "ms_per_step": [float(v) for v in allr[:, 2]], "march_ms": [float(v) for v in allr[:, 4]]}
+        allreduce_exposed_ms = float(max(allr[:, 2]) - max(allr[:, 3]))
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     tot = torch.tensor([float(local_total), float(n_failed)], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -547,6 +571,13 @@ def _main(real_stdout):
             "kernel_ms_note": "from a second pass of the same K steps with the library's HIP events on (option \"timing\"); "
                               "that pass took %.4f ms per step" % (elapsed_with_events / args.steps * 1e3),
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank  # load balance of the Σℓ-balanced uid ranges
+            for r, v in enumerate(per_rank["segments"]):
+                out["config"]["segments_rank%d" % r] = v
+            out["allreduce_ms_exposed"] = allreduce_exposed_ms
+            out["allreduce_note"] = ("slowest rank's ms per step with the pipelined volumes all-reduce minus the same K steps without "
+                                     "any all-reduce (max over ranks each): what the reduction adds to a step")
         if rehearsal:
             out["rehearsal"] = "RT_BENCH_REHEARSAL=1: all ranks on GPU 0, collectives over gloo on host copies — a functional run, its timings mean nothing"
         if latency is not None:

@@ -1,0 +1,37 @@
+"""The N > 1 path of bench.py as the driver launches it — ``python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2``
+— as a fresh child process on the one GPU of the test box (RT_BENCH_REHEARSAL=1: both ranks use GPU 0 and the collectives
+run over gloo on host copies; RCCL refuses two ranks on one device).  What it pins: the launch contract (one JSON line on
+stdout from rank 0), the FIXED global problem of BASELINE configs[4] sharded by uid (114,447,177 segments whatever N), the
+per-rank load balance, the all-reduce inside the step and the all-gather-v report.  Timings of such a run mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, RT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "segments/s" and d["scaling"] == "strong"
+    assert d["config"]["segments_global"] == 114447177 and d["config"]["tracks_global"] == 1043212
+    assert d["config"]["failed_tracks"] >= 0  # (tracks on which the reference's own Σℓ check fails on the substitute BWR mesh)
+    pr = d["per_rank"]
+    assert sum(pr["segments"]) == 114447177 and sum(pr["tracks"]) == 1043212 and len(pr["segments"]) == 2
+    assert d["config"]["segments_rank0"] == pr["segments"][0] and d["config"]["segments_rank1"] == pr["segments"][1]
+    assert abs(pr["segments"][0] - pr["segments"][1]) < 0.02 * 114447177  # Σℓ-balanced uid ranges: segments ∝ ℓ
+    assert "allreduce_ms_exposed" in d and "ms" in d["allgather"], d.get("allgather")
+    assert d["allgather"]["bytes_received_per_rank"] == 44.0 * pr["segments"][1]  # rank 0 receives rank 1's shard
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "rehearsal" in d
