@@ -433,14 +433,24 @@ RT_HD __forceinline__ bool order_points(double phi, double x1, double y1, double
 // branch in which the reference reads an unassigned variable (n_int == 3, all coincident).
 // `eq` receives the index (0..2) of the cell edge the exit point q lies on (-1 if q was not
 // produced): the walk step uses it to predict the next cell through the adjacency table.
+// The three edges' results (edge_hit of edges (n1,n2), (n2,n3), (n3,n1), src/intersection.jl:48-54) combined into the pair
+// (p, q): src/intersection.jl:56-119.  Separate from the edge tests so that k_first can evaluate the three edges on three lanes.
+RT_HD __forceinline__ bool intersections_combine(int h0, double ex0, double ey0, int h1, double ex1, double ey1, int h2, double ex2,
+                                                 double ey2, double phi, double &px, double &py, double &qx, double &qy, int &eq);
+
 RT_HD __forceinline__ bool intersections(const Tri &t, double phi, double tA, double tB,
                                               double tC, double &px, double &py, double &qx, double &qy, int &eq) {
-    eq = -1;
     const double x1 = t.x1, y1 = t.y1, x2 = t.x2, y2 = t.y2, x3 = t.x3, y3 = t.y3;
     double ex0 = 0, ey0 = 0, ex1 = 0, ey1 = 0, ex2 = 0, ey2 = 0;
     const int h0 = edge_hit(tA, tB, tC, x1, y1, x2, y2, ex0, ey0);
     const int h1 = edge_hit(tA, tB, tC, x2, y2, x3, y3, ex1, ey1);
     const int h2 = edge_hit(tA, tB, tC, x3, y3, x1, y1, ex2, ey2);
+    return intersections_combine(h0, ex0, ey0, h1, ex1, ey1, h2, ex2, ey2, phi, px, py, qx, qy, eq);
+}
+
+RT_HD __forceinline__ bool intersections_combine(int h0, double ex0, double ey0, int h1, double ex1, double ey1, int h2, double ex2,
+                                                 double ey2, double phi, double &px, double &py, double &qx, double &qy, int &eq) {
+    eq = -1;
     const bool v0 = h0 == 1, v1 = h1 == 1, v2 = h2 == 1;
     const bool parallel_found = (h0 == 2) || (h1 == 2) || (h2 == 2);
     const int n_int = (int)v0 + (int)v1 + (int)v2;

@@ -286,13 +286,138 @@ __device__ __forceinline__ unsigned long long rt_tick(double dep) {
     return t;
 }
 #endif
+// ---- every track's first record, ahead of the march (k_first) -------------------------------------------------------
+// A track's first record is the one step of the march that has no prediction: start band (src/track.jl:125-129), then the
+// literal locate (src/mesh.jl:103-146) and intersections (src/intersection.jl:34-119) — a chain of ≈15 dependent gathers
+// (bucket -> node range -> nearest node -> its cells' entries one after the other -> ...) that every lane of the march
+// walked alone, two waves per SIMD, right after the compaction had flushed the caches: ≈60 of the march's 178 µs at C3.
+// k_first does that step for all tracks before the march with EIGHT lanes per track: the bucket's node range is scanned
+// eight nodes at a time, the nearest node's incident cells are tested eight at a time (first hit in stored order wins, as in
+// the reference), the three edges are intersected on three lanes — five dependent round trips instead of fifteen, on 16 k
+// waves instead of 2 k.  It only handles the plain case (nearest node found within the bucket's 3x3 block, one of its cells
+// contains the point, a regular segment comes out); anything else leaves the slot "not done" and the march takes that
+// track from its start as before.  Same device functions, same operation order: the record is bit-identical.
+// The record goes to row 0 of the wave's reserved first chunk; what the march needs to go on (iteration count, exit point,
+// ℓ, walk state) goes to a per-slot SoA.
+struct DFirst {
+    RT_G int32_t *it;    // [n_slots] 0: not done; else the iterations counted up to and including the first emit
+    RT_G int32_t *T;     // cell of the record
+    RT_G int32_t *pred;  // walk record predicted next (-1: none)
+    RT_G double *v;      // [10][n_slots]: qx, qy, ell, ax, ay, bx, by, cx, cy, dT
+    int64_t n_slots;
+};
+
+__global__ __launch_bounds__(256) void k_first(DMesh m, DTracks t, DParams prm, DStage stg, DFirst f) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x & 7, gbase = lane & ~7;
+    const int64_t slot_raw = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool have = slot_raw < t.n;
+    const int64_t slot = have ? slot_raw : t.n - 1;  // (idle groups shadow the last track and write nothing)
+    const int32_t u = t.perm[slot];
+    const DGeo g = load_geo(m.geo);
+    const double tA = t.A[u], tB = t.B[u], tC = t.C[u], phi = t.phi[u];
+    const double sx = prm.tiny_step * t.cs[u], sy = prm.tiny_step * t.sn[u];  // advance_step, src/point.jl:43
+    double xpx = t.px[u] + sx, xpy = t.py[u] + sy;                               // src/track.jl:114
+    const int32_t cap = (int32_t)(prm.iter_cap < 0x7fffffff ? prm.iter_cap : 0x7fffffff);
+    int32_t it = 0;
+    bool ok = true;
+    while (inboundary(m, xpx, xpy, prm.tiny_step)) {  // start band, :125-129
+        if (++it > cap) { ok = false; break; }
+        xpx = xpx + sx; xpy = xpy + sy;
+    }
+    if (++it > cap) ok = false;  // the iteration that emits
+    // ---- nn(kdtree, xp): the bucket's 3x3 block, eight nodes at a time; (squared distance, id) is a total order
+    int ix, iy;
+    bucket_of(g, xpx, xpy, ix, iy);
+    const int b = iy * g.gnx + ix;
+    const int32_t s0 = g.c3start[b], s1 = g.c3start[b + 1];
+    double best = __builtin_huge_val();
+    int32_t best_id = 0x7fffffff;
+    for (int32_t q = s0 + sub; q < s1; q += 8) {
+        const int32_t id = g.c3node[q];
+        const double dx = xpx - g.c3x[q], dy = xpy - g.c3y[q];
+        const double d2 = dx * dx + dy * dy;
+        if (node_before(d2, id, best, best_id)) { best = d2; best_id = id; }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int32_t oi = __shfl_xor(best_id, o, 64);
+        if (node_before(ob, oi, best, best_id)) { best = ob; best_id = oi; }
+    }
+    {   // as nearest_node: accepted only if nothing outside the block can be nearer (else the ring search: left to the march)
+        const double lb = ring_bound(g, xpx, xpy, ix, iy, 1) - 1e-9 * g.gh;
+        ok = ok && best_id != 0x7fffffff && (lb == __builtin_huge_val() || (lb > 0.0 && best < lb * lb));
+    }
+    const int32_t nn = best_id != 0x7fffffff ? best_id : 0;
+    // ---- the cells of node_cells[nn] in stored order, first hit wins (src/mesh.jl:110-118), eight at a time
+    const int32_t f0 = g.ncp[nn], f1 = g.ncp[nn + 1];
+    Tri tri{};
+    int32_t element = -1;
+    for (int32_t base = f0; base < f1 && element < 0; base += 8) {
+        const int32_t q = base + sub;
+        Tri c{};
+        int32_t cell = -1;
+        bool hit = false;
+        if (q < f1) {
+            const RT_G FanEntry *e = g.fan + q;
+            c.x1 = e->x1; c.y1 = e->y1; c.x2 = e->x2; c.y2 = e->y2; c.x3 = e->x3; c.y3 = e->y3;
+            c.adj[0] = e->adj[0]; c.adj[1] = e->adj[1]; c.adj[2] = e->adj[2];
+            cell = e->cell;
+            hit = point_in_triangle(c, xpx, xpy);
+        }
+        const unsigned hits = (unsigned)((__ballot(hit) >> gbase) & 0xffull);
+        if (hits) {
+            const int src = gbase + __builtin_ctz(hits);
+            tri.x1 = __shfl(c.x1, src, 64); tri.y1 = __shfl(c.y1, src, 64); tri.x2 = __shfl(c.x2, src, 64);
+            tri.y2 = __shfl(c.y2, src, 64); tri.x3 = __shfl(c.x3, src, 64); tri.y3 = __shfl(c.y3, src, 64);
+            tri.adj[0] = __shfl(c.adj[0], src, 64); tri.adj[1] = __shfl(c.adj[1], src, 64); tri.adj[2] = __shfl(c.adj[2], src, 64);
+            element = __shfl(cell, src, 64);
+        }
+    }
+    ok = ok && element >= 0;  // (not found among the nearest node's cells: the knn fallback, left to the march)
+    // ---- intersections(mesh, element, track): one edge per lane, then the reference's case analysis on every lane
+    double px = 0, py = 0, qx = 0, qy = 0;
+    int eq = -1;
+    {
+        const int e3 = sub < 3 ? sub : 0;
+        const double ax = e3 == 0 ? tri.x1 : (e3 == 1 ? tri.x2 : tri.x3), ay = e3 == 0 ? tri.y1 : (e3 == 1 ? tri.y2 : tri.y3);
+        const double bx = e3 == 0 ? tri.x2 : (e3 == 1 ? tri.x3 : tri.x1), by = e3 == 0 ? tri.y2 : (e3 == 1 ? tri.y3 : tri.y1);
+        double ex = 0, ey = 0;
+        const int h = ok ? edge_hit(tA, tB, tC, ax, ay, bx, by, ex, ey) : 0;
+        const int h0 = __shfl(h, gbase, 64), h1 = __shfl(h, gbase + 1, 64), h2 = __shfl(h, gbase + 2, 64);
+        const double ex0 = __shfl(ex, gbase, 64), ey0 = __shfl(ey, gbase, 64), ex1 = __shfl(ex, gbase + 1, 64), ey1 = __shfl(ey, gbase + 1, 64);
+        const double ex2 = __shfl(ex, gbase + 2, 64), ey2 = __shfl(ey, gbase + 2, 64);
+        ok = ok && intersections_combine(h0, ex0, ey0, h1, ex1, ey1, h2, ex2, ey2, phi, px, py, qx, qy, eq);  // :153
+    }
+    ok = ok && !isapprox_v2(px, py, qx, qy);  // :156-159 (a vertex touch steps on: left to the march)
+    const double ell = norm2(px - qx, py - qy);  // Segment ctor, src/segment.jl:31-33
+    if (!have || sub != 0) return;
+    if ((slot & 63) == 0) {  // the wave's reserved first chunk (chunk w for march wave w), as the march would record it
+        const int64_t w = slot >> 6;
+        stg.ctab[w * kMaxChunks] = (int32_t)w;
+        stg.cowner[w] = (int32_t)(w * kMaxChunks);
+    }
+    if (!ok) { f.it[slot] = 0; return; }
+    Walk wk;
+    if (m.walk_ok && eq >= 0) walk_enter(m, tri, wk, element, eq);
+    else { wk.T = element; wk.pred = -1; wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0; }
+    const int64_t o = stage_slot((int32_t)(slot >> 6), 0, (int)(slot & 63));
+    stg.qx[o] = qx; stg.qy[o] = qy; stg.element[o] = -(element + 1);  // a record of the generic step keeps its own p
+    stg.px[o] = px; stg.py[o] = py;
+    f.it[slot] = it; f.T[slot] = element; f.pred[slot] = wk.pred;
+    RT_G double *v = f.v + slot;
+    const int64_t S = f.n_slots;
+    v[0] = qx; v[S] = qy; v[2 * S] = ell; v[3 * S] = wk.ax; v[4 * S] = wk.ay; v[5 * S] = wk.bx; v[6 * S] = wk.by;
+    v[7 * S] = wk.cx; v[8 * S] = wk.cy; v[9 * S] = wk.dT;
+}
+
 // k_march's staging pointers are needed once per 32 iterations (chunk hand-out, row addresses) and on rare
 // records: they are read from the kernel-argument segment with scalar loads where they are used instead of
 // living in 19 SGPRs across the whole loop (which the kernel was spilling to VGPR lanes and reloading on
 // its hot path).  The struct mirrors k_march's parameter list.
 struct MarchArgsLayout {
     DMesh m; DTracks t; DParams prm; int32_t *counts; int32_t *status; const int64_t *offsets; DOut out; DStage stg;
-    unsigned long long *fail_info; DSplit sp;
+    unsigned long long *fail_info; DSplit sp; DFirst fst;
 };
 __device__ __forceinline__ const RT_K DStage *march_stage_args() {
     const RT_K char *ka = (const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -325,12 +450,12 @@ template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false, bool LDSREC = fal
 __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) ? 3 : (TOPO ? RT_TOPO_OCC : 0)) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
-                                                      unsigned long long *__restrict__ fail_info, DSplit sp) {
+                                                      unsigned long long *__restrict__ fail_info, DSplit sp, DFirst fst) {
     // The split plan's tables are used at the start and the end of a piece and when a record of the target's cell comes
     // up — never in the steady march: they are read from the argument segment where they are used (as `stg` is), so
     // that their 17 pointers do not occupy scalar registers across the loop.
     const RT_K DSplit *spk = (const RT_K DSplit *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, sp));
-    (void)sp;
+    (void)sp; (void)fst;
     static_assert(!TOPO || (MODE == kStage && !SPLIT && !LDSREC), "cheap steps: staged whole tracks only");
     constexpr bool FUSE = WAVES > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
@@ -444,10 +569,40 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     const RT_G TopoRec *trec_v = m.trec;
     const RT_G EdgeABC *etab_v = m.etab;
     if (TOPO) asm volatile("" : "+v"(trec_v), "+v"(etab_v));
+    // The track's first record may have been made by k_first (whole tracks, staged, reserved first chunks): the march then
+    // starts behind it — iteration count, exit point, Σℓ, walk state and the staging row pointers as its own first
+    // iteration would have left them.  The state is read through the argument segment (nothing of it lives across the loop).
+    if (MODE == kStage && !SPLIT) {
+        const RT_K DFirst *fk = (const RT_K DFirst *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, fst));
+        const RT_G int32_t *f_it = fk->it;
+        if (f_it != nullptr) {
+            const int32_t fit = f_it[slot];
+            if (fit > 0) {
+                const int64_t S = fk->n_slots;
+                const RT_G double *v = fk->v + slot;
+                it = fit; i = 1; n_generic = 1;
+                lqx = v[0]; lqy = v[S];
+                const double ell0 = v[2 * S];
+                sum_ell = ell0;
+                wk.ax = v[3 * S]; wk.ay = v[4 * S]; wk.bx = v[5 * S]; wk.by = v[6 * S]; wk.cx = v[7 * S]; wk.cy = v[8 * S]; wk.dT = v[9 * S];
+                wk.T = fk->T[slot]; wk.pred = fk->pred[slot];
+                prev_element = wk.T;
+                xpx = lqx + sx; xpy = lqy + sy;  // :165
+                my_chunk = (int32_t)wave_id;
+                const int64_t o0 = stage_slot(my_chunk, 0, lane);
+                const RT_K DStage *sk = march_stage_args();
+                row_qx = sk->qx + o0; row_qy = sk->qy + o0; row_el = sk->element + o0;
+                if (TOPO) last_word = -(wk.T + 1);
+                if (FUSE) atomicAdd(&hist[wk.T], w * ell0);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
+                if (TOPO) fl = topo_enter(mh, tt, wk, tA, tB, tC, ts) ? kFlCheap : 0u;
+            }
+        }
+    }
     // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
     // band.  Run as its own loop so that the 64 lanes of the wave, whose bands differ in length
     // (≈1/sin ϕ or 1/|cos ϕ| steps), reach their first locate together.
-    while (!(SPLIT && (seed_pending || piece_dead)) && st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
+    // (i == 0: a lane that starts behind a first record of k_first is past its start band — its xp may lie in the END band)
+    while (i == 0 && !(SPLIT && (seed_pending || piece_dead)) && st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
         xpx = xpx + sx; xpy = xpy + sy;
     }
@@ -1448,6 +1603,7 @@ struct rt_mesh {
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
     int sweep_debug = 0;
+    int first = 1;  // 1: every track's first record by k_first, eight lanes per track, ahead of the whole-track march
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
                            // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is
                            // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
@@ -1500,6 +1656,9 @@ struct rt_tracks {
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy;
     DevBuf<int32_t> gelement, ctab, cowner;
+    DevBuf<int32_t> fst_i;   // k_first: it, T, pred per march slot
+    DevBuf<double> fst_v;    // ... and its ten doubles
+    int32_t last_first = 0;  // 1: the last call made the first records with k_first
     int64_t pool_chunks = 0, chunks_needed_last = 0, total_last = 0;
     // split mode (pieces of tracks)
     int32_t n_vwaves = 0;
@@ -1720,7 +1879,7 @@ void free_tracks(rt_tracks *t) {
     t->spx.release(); t->spy.release(); t->sqx.release(); t->sqy.release(); t->sell.release();
     t->volumes.release(); t->volumes_prev.release(); t->delta_s.release(); t->tau.release(); t->sigma_t.release();
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
-    t->gelement.release(); t->ctab.release(); t->cowner.release();
+    t->gelement.release(); t->ctab.release(); t->cowner.release(); t->fst_i.release(); t->fst_v.release();
     t->sw_src.release(); t->sw_w.release(); t->sw_xs.release(); t->sw_psi_in.release(); t->sw_psi_out.release(); t->sw_phi.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
     t->s_el.release(); t->s_eq.release(); t->p_count.release(); t->p_flags.release(); t->p_valid.release(); t->p_rel.release();
@@ -1880,6 +2039,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "first")) { mesh->first = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }
@@ -2200,6 +2360,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     };
 
     const bool widek = k > rt::kMaxK;  // find_element's knn fallback beyond the in-register list: separate kernel instantiations
+    rt::DFirst fst{};  // (it == nullptr: the march makes every first record itself)
     const int64_t *march_offsets = nullptr;
     hipStream_t march_stream = s;          // (the hybrid path launches its pieces on the auxiliary stream)
     const rt::DTracks *march_tracks = &t->d;
@@ -2209,7 +2370,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         if (smem > 48 * 1024)
             RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC, TOPO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK, LDSREC, TOPO>), dim3(blocks), dim3(64 * WAVES), smem, march_stream, m->d, *march_tracks, prm,
-                           t->counts.p, t->status.p, march_offsets, out, *march_stage, d_fail, sp);
+                           t->counts.p, t->status.p, march_offsets, out, *march_stage, d_fail, sp, fst);
         return RT_SUCCESS;
     };
     t->last_split = 0;
@@ -2277,10 +2438,22 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             // Everything one attempt puts on the stream(s), as one function.  (Capturing it once into a HIP graph and replaying it
             // was tried: the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on
             // events that were only ever recorded inside a graph — DESIGN.md §4.)
+            // every track's first record ahead of the march (k_first): whole tracks with their reserved first chunks, the usual k
+            const bool use_first = m->first && !split && !hybrid && stg.static0 && !widek && n > 0 && m->lds_records == 0;
+            fst = rt::DFirst{};
+            if (use_first) {
+                const size_t ns = (size_t)n_whole_waves * 64;
+                RT_HIP(t->fst_i.reserve(3 * ns)); RT_HIP(t->fst_v.reserve(10 * ns));
+                fst.it = as_global(t->fst_i.p); fst.T = as_global(t->fst_i.p + ns); fst.pred = as_global(t->fst_i.p + 2 * ns);
+                fst.v = as_global(t->fst_v.p); fst.n_slots = (int64_t)ns;
+            }
+            t->last_first = use_first ? 1 : 0;
             auto enqueue_attempt = [&]() -> int {
                 hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
                                    t->volumes.p, m->n_cells, stg.static0 ? (int32_t)n_whole_waves : 0);
                 if (int rc = rec(1)) return rc;
+                if (use_first)
+                    hipLaunchKernelGGL(rt::k_first, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, m->d, t->d, prm, stg, fst);
                 if (n > 0 && split) {
                     hipStream_t ps = s;  // the stream the pieces march on
                     if (hybrid) {

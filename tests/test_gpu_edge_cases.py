@@ -424,3 +424,28 @@ def test_cheap_steps_keep_the_iteration_guard_exact(rt, orc, traced, iter_cap):
     vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
     assert np.allclose(dt.fetch_volumes(), vol, rtol=1e-10, atol=0)
     print(f"iter_cap={iter_cap}: {stats}, failing {int(np.count_nonzero(st))}")
+
+
+@pytest.mark.parametrize("n_azim,delta,mesh", [(32, 5e-3, "pincell"), (16, 0.02, "bwr")])
+def test_first_records_by_k_first(rt, orc, traced, oracle_run, n_azim, delta, mesh):
+    """Option "first" = 1 (off by default: measured slower): every track's first record by k_first — eight lanes
+    per track ahead of the march — must leave the same records, counts, status and volumes as the march's own first step,
+    including the tracks that end right behind their first record (their xp lies in the END band)."""
+    from raytracing_jl_amd import _capi
+
+    model = None if mesh == "pincell" else rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
+    tg = traced(n_azim, delta, model=model) if model is not None else traced(n_azim, delta)
+    ref = oracle_run(tg)
+    aq = tg.azimuthal_quadrature
+    for topo in (0, 1):
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        dm.set_option("split", 0); dm.set_option("first", 1); dm.set_option("topo", topo)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+        off, st = dt.fetch_offsets()
+        s = dt.fetch_segments()
+        assert np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and np.array_equal(s["element"], ref["element"])
+        for k in FIELDS:
+            assert np.array_equal(s[k], ref[k]), k
+        assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
+        dt.close(); dm.close()
