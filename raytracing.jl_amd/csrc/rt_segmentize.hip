@@ -1603,7 +1603,8 @@ struct rt_mesh {
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
     int sweep_debug = 0;
-    int first = 1;  // 1: every track's first record by k_first, eight lanes per track, ahead of the whole-track march
+    int first = 0;  // 1: every track's first record by k_first, eight lanes per track, ahead of the whole-track march.  Built,
+                    // parity-green, and measured SLOWER (C3: the march 178 -> 163 µs, k_first itself 50 µs): off
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
                            // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is
                            // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
