@@ -85,6 +85,7 @@ struct DOut {
     RT_G double *volumes;  // accumulated δs·ℓ per cell (un-normalised)
     const RT_G double *delta_s;
     int32_t fused_volumes;  // 1: accumulate δs·ℓ with global f64 atomics inside the fill march
+    int32_t dbg;            // development (option "compact_debug"): 1 the compaction stores nothing, 2 it loads nothing
     int64_t cap;            // records the six arrays can hold: the single-pass compaction does not write beyond (the host
                             // sizes them from an estimate, sees the true total afterwards, and compacts again if it was short)
 };
@@ -1088,6 +1089,7 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t sidx = stage_slot(c, i * 4 + rr, lane_q);
+            if (out.dbg & 2) { vx[i] = (double)sidx; vy[i] = 1.0; ve[i] = 1; continue; }
             vx[i] = __builtin_nontemporal_load(&stg.qx[sidx]);
             vy[i] = __builtin_nontemporal_load(&stg.qy[sidx]);
             ve[i] = __builtin_nontemporal_load(&stg.element[sidx]);
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
         }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (ro[g] >= 0) {
+            if (ro[g] >= 0 && !((out.dbg & 1) && rpx[g] != -1.25)) {
                 const int64_t o = ro[g];
                 // plain stores: the partial lines at the ends of a run wait in L2 for the sibling wave's half
                 // (nontemporal stores push them out half-written: +30 % compaction time)
@@ -1148,6 +1150,133 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
             }
         }
         __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
+    }
+}
+
+// k_compact3's stores are runs of 32 rows (256 B) per track and array, two runs per store instruction; on batches whose
+// records run to gigabytes (C5: 5 GB) they reach 3.75 TB/s while the loads alone run at 3.9 and a plain copy at 4.7-5.2.
+// k_compact4 (whole tracks) writes the SAME records in memory order: a workgroup still owns (march wave, quarter) = 16 tracks
+// and loads the same 4-KB staging blocks, four chunks = 128 rows per round, into track-major LDS tiles; after a barrier
+// its 256 threads walk the concatenation of the 16 tracks' rows of the round — for tracks of up to 128 records that IS the
+// workgroup's contiguous output span — so every store instruction writes 512 consecutive bytes and the four waves write
+// 2 KB side by side.  Position -> (track, row) is a rank among the 16 wave-uniform prefix sums.  Same values, same
+// expressions (p = previous q or the staged p of a marked row, ℓ = ‖p − q‖): bit-identical records.
+constexpr int kC4Rows = 4 * kChunkRows;   // rows per round
+constexpr int kC4Pitch = kC4Rows + 1;     // doubles per track in a tile: slot 0 = q of the row before the round, then the rows
+__global__ __launch_bounds__(256) void k_compact4(DTracks t, const int32_t *__restrict__ counts, const int64_t *__restrict__ offsets,
+                                                  DStage stg, DOut out, const int32_t *__restrict__ corder) {
+    static_assert(kChunkRows == 32, "k_compact4 moves 32-row chunks");
+    __shared__ double tiles_x[16 * kC4Pitch];
+    __shared__ double tiles_y[16 * kC4Pitch];
+    __shared__ int32_t tiles_e[16 * kC4Rows];
+    __shared__ int32_t s_cnt[16];
+    __shared__ int64_t s_off[16];
+    if (stg.cursor[1] != 0) return;  // pool overflow: this attempt is void
+    typedef __attribute__((address_space(3))) volatile double lds_f64;
+    typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
+    typedef __attribute__((address_space(3))) volatile int64_t lds_i64;
+    lds_f64 *tx = (lds_f64 *)tiles_x, *ty = (lds_f64 *)tiles_y;
+    lds_i32 *te = (lds_i32 *)tiles_e, *scnt = (lds_i32 *)s_cnt;
+    lds_i64 *soff = (lds_i64 *)s_off;
+    const int64_t w = corder ? corder[blockIdx.x >> 2] : (blockIdx.x >> 2);
+    const int q = blockIdx.x & 3;
+    const int tid = threadIdx.x, k = tid >> 6, lane = tid & 63, tl = lane & 15, rr = lane >> 4;
+    if (tid < 16) {
+        const int64_t slot = w * 64 + 16 * q + tid;
+        int32_t cnt = 0;
+        int64_t off = 0;
+        if (slot < t.n) {
+            const int32_t u = t.perm[slot];
+            cnt = counts[u];
+            off = offsets[u];
+        }
+        scnt[tid] = cnt; soff[tid] = off;
+    }
+    __syncthreads();
+    int32_t cnt16[16];  // wave-uniform: scalar registers
+    int32_t gmax = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        cnt16[j] = __builtin_amdgcn_readfirstlane(scnt[j]);
+        gmax = cnt16[j] > gmax ? cnt16[j] : gmax;
+    }
+    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
+    const int lane_q = 16 * q + tl;  // this lane's column of the march wave (load mapping)
+    for (int r0 = 0; r0 < gmax; r0 += kC4Rows) {
+        // ---- load: wave k moves chunk (r0 / 32) + k of the quarter into the tiles' rows 32 k ...
+        const int j = (r0 >> kChunkLog2) + k;
+        if ((j << kChunkLog2) < gmax) {
+            const int32_t c = ctab[j];
+            double vx[8], vy[8];
+            int32_t ve[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t sidx = stage_slot(c, i * 4 + rr, lane_q);
+                vx[i] = __builtin_nontemporal_load(&stg.qx[sidx]);
+                vy[i] = __builtin_nontemporal_load(&stg.qy[sidx]);
+                ve[i] = __builtin_nontemporal_load(&stg.element[sidx]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rl = 32 * k + i * 4 + rr;
+                tx[tl * kC4Pitch + 1 + rl] = vx[i];
+                ty[tl * kC4Pitch + 1 + rl] = vy[i];
+                te[tl * kC4Rows + rl] = ve[i];
+            }
+        }
+        if (r0 > 0 && tid < 16) {  // q of the row before this round's first
+            const int64_t sidx = stage_slot(ctab[(r0 >> kChunkLog2) - 1], kChunkRows - 1, 16 * q + tid);
+            tx[tid * kC4Pitch] = stg.qx[sidx]; ty[tid * kC4Pitch] = stg.qy[sidx];
+        }
+        __syncthreads();
+        // ---- store: position p of the concatenated rows of this round -> (track, row); gather first, then only stores
+        int32_t pre[17];  // wave-uniform prefix sums of the tracks' rows in this round
+        pre[0] = 0;
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) {
+            const int32_t left = cnt16[jt] - r0;
+            pre[jt + 1] = pre[jt] + (left < 0 ? 0 : (left > kC4Rows ? kC4Rows : left));
+        }
+        double rpx[8], rpy[8], rqx[8], rqy[8];
+        int32_t re[8];
+        int64_t ro[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int32_t p = tid + 256 * e;
+            ro[e] = -1;
+            if (p < pre[16]) {
+                int tt = 0;
+#pragma unroll
+                for (int jt = 1; jt < 16; ++jt) tt += p >= pre[jt] ? 1 : 0;
+                int32_t base = 0;
+#pragma unroll
+                for (int jt = 1; jt < 16; ++jt) base = p >= pre[jt] ? pre[jt] : base;
+                const int rl = p - base;            // row inside the round
+                const int64_t o = soff[tt] + r0 + rl;
+                ro[e] = o < out.cap ? o : -1;
+                rqx[e] = tx[tt * kC4Pitch + 1 + rl]; rqy[e] = ty[tt * kC4Pitch + 1 + rl];
+                rpx[e] = tx[tt * kC4Pitch + rl]; rpy[e] = ty[tt * kC4Pitch + rl];
+                re[e] = te[tt * kC4Rows + rl];
+                if (ro[e] >= 0 && re[e] < 0) {  // this record keeps its own entry point
+                    const int row = r0 + rl;
+                    const int64_t sidx = stage_slot(ctab[row >> kChunkLog2], row & (kChunkRows - 1), 16 * q + tt);
+                    rpx[e] = stg.px[sidx]; rpy[e] = stg.py[sidx];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (ro[e] >= 0) {
+                const int64_t o = ro[e];
+                out.px[o] = rpx[e];
+                out.py[o] = rpy[e];
+                out.qx[o] = rqx[e];
+                out.qy[o] = rqy[e];
+                out.ell[o] = norm2(rpx[e] - rqx[e], rpy[e] - rqy[e]);
+                out.element[o] = re[e] < 0 ? -re[e] : re[e];
+            }
+        }
+        __syncthreads();  // the tiles are rewritten by the next round
     }
 }
 
@@ -1602,7 +1731,8 @@ struct rt_mesh {
     int n_cus = 256;
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
-    int sweep_debug = 0;
+    int sweep_debug = 0, compact_debug = 0;
+    int compact_kernel = 0;  // 4: k_compact4 (memory-order stores) for whole-track batches; else k_compact3
     int first = 0;  // 1: every track's first record by k_first, eight lanes per track, ahead of the whole-track march.  Built,
                     // parity-green, and measured SLOWER (C3: the march 178 -> 163 µs, k_first itself 50 µs): off
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
@@ -1844,9 +1974,17 @@ int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out) {
 // Staged rows -> compact CSR records (k_compact3) for the plan of the last single-pass call.
 void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s) {
     const rt_tracks::CompactPlan &c = t->cplan;
-    if (t->n > 0 && !c.split_all && c.n_whole_waves > 0)
-        hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)c.n_whole_waves), dim3(256), 0, s, c.d_whole,
-                           (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg, out, c.sp, c.corder);
+    // k_compact4 (stores in memory order) was built for batches whose records run to gigabytes and measured no faster:
+    // C5 1.95 vs 1.84 ms, C4 0.270 vs 0.262, C3 0.149 vs 0.151 — it runs only on request (option "compact_kernel" = 4)
+    const bool use4 = t->mesh->compact_kernel == 4;
+    if (t->n > 0 && !c.split_all && c.n_whole_waves > 0) {
+        if (use4)
+            hipLaunchKernelGGL(rt::k_compact4, dim3(4u * (unsigned)c.n_whole_waves), dim3(256), 0, s, c.d_whole,
+                               (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg, out, c.corder);
+        else
+            hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)c.n_whole_waves), dim3(256), 0, s, c.d_whole,
+                               (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg, out, c.sp, c.corder);
+    }
     if (t->n > 0 && c.split)
         hipLaunchKernelGGL(rt::k_compact3<true>, dim3(4u * (unsigned)t->n_vwaves), dim3(256), 0, s, t->d,
                            (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg_pieces, out, c.sp, (const int32_t *)nullptr);
@@ -2040,6 +2178,8 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "compact_debug")) { mesh->compact_debug = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "compact_kernel")) { mesh->compact_kernel = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "first")) { mesh->first = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
@@ -2273,6 +2413,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     out.volumes = as_global(t->volumes.p);
     out.delta_s = as_global(t->delta_s.p);
     out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
+    out.dbg = m->compact_debug;
     rt::DStage stg{};
     rt::DSplit sp{};
     // Track pieces (DSplit): every wave of a batch too small to fill the chip, or — hybrid plan — only the longest waves

@@ -449,3 +449,28 @@ def test_first_records_by_k_first(rt, orc, traced, oracle_run, n_azim, delta, me
             assert np.array_equal(s[k], ref[k]), k
         assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
         dt.close(); dm.close()
+
+
+def test_compaction_in_memory_order_kernel(rt, traced, oracle_run):
+    """Option "compact_kernel" = 4: k_compact4 writes the records of a whole-track batch in memory order (built for batches whose
+    records run to gigabytes; measured no faster, so it only runs on request) — same records, bit for bit, incl. tracks
+    longer than one 128-row round and the re-compaction after an undersized output estimate."""
+    from raytracing_jl_amd import _capi
+
+    for n_azim, delta, extra in ((32, 5e-3, {}), (8, 2e-2, {"test_out_records": 1000})):
+        tg = traced(n_azim, delta)
+        ref = oracle_run(tg)
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        dm.set_option("split", 0); dm.set_option("compact_kernel", 4)
+        for k, v in extra.items():
+            dm.set_option(k, v)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        aq = tg.azimuthal_quadrature
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+        assert np.diff(ref["offsets"]).max() > 128  # some track spans more than one round
+        off, st = dt.fetch_offsets()
+        s = dt.fetch_segments()
+        assert np.array_equal(off, ref["offsets"]) and np.array_equal(s["element"], ref["element"])
+        for k in FIELDS:
+            assert np.array_equal(s[k], ref[k]), k
+        dt.close(); dm.close()
