@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 # and ℓ, and writes the 44-B record to its CSR position.
 BYTES_PER_SEGMENT = {"march": 45.0, "compact": 64.0, "scan": 0.0}
 STEP_BYTES_PER_SEGMENT = 45.0  # the whole step, by the same definition (what one segmentize! must at least move)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")
 
 WORKLOADS = {
     "c3": dict(mesh="pincell.msh", n_azim=128, delta=1e-3, name="BASELINE configs[2]: demo/pincell.msh, nφ=128, δ=1e-3"),
@@ -71,9 +71,9 @@ def pmc_traffic():
     try:
         d = json.load(open(PMC_SUMMARY))
         if d.get("lib_sha256") != lib_sha256():
-            return {}, "profiles/r02/pmc_summary.json was taken from another build of the library"
+            return {}, "profiles/r03/pmc_summary.json was taken from another build of the library"
         return ({k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in d["kernels"].items()
-                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r02/pmc_summary.json (same library, sha256 match)")
+                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r03/pmc_summary.json (same library, sha256 match)")
     except Exception as e:
         return {}, "no PMC summary: %r" % (e,)
 
@@ -104,14 +104,18 @@ def run_steps(rt, dt, tg, aq, n):
     return total, time.perf_counter() - t0
 
 
-def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=None):
+def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=None, e2e=False):
     """The given workload, unsharded, on one GPU: ms per step (host clock around K synchronous calls)."""
     tg = tg if tg is not None else make_tg(rt, wl)
     aq = tg.azimuthal_quadrature
+    t0 = time.perf_counter()
     dm = _capi.DeviceMesh(tg.mesh, device)
+    mesh_ms = (time.perf_counter() - t0) * 1e3
     if stream_ptr:
         dm.set_stream(stream_ptr)
+    t0 = time.perf_counter()
     dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    h2d_ms = (time.perf_counter() - t0) * 1e3
     run_steps(rt, dt, tg, aq, warmup)
     total, el = run_steps(rt, dt, tg, aq, steps)
     dm.set_option("timing", 1)
@@ -121,6 +125,13 @@ def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=Non
            "ms_per_step": el / steps * 1e3, "value": total * steps / el, "unit": "segments/s",
            "kernel_ms_last_step": {k: tm[k] for k in ("march", "scan", "compact", "total")},
            "device_GB_held_by_the_handle": dt.stats()["device_bytes"] / 1e9}
+    if e2e:
+        try:
+            out["e2e"] = boundary_costs(dt, total)
+            out["e2e"].update({"mesh_create_ms": mesh_ms, "mesh_prep_host_ms": dm.info()["prep_ms"], "tracks_h2d_ms": h2d_ms,
+                               "segmentize_ms": out["ms_per_step"]})
+        except Exception as e:  # pragma: no cover
+            out["e2e"] = {"error": repr(e)}
     dt.close()
     dm.close()
     return out
@@ -161,6 +172,27 @@ def two_in_flight(tg, aq, dmesh, dt, steps, segments_per_step):
                 "note": "two independent batches overlapped on two streams; not the headline value"}
     except Exception as e:  # pragma: no cover
         return {"error": repr(e)}
+
+
+def boundary_costs(dt, total):
+    """What the boundary adds around one step when the caller wants host arrays (never part of `value`): all eight result
+    arrays through the handle's page-locked buffers in one call (rt_fetch_pinned), and the older pair of calls beside it."""
+    dt.fetch_pinned()  # first use pins the buffers (one-time)
+    a = time.perf_counter()
+    dt.fetch_pinned()
+    all_ms = (time.perf_counter() - a) * 1e3
+    a = time.perf_counter()
+    dt.fetch_segments_pinned()
+    seg_ms = (time.perf_counter() - a) * 1e3
+    a = time.perf_counter()
+    dt.fetch_offsets()
+    off_ms = (time.perf_counter() - a) * 1e3
+    return {"fetch_pinned_all_ms": all_ms, "fetch_offsets_status_ms": max(all_ms - seg_ms, 0.0), "fetch_records_pinned_ms": seg_ms,
+            "fetch_offsets_pageable_ms": off_ms, "fetch_GBs": 44.0 * total / (all_ms * 1e-3) / 1e9 if all_ms > 0 else 0.0,
+            "note": "one call as the shim sees it: rt_mesh_create (once per mesh), rt_tracks_create (H2D of the track arrays), rt_segmentize, "
+                    "rt_fetch_pinned (offsets, status and the 44-B records over PCIe into page-locked buffers, one synchronisation); "
+                    "fetch_offsets_status_ms = what offsets + status add to the records' copy; fetch_offsets_pageable_ms = the older "
+                    "rt_fetch_offsets into fresh pageable arrays"}
 
 
 def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
@@ -468,18 +500,8 @@ def _main(real_stdout):
         a = time.perf_counter()
         dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
         seg_ms = (time.perf_counter() - a) * 1e3
-        dt.fetch_segments_pinned()  # first use pins the buffers (one-time)
-        a = time.perf_counter()
-        dt.fetch_segments_pinned()
-        fetch_ms = (time.perf_counter() - a) * 1e3
-        a = time.perf_counter()
-        dt.fetch_offsets()
-        off_ms = (time.perf_counter() - a) * 1e3
-        e2e = {"mesh_create_ms": mesh_create_ms, "mesh_prep_host_ms": info["prep_ms"], "tracks_h2d_ms": tracks_h2d_ms,
-               "segmentize_ms": seg_ms, "fetch_pinned_ms": fetch_ms, "fetch_offsets_status_ms": off_ms,
-               "fetch_GBs": 44.0 * local_total / (fetch_ms * 1e-3) / 1e9 if fetch_ms > 0 else 0.0,
-               "note": "one call as the shim sees it: rt_mesh_create (once per mesh), rt_tracks_create (H2D of the track arrays), "
-                       "rt_segmentize, rt_fetch_segments_pinned (D2H of the 44-B records over PCIe) — never part of `value`"}
+        e2e = boundary_costs(dt, local_total)
+        e2e.update({"mesh_create_ms": mesh_create_ms, "mesh_prep_host_ms": info["prep_ms"], "tracks_h2d_ms": tracks_h2d_ms, "segmentize_ms": seg_ms})
     downstream_sweep = None
     if rank == 0 and not args.no_extras and not dist_on:
         try:
@@ -508,7 +530,7 @@ def _main(real_stdout):
         sync()
     if rank == 0 and not args.no_extras and world == 1 and not dist_on and wkey == "c3":
         try:
-            config5 = single_gpu_run(rt, _capi, WORKLOADS["c5"], local_rank, 5, 2, stream.cuda_stream)
+            config5 = single_gpu_run(rt, _capi, WORKLOADS["c5"], local_rank, 5, 2, stream.cuda_stream, e2e=True)
         except Exception as e:  # pragma: no cover
             config5 = {"error": repr(e)}
 

@@ -1619,6 +1619,15 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                     return __builtin_amdgcn_readlane(v, j & 63);
                 };
                 struct Row { double qx, qy; int32_t el; };
+                // the chunk id of a row is looked up only when the row stream enters another 32-row chunk (two streams: the row
+                // being evaluated and the one being prefetched); both lookups stay in scalar registers
+                int cj0 = -1, cj2 = -1;
+                int32_t cid0 = 0, cid2 = 0;
+                auto slot_cached = [&](const int r, int &cj, int32_t &cid) -> int64_t {
+                    const int j = r >> kChunkLog2;
+                    if (j != cj) { cj = j; cid = chunk_of(r); }  // (uniform)
+                    return stage_slot(cid, r & (kChunkRows - 1), lane);
+                };
                 auto slot_of = [&](const int r) -> int64_t { return stage_slot(chunk_of(r), r & (kChunkRows - 1), lane); };
                 auto load_row = [&](const int r) -> Row {
                     const int64_t sl = slot_of(r);
@@ -1635,9 +1644,10 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                     // entry point: staged for marked records (cell < 0: first record of a track, records of the generic step),
                     // else the previous record's exit point — forward the row before, backward the NEXT step's row
                     double px = dir ? R1.qx : lqx, py = dir ? R1.qy : lqy;
-                    const int64_t sl0 = slot_of(r);  // (outside the branch: see chunk_of)
+                    const int64_t sl0 = slot_cached(r, cj0, cid0);  // (outside the branch: see chunk_of)
                     if (act && R0.el < 0) { px = a.stg.px[sl0]; py = a.stg.py[sl0]; }
-                    const Row R2 = load_row(row_of(t + 2));
+                    const int64_t sl2 = slot_cached(row_of(t + 2), cj2, cid2);
+                    const Row R2{a.stg.qx[sl2], a.stg.qy[sl2], a.stg.element[sl2]};
                     double st1[GP], qs1[GP];
                     load_xs(cell_of(R1, row_of(t + 1)), st1, qs1);
                     const double ell = norm2(px - R0.qx, py - R0.qy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
@@ -3009,7 +3019,10 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     if (!a.use_lds) gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
     if (m->sweep_gp >= 8) a.use_lds = 0;  // experiment: tallies straight to HBM (measured 4x slower at C3: 2.1 ms against 0.48)
     const size_t smem = a.use_lds ? (size_t)m->n_cells * gp * sizeof(double) : 0;
-    int W = smem > 79 * 1024 ? 16 : 8;  // one workgroup per CU: sixteen waves; else two or more workgroups of eight
+    // one workgroup per CU (its tallies fill the LDS): sixteen waves when the rows are the staging rows (every load
+    // instruction reads four full lines), eight when they are the compact records (64 lanes, 64 lines: sixteen waves
+    // thrash the CU's L1 — 1.04 against 0.62 ms at C3); two or more workgroups per CU: eight waves each
+    int W = (smem > 79 * 1024 && staged) ? 16 : 8;
     if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
     const unsigned blocks = (unsigned)((2 * (int64_t)a.n_waves + W - 1) / W);
     RT_HIP(hipEventRecord(t->ev[0], s));
