@@ -1299,12 +1299,15 @@ __global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restr
 // total, and — host_copy, optional — copies the 32-word control block to pinned host memory: the march (and
 // k_resolve) are over when this kernel runs, so `total`, the failure summary and the pool cursor are final
 // and the call needs no device-to-host copy after its last kernel.
+// ctl_next (optional): the OTHER control block — calls alternate between two — is reset here for the next call (cursor behind
+// `first_chunk_next` reserved chunks), so that a call needs no reset kernel in front of its march.
 __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__restrict__ counts, int64_t n,
                                                                int64_t *__restrict__ tile_sums, int64_t n_tiles,
                                                                int64_t *__restrict__ total,
                                                                unsigned int *__restrict__ ticket,
                                                                const unsigned long long *__restrict__ ctl,
-                                                               unsigned long long *__restrict__ host_copy) {
+                                                               unsigned long long *__restrict__ host_copy,
+                                                               unsigned long long *__restrict__ ctl_next, int32_t first_chunk_next) {
     __shared__ int64_t red[kScanBlock / 64];
     __shared__ int64_t carry;
     __shared__ int last;
@@ -1352,6 +1355,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
         __threadfence();
         if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __builtin_nontemporal_load(&ctl[threadIdx.x]);
     }
+    if (ctl_next && threadIdx.x < kCtlWords) {
+        const int i = threadIdx.x;
+        ctl_next[i] = i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk_next : 0ull);
+    }
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__restrict__ counts, int64_t n,
@@ -1359,11 +1366,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__rest
                                                            const int64_t *__restrict__ total,
                                                            int64_t *__restrict__ offsets,
                                                            double *__restrict__ volumes, int32_t n_cells,
-                                                           double n_azim_2) {
-    // volumes ./= n_azim_2 (src/trackgenerator.jl:386) rides along when fill_volumes was fused into the march
+                                                           double n_azim_2, double *__restrict__ vacc) {
+    // volumes ./= n_azim_2 (src/trackgenerator.jl:386) rides along when fill_volumes was fused into the march: the march
+    // accumulated into `vacc`, which is read, scaled into `volumes` and left ZERO for the next call's march
     if (volumes)
-        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += gridDim.x * blockDim.x)
-            volumes[c] = volumes[c] / n_azim_2;
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += gridDim.x * blockDim.x) {
+            volumes[c] = vacc[c] / n_azim_2;
+            vacc[c] = 0.0;
+        }
     __shared__ int64_t wsum[kScanBlock / 64];
     const int64_t i0 = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
     int64_t c[kScanPer];
@@ -1785,11 +1795,17 @@ struct rt_tracks {
     DevBuf<int64_t> offsets, tile_sums;
     // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag,
     // 20 ticket of the scan's "last block" step, 21 tracks that reached MAX_ITER segments in split mode
-    DevBuf<unsigned long long> ctl;
+    DevBuf<unsigned long long> ctl;  // two blocks of kCtlWords: calls alternate, each call's scan resets the other block
+    int ctl_idx = 0;                 // block of the next call
+    bool ctl_clean[2] = {false, false};
+    int32_t ctl_first_chunk[2] = {-1, -1};  // ... reset with this many reserved chunks
+    DevBuf<double> vacc;             // fused fill_volumes accumulates here; k_scan_write scales it into `volumes` and zeroes it
+    bool vacc_clean = false;
 #ifdef RT_TIMING
     DevBuf<unsigned long long> dbg;
 #endif
     unsigned long long *h_ctl = nullptr;  // pinned: [0..63] init image, [64..127] read-back
+    unsigned long long *h_res_dev = nullptr;  // device address of the read-back half
     DevBuf<double> spx, spy, sqx, sqy, sell, volumes, delta_s;
     DevBuf<double> tau, sigma_t;  // rt_fill_tau
     int32_t tau_groups = 0;
@@ -2017,7 +2033,7 @@ void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->perm_whole.release(); t->corder.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
-    t->tile_sums.release(); t->ctl.release();
+    t->tile_sums.release(); t->ctl.release(); t->vacc.release();
 #ifdef RT_TIMING
     t->dbg.release();
 #endif
@@ -2399,18 +2415,30 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     RT_HIP(t->status.reserve(n + 1));
     RT_HIP(t->offsets.reserve(n + 1));
     RT_HIP(t->tile_sums.reserve(n_tiles + 1));
-    RT_HIP(t->ctl.reserve(rt::kCtlWords));
+    RT_HIP(t->ctl.reserve(2 * rt::kCtlWords));
+    RT_HIP(t->vacc.reserve(m->n_cells));
     if (!t->h_ctl) {
         RT_HIP(hipHostMalloc((void **)&t->h_ctl, 2 * rt::kCtlWords * sizeof(unsigned long long), hipHostMallocDefault));
         for (int i = 0; i < 2 * rt::kCtlWords; ++i) t->h_ctl[i] = 0;
         t->h_ctl[1] = ~0ull;  // first failing uid: atomicMin target
     }
-    unsigned long long *const d_fail = t->ctl.p;
-    int64_t *const d_total = reinterpret_cast<int64_t *>(t->ctl.p + 16);
-    int32_t *const d_cursor = reinterpret_cast<int32_t *>(t->ctl.p + 18);
+    // the call's control block: calls alternate between two, and the scan of a call resets the other one for the next call —
+    // in the steady state no reset kernel runs in front of the march (its launch gap was 5 µs of every step)
+    const int cb = t->ctl_idx;
+    unsigned long long *const d_ctl = t->ctl.p + (size_t)cb * rt::kCtlWords;
+    unsigned long long *const d_ctl_other = t->ctl.p + (size_t)(1 - cb) * rt::kCtlWords;
+    const bool ctl_was_clean = t->ctl_clean[cb];
+    const int32_t ctl_was_first = t->ctl_first_chunk[cb];
+    const bool vacc_was_clean = t->vacc_clean;
+    t->ctl_clean[0] = t->ctl_clean[1] = false;  // (set again when this call has succeeded)
+    t->vacc_clean = false;
+    unsigned long long *const d_fail = d_ctl;
+    int64_t *const d_total = reinterpret_cast<int64_t *>(d_ctl + 16);
+    int32_t *const d_cursor = reinterpret_cast<int32_t *>(d_ctl + 18);
     unsigned long long *const h_res = t->h_ctl + rt::kCtlWords;
-    unsigned long long *h_res_dev = nullptr;  // the same pinned block as the device sees it (k_scan_tile_sums writes it)
-    RT_HIP(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
+    // the same pinned block as the device sees it (k_scan_tile_sums writes it); looked up once per handle
+    if (!t->h_res_dev) RT_HIP(hipHostGetDevicePointer((void **)&t->h_res_dev, h_res, 0));
+    unsigned long long *const h_res_dev = t->h_res_dev;
     std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
     RT_HIP(t->volumes.reserve(m->n_cells));
     if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
@@ -2420,7 +2448,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
     rt::DOut out{};
     using rt::as_global;
-    out.volumes = as_global(t->volumes.p);
+    out.volumes = as_global(t->volumes.p);  // (single pass with fused fill_volumes: the accumulator `vacc`, see below)
     out.delta_s = as_global(t->delta_s.p);
     out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
     out.dbg = m->compact_debug;
@@ -2463,14 +2491,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
     // copy_out: k_scan_tile_sums' last block also writes the control block to the pinned host copy; scale: k_scan_write also
     // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
+    int32_t first_chunk_this_call = 0;
     auto scan_counts = [&](bool copy_out, bool scale) -> int {
         if (n > 0) {
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
-                               t->tile_sums.p, n_tiles, d_total, reinterpret_cast<unsigned int *>(t->ctl.p + 20),
-                               (const unsigned long long *)t->ctl.p, copy_out ? h_res_dev : (unsigned long long *)nullptr);
+                               t->tile_sums.p, n_tiles, d_total, reinterpret_cast<unsigned int *>(d_ctl + 20),
+                               (const unsigned long long *)d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
+                               copy_out ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, d_total, t->offsets.p, scale ? t->volumes.p : (double *)nullptr, m->n_cells,
-                               (double)n_azim_2);
+                               (double)n_azim_2, t->vacc.p);
         } else {
             RT_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
             RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
@@ -2600,9 +2630,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 fst.v = as_global(t->fst_v.p); fst.n_slots = (int64_t)ns;
             }
             t->last_first = use_first ? 1 : 0;
+            // fused fill_volumes accumulates into `vacc` (zero between calls: k_scan_write leaves it so); otherwise the separate
+            // pass adds into `volumes`, zeroed here.  The reset kernel runs only when the control block or the accumulator is
+            // not known to be clean: a handle's first call, a re-run after a pool overflow, a changed number of reserved chunks.
+            first_chunk_this_call = stg.static0 ? (int32_t)n_whole_waves : 0;
+            if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
+            const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != first_chunk_this_call || !(fuse && n > 0 && vacc_was_clean);
             auto enqueue_attempt = [&]() -> int {
-                hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, t->ctl.p,
-                                   t->volumes.p, m->n_cells, stg.static0 ? (int32_t)n_whole_waves : 0);
+                if (need_reset)
+                    hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, d_ctl,
+                                       (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk_this_call);
                 if (int rc = rec(1)) return rc;
                 if (use_first)
                     hipLaunchKernelGGL(rt::k_first, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, m->d, t->d, prm, stg, fst);
@@ -2662,7 +2699,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             };
             if (int rc_enq = enqueue_attempt()) return rc_enq;
             int32_t cur[4] = {0, 0, 0, 0};
-            if (n == 0) RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            if (n == 0) RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
             RT_HIP(wait_stream(s));
             memcpy(fi, h_res, sizeof(fi));
@@ -2704,12 +2741,21 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 t->force_unsplit = true;
                 return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
             }
-            if (!cur[1]) { t->cplan.staged = true; if (do_compact) t->compacted = true; break; }
+            if (!cur[1]) {
+                t->cplan.staged = true;
+                if (do_compact) t->compacted = true;
+                if (n > 0) {  // this call's scan has reset the other control block and (fused) left the accumulator zero
+                    t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = first_chunk_this_call;
+                    t->vacc_clean = fuse;
+                    t->ctl_idx = 1 - cb;
+                }
+                break;
+            }
             if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
             want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
         }
     } else {
-        RT_HIP(hipMemcpyAsync(t->ctl.p, t->h_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        RT_HIP(hipMemcpyAsync(d_ctl, t->h_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         if (int rc = rec(1)) return rc;
         if (n > 0) {
             if (int rc = widek ? march.template operator()<rt::kCount, 1, false, true>(grid, sizeof(int32_t))
@@ -2718,7 +2764,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         if (int rc = rec(2)) return rc;
         if (int rc = scan_counts(false, false)) return rc;
         if (int rc = rec(3)) return rc;
-        RT_HIP(hipMemcpyAsync(h_res, t->ctl.p, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if (m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);  // (the count march is the longer half of this mode)
         RT_HIP(hipStreamSynchronize(s));
         memcpy(fi, h_res, sizeof(fi));

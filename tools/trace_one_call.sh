@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel trace of a few rt_segmentize calls (default options): per-kernel start / end of the last call, to see overlap.
+# rocprofv3 kernel trace of a few rt_segmentize calls (tools/exp_calls.py: default options, no HIP events between the kernels): per-kernel start / end of the last call, to see overlap.
 # usage (GPU box): bash tools/trace_one_call.sh <out_subdir> [gpu_modes args]
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/gpu_modes.py "$@" > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/exp_calls.py "$@" > $OUT/trace.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/trace/*/*kernel_trace.csv"))[-1]
