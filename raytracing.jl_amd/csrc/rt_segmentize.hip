@@ -1580,9 +1580,11 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                 wd[g] = w * d;
             }
             // Neighbouring lanes are neighbouring parallel tracks: at the same row most of them are in the same cell, and
-            // atomics of one wave instruction to one address are served one lane at a time (measured: the tallies were 40 %
-            // of the sweep).  Lanes of an aligned group of 2, 4, 8, 16 with equal cells are therefore summed first — four DPP
-            // row shifts, no LDS traffic — and only the lanes left over add to the tally.
+            // atomics of one wave instruction to one address are served one lane at a time (measured at C3: the tallies were
+            // 0.21 of the sweep's 0.62 ms).  Lanes of an aligned pair, then quad, with equal cells are therefore summed first —
+            // two DPP row shifts, no LDS traffic — and only the lanes left over add to the tally.  The sweep is bound by
+            // instruction issue, so folding further costs more than the atomics it saves: over 2 / 4 / 8 / 16 lanes the
+            // sweep took 0.440 / 0.438 / 0.466 / 0.494 ms (0.414 without any tally).
             bool mine = act;
             if (!(a.debug & 2)) {
                 const int32_t key = act ? e : -1 - lane;  // (an inactive lane matches nobody)
@@ -1602,7 +1604,7 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                     }
                     mine = mine && !given;
                 };
-                fold.template operator()<1>(); fold.template operator()<2>(); fold.template operator()<4>(); fold.template operator()<8>();
+                fold.template operator()<1>(); fold.template operator()<2>();
             }
             if (mine && !(a.debug & 1)) {
 #pragma unroll

@@ -58,6 +58,15 @@ def test_allgather_on_every_device_and_failures(rt, traced, oracle_run):
         for a, k in enumerate(FIELDS):
             t = torch.as_tensor(rtd.DevArray(ptrs[i][a], md.total, "<i4" if k == "element" else "<f8", md), device=dev)
             assert np.array_equal(t.cpu().numpy(), ref[k]), (i, k)
+    # every (destination, source) pair ran on its own stream: a rate per pair, none for an empty shard, and a second
+    # all-gather (buffers and streams reused) gives the same arrays
+    rates = md.link_rates()
+    _, sb = md.shards()
+    assert rates.shape == (3, 3) and np.all((rates > 0) == (np.diff(sb) > 0)[None, :])
+    ms2, ptrs2 = md.allgather()
+    assert ptrs2 == ptrs
+    t = torch.as_tensor(rtd.DevArray(ptrs2[2][4], md.total, "<f8", md), device=dev)
+    assert np.array_equal(t.cpu().numpy(), ref["ell"])
     md.close()
     # the Σℓ check of one track in the last shard fails: global uid, reference status
     ell = tg.ell.copy()

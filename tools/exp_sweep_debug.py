@@ -12,7 +12,7 @@ tg = rt.TrackGenerator(model, na, d, bcs=rt.BoundaryConditions(top=rt.Reflective
 rt.trace(tg); aq = tg.azimuthal_quadrature; nc = tg.mesh.num_cells; G = 7
 sig = np.linspace(0.2, 1.6, nc * G).reshape(nc, G); src = np.linspace(0.0, 1.0, nc * G).reshape(nc, G)
 ref = None
-for gp, dbg, waves in ((0, 0, 16), (0, 0, 8), (8, 0, 16), (8, 0, 8), (8, 0, 4), (8, 1, 8), (8, 2, 8), (0, 1, 16), (0, 2, 16)):
+for gp, dbg, waves in ((0, 0, 16), (0, 0, 8), (0, 2, 16), (0, 1, 16), (1, 0, 16), (2, 0, 16), (8, 0, 16)):  # debug: 2 = no pre-reduction of the tallies, 1 = no tallies; gp 8 = tallies straight to HBM
     dm = _capi.DeviceMesh(tg.mesh, 0); dm.set_option("compact", 0); dm.set_option("sweep_debug", dbg); dm.set_option("sweep_waves", waves); dm.set_option("sweep_gp", gp)
     dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
     total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2); dt.sweep_set_links(tg)
