@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
 #pragma unroll
             for (int g = 0; g < GP; ++g) {
                 const double tau = st[g] * ell;
-                const double ex = -expm1(-tau);
+                const double ex = one_minus_exp_neg(tau);  // −expm1(−τ) to within an ulp (rt_device.hpp)
                 const double d = (psi[g] - qs[g]) * ex;
                 psi[g] = act ? psi[g] - d : psi[g];
                 wd[g] = w * d;

@@ -296,6 +296,11 @@ int32_t hostmarch_prep(const double *x, const double *y, int32_t n_nodes, const 
     return 0;
 }
 
+// rt_sweep's attenuation factor 1 - exp(-tau) (rt_device.hpp, one_minus_exp_neg), for its accuracy test.
+void hostmarch_one_minus_exp_neg(const double *tau, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = rt::one_minus_exp_neg(tau[i]);
+}
+
 // bf16_up / bf16_value of the preprocessing (the cheap step's four per-record constants are stored as bfloat16 rounded UP).
 void hostmarch_bf16(const double *v, int64_t n, uint16_t *pattern, double *value) {
     for (int64_t i = 0; i < n; ++i) { pattern[i] = rtprep::bf16_up(v[i]); value[i] = rtprep::bf16_value(pattern[i]); }

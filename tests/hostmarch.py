@@ -39,6 +39,7 @@ def lib():
         L.hostmarch_prep.restype = C.c_int32
         L.hostmarch_prep.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip, _ip, _ip, _dp, C.c_char_p, C.c_int32]
         L.hostmarch_bf16.argtypes = [_dp, C.c_int64, C.POINTER(C.c_uint16), _dp]
+        L.hostmarch_one_minus_exp_neg.argtypes = [_dp, C.c_int64, _dp]
         L.hostmarch_topo.restype = C.c_int32
         L.hostmarch_topo.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip] + [_dp] * 6
         _lib = L
@@ -130,4 +131,12 @@ def topo_records(mesh):
     lib().hostmarch_topo(p(x, _dp), p(y, _dp), len(x), p(cn, _ip), nc, p(bb, _dp), p(extras, _ip), *[p(a, _dp) for a in arr], p(sc, _dp))
     out = dict(extras=extras.reshape(nc, 3), **{k: a.reshape(nc, 3) for k, a in zip(("E", "g1", "k2", "dtf", "lc"), arr)})
     out.update(tiny_max=sc[0], rmax=sc[1], end_err=sc[2], l_min=sc[3], d_vertex=sc[4], on=bool(sc[5]))
+    return out
+
+
+def one_minus_exp_neg(tau):
+    """rt::one_minus_exp_neg (rt_device.hpp): the sweep's 1 - exp(-tau), evaluated on the host."""
+    tau = _f(tau)
+    out = np.zeros(len(tau))
+    lib().hostmarch_one_minus_exp_neg(tau.ctypes.data_as(_dp), len(tau), out.ctypes.data_as(_dp))
     return out

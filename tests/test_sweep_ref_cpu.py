@@ -38,3 +38,21 @@ def test_linking_is_a_permutation_for_reflective_and_zero_for_vacuum(rt, pincell
             assert not nxt.any()
         else:  # every entry receives exactly one outgoing flux (the tracks form closed cycles, src/track.jl:36-38)
             assert np.array_equal(np.sort(nxt.ravel()), out.ravel())
+
+
+def test_attenuation_factor_is_accurate_to_an_ulp():
+    """rt_sweep evaluates 1 − e^{−τ} with its own routine (rt_device.hpp, one_minus_exp_neg: fewer issue cycles than the device
+    library's expm1); here it runs on the host against numpy's expm1 over the whole range of optical lengths — denormal to
+    beyond the point where the result is 1 — and across the range-reduction boundaries."""
+    import hostmarch as hm
+
+    rng = np.random.default_rng(5)
+    k = np.arange(1, 61)
+    edges = np.concatenate([(k - 0.5) * np.log(2.0), np.nextafter((k - 0.5) * np.log(2.0), 0), np.nextafter((k - 0.5) * np.log(2.0), 100)])
+    tau = np.concatenate([10.0 ** rng.uniform(-310, 2, 200000), rng.uniform(0, 2, 200000), rng.uniform(0, 60, 100000), edges,
+                          [0.0, 5e-324, 41.4999, 41.5, 41.5001, 700.0, 1e300]])
+    got = hm.one_minus_exp_neg(tau)
+    ref = -np.expm1(-tau)
+    assert np.all(got >= 0) and np.all(got <= 1)
+    assert np.all(np.abs(got - ref) <= 4.5e-16 * ref)  # 2 ulp of headroom over numpy's own rounding
+    assert got[tau == 0.0][0] == 0.0 and got[-1] == 1.0
