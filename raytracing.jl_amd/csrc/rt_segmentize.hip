@@ -159,7 +159,7 @@ struct DSplit {
     int32_t n_vwaves;
 };
 
-// The Σℓ check `isapprox(track.ℓ, sum(ℓ.(segments)); rtol)` (src/track.jl:171) is decided here — and in the oracle — with a
+// The Σℓ check `isapprox(track.ℓ, sum(ℓ.(segments)); rtol)` (src/track.jl:171) is decided here (and in the CPU checker) with a
 // left-to-right sum; Julia's `sum` reassociates (pairwise blocks, @simd lanes), so its Σℓ can differ by a few ulp·n.  A
 // track whose |ℓ − Σℓ| lies within 64·ulp·n·max(ℓ, Σℓ) of the threshold rtol·max(ℓ, Σℓ) could get the other status there:
 // such tracks are counted (rt_last_stats) so that a caller knows when this cannot be pinned.
