@@ -1754,6 +1754,7 @@ struct rt_mesh {
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
     int sweep_debug = 0, compact_debug = 0;
+    int march_waves = 0;     // 4 / 6: waves per workgroup of the fused march (0: automatic)
     int compact_kernel = 0;  // 4: k_compact4 (memory-order stores) for whole-track batches; else k_compact3
     int first = 0;  // 1: every track's first record by k_first, eight lanes per track, ahead of the whole-track march.  Built,
                     // parity-green, and measured SLOWER (C3: the march 178 -> 163 µs, k_first itself 50 µs): off
@@ -2208,6 +2209,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_debug")) { mesh->compact_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_kernel")) { mesh->compact_kernel = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "march_waves")) { mesh->march_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "first")) { mesh->first = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
@@ -2387,8 +2389,16 @@ void rt_tracks_destroy(rt_tracks *tracks) {
     free_tracks(tracks);
 }
 
+#ifdef RT_HOST_TIMING
+static double g_ht[6];
+static long g_hn;
+static inline double ht_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#endif
 static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s,
                       int32_t n_azim_2) {
+#ifdef RT_HOST_TIMING
+    const double ht0 = ht_now();
+#endif
     if (!t || !delta_s || n_azim_2 <= 0) { set_error("rt_segmentize: bad arguments"); return RT_ERR_INVALID; }
     if (k < 0) {  // knn(kdtree, x, k, ...) rejects a negative k (src/mesh.jl:123); any k >= 0 is honoured
         set_error("rt_segmentize: k = %d (must be >= 0)", k);
@@ -2461,7 +2471,8 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     // usual k; a call that cannot use it (or any plan, once a track reached MAX_ITER segments) marches every track whole.
     const bool widek_ = k > rt::kMaxK;
     const size_t hist_bytes_ = (size_t)m->n_cells * sizeof(double);
-    const int fuse_waves_ = (3 * (hist_bytes_ + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || (n + 63) / 64 > 3072) ? 4 : 6;
+    int fuse_waves_ = (3 * (hist_bytes_ + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || (n + 63) / 64 > 3072) ? 4 : 6;
+    if (m->march_waves == 4 || m->march_waves == 6) fuse_waves_ = m->march_waves;  // (experiments)
     const bool fuse_ = m->volumes_mode == 2 && m->fuse_volumes && 2 * (hist_bytes_ + fuse_waves_ * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 && !widek_;
     // Option "compact" = 0: stop after march + scan (a device-resident consumer, rt_sweep, reads the staged rows); the separate
     // volumes pass needs the compact records, so a call that cannot fuse fill_volumes compacts anyway.  Whole tracks only.
@@ -2699,11 +2710,24 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
                 return RT_SUCCESS;
             };
+#ifdef RT_HOST_TIMING
+            const double ht1 = ht_now();
+#endif
             if (int rc_enq = enqueue_attempt()) return rc_enq;
+#ifdef RT_HOST_TIMING
+            const double ht2 = ht_now();
+#endif
             int32_t cur[4] = {0, 0, 0, 0};
             if (n == 0) RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
             RT_HIP(wait_stream(s));
+#ifdef RT_HOST_TIMING
+            {
+                const double ht3 = ht_now();
+                g_ht[0] += ht1 - ht0; g_ht[1] += ht2 - ht1; g_ht[2] += ht3 - ht2; ++g_hn;
+                if (g_hn % 50 == 0) fprintf(stderr, "[rt host] per call: before enqueue %.1f us, enqueue %.1f us, wait %.1f us\n", g_ht[0] / g_hn, g_ht[1] / g_hn, g_ht[2] / g_hn);
+            }
+#endif
             memcpy(fi, h_res, sizeof(fi));
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
