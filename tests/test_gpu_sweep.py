@@ -139,3 +139,43 @@ def test_sweep_argument_errors(rt, traced):
     with pytest.raises(_capi.RtError, match="bad link"):
         dt.sweep_set_links(bad)
     dt.close(); dm.close()
+
+
+@pytest.mark.parametrize("mesh,n_azim,delta", [("pincell.msh", 128, 1e-3), ("bwr_like.msh", 64, 2e-3)])
+def test_sweep_properties_at_full_size(rt, mesh, n_azim, delta):
+    """BASELINE configs[2] and [3] (9.3 M and 14.3 M segments), where the sequential checker would take minutes: properties that do
+    not depend on the size.  (a) A flat source in equilibrium with the incoming flux (ψ = q/Σt everywhere) is a fixed point: nothing
+    is attenuated, nothing is tallied, every traversal ends with what it started with.  (b) A pure absorber is in balance: what the
+    tallies hold is what the traversals lost, Σ φ = Σ w·(ψ_in − ψ_out), and with Σt uniform ψ_out = ψ_in·exp(−Σt·ℓ_track) — the
+    records of a track add up to its length (src/track.jl:171).  (c) Both inputs — compact records and staging rows — give the same
+    fluxes bit for bit (same ℓ, same order) and the same tallies to rounding."""
+    from raytracing_jl_amd import _capi
+
+    model = rt.GmshDiscreteModel(rt.data_path(mesh))
+    tg = rt.TrackGenerator(model, n_azim, delta, bcs=_bcs(rt, "reflective"))
+    rt.trace(tg)
+    n, nc, G = tg.n_total_tracks, tg.mesh.num_cells, 7
+    rng = np.random.default_rng(2)
+    sigma_t = rng.uniform(0.05, 3.0, (nc, G))
+    level = rng.uniform(0.5, 2.0, G)
+    w = rng.uniform(0.5, 1.5, n)
+    dm, dt = _device(rt, tg, 0)
+    # (a)
+    r = dt.sweep(G, sigma_t, sigma_t * level, w, np.broadcast_to(level, (2, n, G)).copy(), input="staged")
+    assert np.abs(r["psi_out"] - level).max() <= 1e-13 * level.max() and np.abs(r["phi"]).max() <= 1e-10
+    # (b)
+    psi_in = rng.uniform(0.5, 1.5, (2, n, G))
+    st = np.broadcast_to(np.linspace(0.3, 1.1, G), (nc, G)).copy()
+    r = dt.sweep(G, st, np.zeros((nc, G)), w, psi_in, input="staged")
+    lost = (w[None, :, None] * (psi_in - r["psi_out"])).sum(axis=(0, 1))
+    assert np.allclose(r["phi"].sum(axis=0), lost, rtol=1e-11)
+    off, status = dt.fetch_offsets()
+    good = status == 0  # (a track on which the reference's own Σℓ check fails misses a sliver: its Σℓ is not its length)
+    expect = psi_in[:, good, :] * np.exp(-st[0][None, None, :] * tg.ell[good][None, :, None])
+    assert np.allclose(r["psi_out"][:, good, :], expect, rtol=1e-6)  # Σℓ ≈ ℓ to rtol = √eps, times Σt·ℓ ≤ 10
+    # (c)
+    rc = dt.sweep(G, st, np.zeros((nc, G)), w, psi_in, input="compact")
+    assert np.array_equal(rc["psi_out"], r["psi_out"]) and np.array_equal(rc["psi_next"], r["psi_next"])
+    assert np.allclose(rc["phi"], r["phi"], rtol=1e-11, atol=1e-300)
+    print(f"{mesh} nφ={n_azim} δ={delta}: {dt.total} segments, staged {r['ms']:.3f} ms ({r['passes']} passes of {r['groups_per_pass']}), compact {rc['ms']:.3f} ms")
+    dt.close(); dm.close()
