@@ -5,7 +5,8 @@
  * types: dlopen of the library by path (what Julia's `ccall((:sym, LIB), ...)` does), 1-based CSR `ptrs` as
  * Gridap's Table holds them, rt_mesh_create -> rt_tracks_create -> rt_segmentize -> rt_failed_tracks (+ the
  * "%d" -> uid substitution into rt_status_message's text) -> rt_fetch_pinned (offsets, status and the six record arrays in
- * page-locked buffers; cross-checked against rt_fetch_offsets) -> rt_fetch_volumes -> destroy.  Inputs come from the library's own host rows (rt_msh_load, rt_trace_counts,
+ * page-locked buffers; cross-checked against rt_fetch_offsets) -> rt_fetch_volumes -> rt_sweep_set_links -> rt_sweep ->
+ * rt_sweep_fetch (one transport sweep over the cyclic tracks on the device) -> destroy.  Inputs come from the library's own host rows (rt_msh_load, rt_trace_counts,
  * rt_trace), so no Julia or Python is involved.  Prints one JSON line with order-sensitive checksums of every
  * result array; tests/test_gpu_c_abi.py compares them with the checker's arrays.
  *
@@ -52,6 +53,7 @@ int main(int argc, char **argv) {
     LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_pinned) LOAD(rt_fetch_volumes)
     LOAD(rt_multi_create) LOAD(rt_multi_destroy) LOAD(rt_multi_segmentize) LOAD(rt_multi_failed_tracks) LOAD(rt_multi_fetch_offsets)
     LOAD(rt_multi_fetch_segments) LOAD(rt_multi_fetch_volumes) LOAD(rt_multi_shards)
+    LOAD(rt_sweep_set_links) LOAD(rt_sweep) LOAD(rt_sweep_fetch) LOAD(rt_sweep_info)
     LOAD(rt_msh_load) LOAD(rt_msh_sizes) LOAD(rt_msh_fetch) LOAD(rt_msh_free) LOAD(rt_trace_counts) LOAD(rt_trace)
     if (p_rt_abi_version() != RT_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
     if (p_rt_device_count() < 1) { fprintf(stderr, "no GPU\n"); return 3; }
@@ -93,6 +95,8 @@ int main(int argc, char **argv) {
     int32_t *status = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     double *volumes = malloc(sizeof(double) * n_cells);
     void *hp[6];
+    double sweep_phi = 0.0, sweep_psi = 0.0;
+    int32_t sweep_input = 0;
     rt_mesh *hm = NULL;
     rt_tracks *ht = NULL;
     rt_multi *mm = NULL;
@@ -135,6 +139,25 @@ int main(int argc, char **argv) {
     }
     for (int a = 0; a < 6; ++a) hp[a] = hp8[2 + a];
     if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
+    /* ---- a consumer that stays on the device: one transport sweep over the cyclic tracks with the linking rt_trace produced
+     *      (next_track_fwd / next_track_bwd, dir_next_track_*, bc_*: src/trackgenerator.jl:231-348), two groups */
+    {
+        const int32_t G = 2;
+        const size_t ncg = (size_t)n_cells * G;
+        double *sig = malloc(sizeof(double) * ncg), *src = malloc(sizeof(double) * ncg), *phi_t = malloc(sizeof(double) * ncg);
+        double *psi_in = malloc(sizeof(double) * 2 * (size_t)n * G), *psi_out = malloc(sizeof(double) * 2 * (size_t)n * G);
+        for (size_t i = 0; i < ncg; ++i) { sig[i] = 0.2 + 1.4 * (double)i / (double)(ncg - 1); src[i] = (double)i / (double)(ncg - 1); }
+        for (size_t i = 0; i < 2 * (size_t)n * G; ++i) psi_in[i] = 1.0;
+        if (p_rt_sweep_set_links(ht, nf, nb, b8[2], b8[3], b8[0], b8[1])) { fprintf(stderr, "rt_sweep_set_links: %s\n", p_rt_last_error()); return 1; }
+        double ms = 0.0;
+        if (p_rt_sweep(ht, G, sig, src, NULL, psi_in, 0, &ms)) { fprintf(stderr, "rt_sweep: %s\n", p_rt_last_error()); return 1; }
+        if (p_rt_sweep_fetch(ht, phi_t, psi_out, NULL)) { fprintf(stderr, "rt_sweep_fetch: %s\n", p_rt_last_error()); return 1; }
+        int32_t info[4] = {0, 0, 0, 0};
+        p_rt_sweep_info(ht, NULL, info);
+        for (size_t i = 0; i < ncg; ++i) sweep_phi += phi_t[i];
+        for (size_t i = 0; i < 2 * (size_t)n * G; ++i) sweep_psi += psi_out[i];
+        sweep_input = info[0];
+    }
     }
     char message[512] = "";
     if (n_failed > 0) { /* error(replace(msg, "%d" => string(uid))) */
@@ -151,10 +174,12 @@ int main(int argc, char **argv) {
     printf("{\"n_tracks\": %" PRId64 ", \"total\": %" PRId64 ", \"walked\": %" PRId64 ", \"n_failed\": %" PRId64
            ", \"first_uid\": %" PRId64 ", \"first_status\": %d, \"message\": \"%s\", \"walk_enabled\": %d, "
            "\"sum_offsets\": %" PRIu64 ", \"sum_status\": %" PRIu64 ", \"px\": %" PRIu64 ", \"py\": %" PRIu64 ", \"qx\": %" PRIu64
-           ", \"qy\": %" PRIu64 ", \"ell\": %" PRIu64 ", \"element\": %" PRIu64 ", \"volumes_sum\": %.17g, \"tracks_px\": %" PRIu64 "}\n",
+           ", \"qy\": %" PRIu64 ", \"ell\": %" PRIu64 ", \"element\": %" PRIu64 ", \"volumes_sum\": %.17g, \"tracks_px\": %" PRIu64
+           ", \"sweep_phi_sum\": %.17g, \"sweep_psi_out_sum\": %.17g, \"sweep_input\": %d}\n",
            n, total, walked, n_failed, first_uid, first_status, message, (int)walk_enabled,
            sum_bits64(offs, n + 1), sum_bits32(status, n), sum_bits64(hp[0], total), sum_bits64(hp[1], total), sum_bits64(hp[2], total),
-           sum_bits64(hp[3], total), sum_bits64(hp[4], total), sum_bits32((const int32_t *)hp[5], total), vsum, sum_bits64(px, n));
+           sum_bits64(hp[3], total), sum_bits64(hp[4], total), sum_bits32((const int32_t *)hp[5], total), vsum, sum_bits64(px, n),
+           sweep_phi, sweep_psi, (int)sweep_input);
     if (mm) p_rt_multi_destroy(mm);
     if (ht) p_rt_tracks_destroy(ht);
     if (hm) p_rt_mesh_destroy(hm);

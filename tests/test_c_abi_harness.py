@@ -63,6 +63,17 @@ def test_c_caller_matches_checker(rt, orc, n_azim, delta, shards):
         assert got[k] == _bits64(ref[k]), k
     assert got["element"] == _bits32(ref["element"])
     assert abs(got["volumes_sum"] - vol.sum()) < 1e-10
+    if not shards:  # the sweep the C caller ran on the device against a sequential sweep over the checker's records
+        import sweep_ref
+
+        G, nc, n = 2, tg.mesh.num_cells, tg.n_total_tracks
+        i = np.arange(nc * G, dtype=np.float64)
+        sig = (0.2 + 1.4 * i / (nc * G - 1)).reshape(nc, G)
+        src = (i / (nc * G - 1)).reshape(nc, G)
+        phi, out = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sig, src, aq.delta_s[tg.azim_idx - 1], np.ones((2, n, G)))
+        assert got["sweep_input"] in (1, 2)
+        assert abs(got["sweep_phi_sum"] - phi.sum()) <= 1e-11 * np.abs(phi).sum()
+        assert abs(got["sweep_psi_out_sum"] - out.sum()) <= 1e-12 * out.sum()
 
 
 @pytest.mark.gpu
