@@ -483,6 +483,39 @@ def _main(real_stdout):
         except Exception as e:  # the headline line must survive a failure of the extra
             allgather = {"error": repr(e)}
 
+    # ---- N > 1: the consumer that never gathers — a transport sweep over every rank's own tracks (rt_sweep on the shard's staging
+    #      rows), the fluxes that leave a shard exchanged by RCCL send/recv pairs, the tallies all-reduced (distributed.ShardedSweep)
+    sharded_sweep = None
+    if dist_on and not args.no_extras:
+        if rehearsal:
+            sharded_sweep = {"skipped": "rehearsal (the exchange needs device tensors on an RCCL group; tests/test_gpu_sharded_sweep.py covers it over gloo)"}
+        else:
+            try:
+                G = 7
+                nc = dmesh.n_cells
+                sig = np.linspace(0.2, 1.6, nc * G).reshape(nc, G)
+                src = np.linspace(0.0, 1.0, nc * G).reshape(nc, G)
+                ss = rtd.ShardedSweep(tg, dt, rank, world, device=dev)
+                ss.sweep(G, sig, src, None, np.ones((2, hi - lo, G)), input="auto")  # warm-up: uploads, peer connections
+                sync()
+                reps, sw_ms = 3, 0.0
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    sw_ms += ss.sweep(G)["ms"]
+                sync()
+                wall_ms = (time.perf_counter() - t0) / reps * 1e3
+                tt = torch.tensor([wall_ms, sw_ms / reps], dtype=torch.float64, device=cdev)
+                if world > 1:
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                n_cross = sum(len(v[0]) for v in ss.plan.send.values())
+                sharded_sweep = {"groups": G, "ms_per_sweep": float(tt[0].item()), "rt_sweep_kernel_ms": float(tt[1].item()),
+                                 "fluxes_sent_by_rank0": int(n_cross), "bytes_sent_by_rank0": int(n_cross) * G * 8,
+                                 "segment_group_updates_per_s": global_segments * 2.0 * G / (float(tt[0].item()) * 1e-3),
+                                 "note": "every rank sweeps its own uid range (forward and backward over the staging rows), sends the fluxes whose "
+                                         "linked track lives on another rank (point-to-point), all-reduces the tallies; slowest rank; outside `value`"}
+            except Exception as e:  # the headline line must survive a failure of the extra
+                sharded_sweep = {"error": repr(e)}
+
     # ---- extras measured outside the timed region (rank 0)
     latency = e2e = same_workload = config5 = None
     if rank == 0 and not args.no_extras and not dist_on:
@@ -608,6 +641,8 @@ def _main(real_stdout):
             out["e2e"] = e2e
         if allgather is not None:
             out["allgather"] = allgather
+        if sharded_sweep is not None:
+            out["sharded_sweep"] = sharded_sweep
         if same_workload is not None:
             out["single_gpu_same_workload"] = same_workload
             out["speedup_vs_single_gpu"] = same_workload["ms_per_step"] / ms_per_step

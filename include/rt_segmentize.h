@@ -196,7 +196,9 @@ int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
  *
  * rt_sweep_set_links: the linking that trace! / next_tracks produced (src/trackgenerator.jl:231-348), in uid order, exactly
  * the arrays rt_trace returns: 1-based uids of next_track_fwd / next_track_bwd, dir_next_track_* (0 Forward, 1 Backward),
- * bc_fwd / bc_bwd (0 Vacuum, 1 Reflective, 2 Periodic).
+ * bc_fwd / bc_bwd (0 Vacuum, 1 Reflective, 2 Periodic).  A next uid of 0 means "not in this track set": nothing is handed on
+ * locally (a uid shard of a multi-GPU run: the host sends psi_out of such traversals to the owner of the linked track, which
+ * writes it into its psi_in — both reachable through rt_sweep_info; raytracing.jl_amd/distributed.py, ShardedSweep).
  *
  * rt_sweep: one method-of-characteristics sweep over the records of the last rt_segmentize.  Every track u is traversed
  * forward (its segments in march order, starting from psi_in[0][u][:]) and backward (reversed, from psi_in[1][u][:]); along

@@ -433,6 +433,14 @@ class DeviceTracks:
             _check(lib().rt_sweep_fetch(self._h, *[out[k].ctypes.data_as(_dp) for k in ("phi", "psi_out", "psi_next")]))
         return out
 
+    def sweep_pointers(self) -> dict:
+        """``rt_sweep_info``: device addresses of the last sweep's ``phi`` [n_cells, G], ``psi_out`` and ``psi_in`` [2, n_tracks, G]
+        (``psi_in`` holds what the sweep handed on: the boundary flux of the next one) + ``groups``."""
+        ptrs = (_vp * 3)()
+        info = (C.c_int32 * 4)()
+        _check(lib().rt_sweep_info(self._h, ptrs, info))
+        return dict(phi=ptrs[0] or 0, psi_out=ptrs[1] or 0, psi_in=ptrs[2] or 0, groups=int(info[3]))
+
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
         v = (C.c_int64 * 20)()

@@ -3019,6 +3019,7 @@ static int32_t sweep_set_links_impl(rt_tracks *t, const int64_t *next_fwd, const
             const int64_t v = (d == 0 ? next_fwd[u] : next_bwd[u]) - 1;  // 1-based uids, as trace! links them
             const int dn = d == 0 ? dir_fwd[u] : dir_bwd[u];             // 0 Forward, 1 Backward (src/track.jl:11-14)
             const int bc = d == 0 ? bc_fwd[u] : bc_bwd[u];               // 0 Vacuum (src/boundary.jl:12-16)
+            if (v == -1) continue;  // uid 0: the linked track is not in this track set (a shard: its owner receives the flux)
             if (v < 0 || v >= n || (dn != 0 && dn != 1) || bc < 0 || bc > 2) {
                 set_error("rt_sweep_set_links: track %lld has a bad link (next uid %lld, dir %d, bc %d)", (long long)(u + 1), (long long)(v + 1), dn, bc);
                 return RT_ERR_INVALID;

@@ -19,7 +19,8 @@ from typing import Callable, Dict, List, Tuple
 import numpy as np
 
 __all__ = ["shard_ranges", "shard_arrays", "segmentize_shard", "allreduce_volumes",
-           "allgather_segments", "SegmentGather", "DevArray", "TRACK_FIELDS", "PipelinedVolumesAllReduce"]
+           "allgather_segments", "SegmentGather", "DevArray", "TRACK_FIELDS", "PipelinedVolumesAllReduce",
+           "SweepExchangePlan", "ShardedSweep"]
 
 TRACK_FIELDS = ("px", "py", "phi", "cos_phi", "sin_phi", "A", "B", "C", "ell", "azim_idx")
 
@@ -225,3 +226,117 @@ class PipelinedVolumesAllReduce:
             if w is not None:
                 w.wait()
                 self._work[k] = None
+
+
+class SweepExchangePlan:
+    """The one real exchange of the sharded path (pure numpy; no communication): a transport sweep hands the flux a traversal
+    ends with to the entry of the linked track (``next_track_fwd / next_track_bwd`` + ``dir_next_track_*``,
+    ``src/track.jl:42-77``), and with ``tracks_by_uid`` cut into uid ranges most links leave the rank — reflective links pair an
+    azimuthal angle with its supplementary one, i.e. the first ranks with the last.  For rank ``rank`` of ``ranges``:
+
+    * ``local_links``: the link arrays for ``rt_sweep_set_links`` of the shard — local 1-based uids, 0 where the linked track
+      lives on another rank (the library then hands nothing on locally);
+    * ``send[p]`` = (indices into the shard's ``psi_out`` viewed as [2·n_local, G], 0/1 mask: 0 behind a Vacuum boundary) and
+      ``recv[p]`` = indices into the shard's ``psi_in``, for every peer ``p`` with traffic — both in the order of the global
+      source key (uid, direction), which every rank derives from the same global arrays, so the two sides agree without talking.
+    """
+
+    def __init__(self, next_fwd, next_bwd, dir_fwd, dir_bwd, bc_fwd, bc_bwd, ranges, rank):
+        nxt = (np.asarray(next_fwd, np.int64) - 1, np.asarray(next_bwd, np.int64) - 1)
+        dirs = (np.asarray(dir_fwd, np.int64), np.asarray(dir_bwd, np.int64))
+        bcs = (np.asarray(bc_fwd, np.int64), np.asarray(bc_bwd, np.int64))
+        n = len(nxt[0])
+        bounds = np.array([r[0] for r in ranges] + [ranges[-1][1]], np.int64)
+        owner = lambda u: np.clip(np.searchsorted(bounds, u, side="right") - 1, 0, len(ranges) - 1)
+        lo, hi = ranges[rank]
+        self.rank, self.lo, self.hi, self.n_local = rank, lo, hi, hi - lo
+        own = np.arange(lo, hi)
+        loc = {}
+        for d, name in ((0, "fwd"), (1, "bwd")):
+            v = nxt[d][own]
+            here = (v >= lo) & (v < hi)
+            loc["next_" + name] = np.where(here, v - lo + 1, 0).astype(np.int64)
+            loc["dir_" + name] = dirs[d][own].astype(np.int8)
+            loc["bc_" + name] = bcs[d][own].astype(np.int8)
+        self.local_links = loc
+        # every cross-rank link of the global problem, in the order of its source key
+        g = np.repeat(np.arange(n, dtype=np.int64), 2)
+        d = np.tile(np.array([0, 1], np.int64), n)
+        v = np.where(d == 0, nxt[0][g], nxt[1][g])
+        dn = np.where(d == 0, dirs[0][g], dirs[1][g])
+        vac = np.where(d == 0, bcs[0][g], bcs[1][g]) == 0
+        s_rank, r_rank = owner(g), owner(v)
+        cross = s_rank != r_rank
+        self.send, self.recv = {}, {}
+        for p in range(len(ranges)):
+            if p == rank:
+                continue
+            out = cross & (s_rank == rank) & (r_rank == p)
+            if out.any():
+                self.send[p] = ((d[out] * self.n_local + (g[out] - lo)).astype(np.int64), (~vac[out]).astype(np.float64))
+            inc = cross & (s_rank == p) & (r_rank == rank)
+            if inc.any():
+                self.recv[p] = (dn[inc] * self.n_local + (v[inc] - lo)).astype(np.int64)
+
+
+class ShardedSweep:
+    """``rt_sweep`` on a uid shard + the exchange of the fluxes that leave it + the all-reduce of the tallies: the consumer of
+    the sharded segments that never gathers them (DESIGN.md §5).  ``dt``: the rank's ``DeviceTracks`` after ``segmentize``;
+    ``tg``: the GLOBAL traced ``TrackGenerator`` (every rank holds it: ``trace!`` stays on the host).  Point-to-point RCCL
+    send/recv pairs (``batch_isend_irecv``) straight out of / into the library's ``psi_out`` / ``psi_in``; gloo in the CPU tests
+    through the injectable ``tensors`` (a callable returning the three torch tensors phi [n_cells, G], psi_out, psi_in [2·n_local, G])."""
+
+    def __init__(self, tg, dt, rank, world, ranges=None, group=None, device=None, tensors=None):
+        self.ranges = ranges if ranges is not None else shard_ranges(tg.ell, world)
+        self.plan = SweepExchangePlan(tg.next_fwd_uid, tg.next_bwd_uid, tg.dir_next_fwd, tg.dir_next_bwd, tg.bc_fwd, tg.bc_bwd,
+                                      self.ranges, rank)
+        self.dt, self.rank, self.world, self.group, self.device = dt, rank, world, group, device
+        self._tensors = tensors
+        self._idx = None
+        if dt is not None:
+            dt.sweep_set_links(self.plan.local_links)
+
+    def _views(self, G):
+        import torch
+
+        if self._tensors is not None:
+            return self._tensors()
+        p = self.dt.sweep_pointers()
+        n2 = 2 * self.plan.n_local
+        mk = lambda ptr, rows: torch.as_tensor(DevArray(ptr, rows * G, "<f8", self.dt), device=self.device).view(rows, G)
+        return mk(p["phi"], self.dt.dmesh.n_cells), mk(p["psi_out"], n2), mk(p["psi_in"], n2)
+
+    def exchange(self, G):
+        """Hand the fluxes that leave this shard to their owners and take in the ones that enter it; sum the tallies."""
+        import torch
+        import torch.distributed as dist
+
+        phi, psi_out, psi_in = self._views(G)
+        if self._idx is None or self._idx[0] != psi_out.device:
+            dev = psi_out.device
+            self._idx = (dev, {p: (torch.as_tensor(i, device=dev), torch.as_tensor(m, device=dev)[:, None]) for p, (i, m) in self.plan.send.items()},
+                         {p: torch.as_tensor(i, device=dev) for p, i in self.plan.recv.items()})
+        _, send, recv = self._idx
+        peer = (lambda p: p) if self.group is None else (lambda p: dist.get_global_rank(self.group, p))
+        ops, bufs = [], {}
+        for p, (idx, mask) in send.items():
+            ops.append(dist.P2POp(dist.isend, (psi_out[idx] * mask).contiguous(), peer(p), self.group))
+        for p, idx in recv.items():
+            bufs[p] = torch.empty((idx.numel(), G), dtype=psi_in.dtype, device=psi_in.device)
+            ops.append(dist.P2POp(dist.irecv, bufs[p], peer(p), self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for p, idx in recv.items():
+            psi_in[idx] = bufs[p]
+        if self.world > 1:
+            dist.all_reduce(phi, op=dist.ReduceOp.SUM, group=self.group)
+        return phi, psi_out, psi_in
+
+    def sweep(self, G, sigma_t=None, source=None, track_weight=None, psi_in=None, input="auto"):
+        """One sweep of the global problem: this rank's traversals, then the exchange.  ``track_weight`` / ``psi_in``: this rank's
+        slices ([n_local], [2, n_local, G]).  Returns the library's report + the (device) tensors phi (summed over the ranks),
+        psi_out, psi_in (the boundary flux of the next sweep, complete)."""
+        r = self.dt.sweep(G, sigma_t, source, track_weight, psi_in, input=input, fetch=False)
+        r["phi"], r["psi_out"], r["psi_next"] = self.exchange(G)
+        return r

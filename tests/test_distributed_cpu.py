@@ -139,3 +139,96 @@ def test_two_rank_gloo_pipelined_volumes_allreduce():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def _sweep_worker(rank, world, port, q, bc):
+    """The sharded transport sweep (distributed.ShardedSweep) over gloo: every rank runs the sequential sweep of tests/sweep_ref.py
+    over ITS uid range of the checker's records (standing in for rt_sweep), hands on the fluxes that stay in the shard itself (as
+    the library's k_sweep_link does, with next uid 0 for tracks of other ranks), and ShardedSweep.exchange moves the rest and sums
+    the tallies.  Two sweeps must equal two sweeps of the unsharded problem."""
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch
+        import torch.distributed as dist
+
+        import raytracing_jl_amd as rt
+        import sweep_ref
+        from oracle import oracle as orc
+        from raytracing_jl_amd import distributed as rtd
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        B = rt.BoundaryConditions
+        bcs = {"reflective": B(top=rt.Reflective, bottom=rt.Reflective, left=rt.Reflective, right=rt.Reflective),
+               "periodic": B(top=rt.Periodic, bottom=rt.Periodic, left=rt.Periodic, right=rt.Periodic),
+               "mixed": B(top=rt.Vacuum, bottom=rt.Reflective, left=rt.Periodic, right=rt.Periodic)}[bc]
+        model = rt.DiscreteModelFromFile(rt.data_path("pincell.json"))
+        tg = rt.TrackGenerator(model, 8, 0.04, bcs=bcs)
+        rt.trace(tg)
+        om = orc.OracleMesh.from_mesh(tg.mesh)
+        full = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi)
+        n, nc, G = tg.n_total_tracks, tg.mesh.num_cells, 3
+        rng = np.random.default_rng(4)
+        sig, src, w = rng.uniform(0.1, 2.0, (nc, G)), rng.uniform(0.0, 1.0, (nc, G)), rng.uniform(0.5, 1.5, n)
+        psi0 = rng.uniform(0.5, 1.5, (2, n, G))
+        links = (tg.next_fwd_uid, tg.next_bwd_uid, tg.dir_next_fwd, tg.dir_next_bwd, tg.bc_fwd, tg.bc_bwd)
+        # the unsharded answer: two sweeps
+        phi1, out1 = sweep_ref.sweep(full["offsets"], full["ell"], full["element"], sig, src, w, psi0)
+        nxt1 = sweep_ref.link(out1, *links)
+        phi2, out2 = sweep_ref.sweep(full["offsets"], full["ell"], full["element"], sig, src, w, nxt1)
+        nxt2 = sweep_ref.link(out2, *links)
+        # this rank's shard
+        ranges = rtd.shard_ranges(tg.ell, world)
+        lo, hi = ranges[rank]
+        nl = hi - lo
+        off = full["offsets"][lo:hi + 1] - full["offsets"][lo]
+        s0, s1 = full["offsets"][lo], full["offsets"][hi]
+        state = {"phi": torch.zeros((nc, G), dtype=torch.float64), "out": torch.zeros((2 * nl, G), dtype=torch.float64),
+                 "in": torch.from_numpy(psi0[:, lo:hi].reshape(2 * nl, G).copy())}
+        ss = rtd.ShardedSweep(tg, None, rank, world, ranges=ranges, tensors=lambda: (state["phi"], state["out"], state["in"]))
+        ll = ss.plan.local_links
+
+        def local_sweep():  # what rt_sweep does on the shard: traversals, then the hand-over inside the shard
+            psi_in = state["in"].numpy().reshape(2, nl, G)
+            phi, out = sweep_ref.sweep(off, full["ell"][s0:s1], full["element"][s0:s1], sig, src, w[lo:hi], psi_in)
+            nxt = np.zeros_like(out)
+            for u in range(nl):
+                for d, (nx, dr, b) in enumerate(((ll["next_fwd"], ll["dir_fwd"], ll["bc_fwd"]), (ll["next_bwd"], ll["dir_bwd"], ll["bc_bwd"]))):
+                    if nx[u] > 0:
+                        nxt[int(dr[u]), int(nx[u]) - 1] = 0.0 if int(b[u]) == 0 else out[d, u]
+            state["phi"].copy_(torch.from_numpy(phi)); state["out"].copy_(torch.from_numpy(out.reshape(2 * nl, G)))
+            state["in"].copy_(torch.from_numpy(nxt.reshape(2 * nl, G)))
+
+        ok = True
+        for want_phi, want_out, want_next in ((phi1, out1, nxt1), (phi2, out2, nxt2)):
+            local_sweep()
+            phi, out, nin = ss.exchange(G)
+            ok = ok and np.allclose(phi.numpy(), want_phi, rtol=1e-12, atol=1e-14)
+            ok = ok and np.array_equal(out.numpy().reshape(2, nl, G), want_out[:, lo:hi])
+            ok = ok and np.array_equal(nin.numpy().reshape(2, nl, G), want_next[:, lo:hi])
+        n_cross = sum(len(v[0]) for v in ss.plan.send.values())
+        dist.destroy_process_group()
+        q.put((rank, bool(ok), int(n_cross)))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,bc", [(2, "reflective"), (3, "mixed"), (2, "periodic")])
+def test_gloo_sharded_sweep(world, bc):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, q, bc)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert sum(c for _, _, c in res) > 0  # fluxes did cross ranks
