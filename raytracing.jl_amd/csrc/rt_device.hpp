@@ -931,20 +931,28 @@ RT_HD __forceinline__ TopoTrack topo_track(bool mesh_on, double d_vertex, double
 // n by the 1.5·2^52 trick (two additions), r with ln2 split in two, expm1(r) by its Taylor polynomial to r^13 (the next term is
 // below 4e-18·|r|), 2^n assembled from its exponent bits, and e^x − 1 = 2^n·expm1(r) + (2^n − 1) in one fma (2^n − 1 is exact).
 // Beyond τ = 41.5, e^{−τ} < 2^−59 and the result is 1.
-RT_HD __forceinline__ double one_minus_exp_neg(double tau) {
-    const double x = -(tau < 41.5 ? tau : 41.5);
+// The six highest coefficients of the polynomial below (1/13! ... 1/8!) can be handed in: k_sweep keeps them in vector
+// registers, where its scalar file is short (13 coefficients = 26 scalar registers; with them 23 scalar values of its loop were
+// spilled to vector lanes, −2 % sweep time without).
+struct ExpPoly { double c[6]; };
+RT_HD __forceinline__ ExpPoly exp_poly() {
+    return ExpPoly{{1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06,
+                    2.48015873015873e-05}};
+}
+RT_HD __forceinline__ double one_minus_exp_neg(double tau, const ExpPoly &hi = exp_poly()) {
+    const double x = -__builtin_fmin(tau, 41.5);  // (one v_min_f64; τ is never NaN)
     const double kMagic = 6755399441055744.0;  // 1.5 · 2^52: adding it rounds to an integer, whose low word is that integer
     const double t = __builtin_fma(x, 1.4426950408889634074, kMagic);
     const double n = t - kMagic;
     const int32_t ni = (int32_t)(uint32_t)__builtin_bit_cast(uint64_t, t);
     double r = __builtin_fma(n, -6.93147180369123816490e-01, x);  // ln2 = hi + lo, hi with 21 trailing zero bits: n·hi is exact
     r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-    double q = 1.6059043836821613e-10;           // 1/13!
-    q = __builtin_fma(q, r, 2.08767569878681e-09);    // 1/12!
-    q = __builtin_fma(q, r, 2.505210838544172e-08);   // 1/11!
-    q = __builtin_fma(q, r, 2.755731922398589e-07);   // 1/10!
-    q = __builtin_fma(q, r, 2.7557319223985893e-06);  // 1/9!
-    q = __builtin_fma(q, r, 2.48015873015873e-05);    // 1/8!
+    double q = hi.c[0];                               // 1/13!
+    q = __builtin_fma(q, r, hi.c[1]);                 // 1/12!
+    q = __builtin_fma(q, r, hi.c[2]);                 // 1/11!
+    q = __builtin_fma(q, r, hi.c[3]);                 // 1/10!
+    q = __builtin_fma(q, r, hi.c[4]);                 // 1/9!
+    q = __builtin_fma(q, r, hi.c[5]);                 // 1/8!
     q = __builtin_fma(q, r, 1.984126984126984e-04);   // 1/7!
     q = __builtin_fma(q, r, 1.3888888888888889e-03);  // 1/6!
     q = __builtin_fma(q, r, 8.333333333333333e-03);   // 1/5!

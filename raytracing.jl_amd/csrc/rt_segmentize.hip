@@ -1568,15 +1568,20 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                 st[g] = x[2 * gi]; qs[g] = x[2 * gi + 1];
             }
         };
-        // one segment: attenuation and tally for the GP groups of this pass
-        auto segment = [&](const int32_t e, const double ell, const bool act, const double (&st)[GP], const double (&qs)[GP]) {
+        ExpPoly poly = exp_poly();  // (in vector registers: see one_minus_exp_neg)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(poly.c[i]));
+        // one segment: attenuation and tally for the GP groups of this pass.  A lane beyond its track's end evaluates a segment
+        // of length 0: τ = 0, 1 − e^{−0} = 0 exactly, Δ = ±0 — its ψ keeps its bits, and one select does for all groups.
+        auto segment = [&](const int32_t e, const double ell_row, const bool act, const double (&st)[GP], const double (&qs)[GP]) {
+            const double ell = act ? ell_row : 0.0;
             double wd[GP];
 #pragma unroll
             for (int g = 0; g < GP; ++g) {
                 const double tau = st[g] * ell;
-                const double ex = one_minus_exp_neg(tau);  // −expm1(−τ) to within an ulp (rt_device.hpp)
+                const double ex = one_minus_exp_neg(tau, poly);  // −expm1(−τ) to within an ulp (rt_device.hpp)
                 const double d = (psi[g] - qs[g]) * ex;
-                psi[g] = act ? psi[g] - d : psi[g];
+                psi[g] = psi[g] - d;
                 wd[g] = w * d;
             }
             // Neighbouring lanes are neighbouring parallel tracks: at the same row most of them are in the same cell, and
@@ -1590,15 +1595,17 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                 const int32_t key = act ? e : -1 - lane;  // (an inactive lane matches nobody)
                 // lane l with (l mod 2n) == 0 takes over lane l + n (row_shl:n reads lane l + n of the 16-lane row)
                 auto fold = [&]<int NSH>() {
-                    const int32_t key_up = __builtin_amdgcn_update_dpp(-1, key, 0x100 + NSH, 0xf, 0xf, false);
-                    const int32_t key_dn = __builtin_amdgcn_update_dpp(-1, key, 0x110 + NSH, 0xf, 0xf, false);
+                    // (bound_ctrl: a lane whose source lies outside its row reads 0 and no `old` value has to be moved in first;
+                    //  the lanes that use what they read — `take`, `given` — never read across a row's end)
+                    const int32_t key_up = __builtin_amdgcn_update_dpp(0, key, 0x100 + NSH, 0xf, 0xf, true);
+                    const int32_t key_dn = __builtin_amdgcn_update_dpp(0, key, 0x110 + NSH, 0xf, 0xf, true);
                     const bool take = ((lane & (2 * NSH - 1)) == 0) && key_up == key;
                     const bool given = ((lane & (2 * NSH - 1)) == NSH) && key_dn == key;
 #pragma unroll
                     for (int g = 0; g < GP; ++g) {
                         const uint64_t bits = __builtin_bit_cast(uint64_t, wd[g]);
-                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)bits, 0x100 + NSH, 0xf, 0xf, false);
-                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)(bits >> 32), 0x100 + NSH, 0xf, 0xf, false);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)bits, 0x100 + NSH, 0xf, 0xf, true);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)(bits >> 32), 0x100 + NSH, 0xf, 0xf, true);
                         const double up = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
                         wd[g] = __builtin_fma(up, take ? 1.0 : 0.0, wd[g]);  // (one instruction; the values are finite)
                     }
@@ -1646,28 +1653,43 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                     return Row{a.stg.qx[sl], a.stg.qy[sl], a.stg.element[sl]};
                 };
                 auto cell_of = [&](const Row &R, const int r) -> int32_t { return r < cnt ? (R.el < 0 ? -R.el : R.el) - 1 : 0; };
-                Row R0 = load_row(row_of(0)), R1 = load_row(row_of(1));
-                double st0[GP], qs0[GP];
-                load_xs(cell_of(R0, row_of(0)), st0, qs0);
-                double lqx = 0.0, lqy = 0.0;  // forward: q of the previous row
-                for (int t = 0; t < maxcnt; ++t) {
-                    const int r = row_of(t);
-                    const bool act = r < cnt;
-                    // entry point: staged for marked records (cell < 0: first record of a track, records of the generic step),
-                    // else the previous record's exit point — forward the row before, backward the NEXT step's row
-                    double px = dir ? R1.qx : lqx, py = dir ? R1.qy : lqy;
-                    const int64_t sl0 = slot_cached(r, cj0, cid0);  // (outside the branch: see chunk_of)
-                    if (act && R0.el < 0) { px = a.stg.px[sl0]; py = a.stg.py[sl0]; }
-                    const int64_t sl2 = slot_cached(row_of(t + 2), cj2, cid2);
-                    const Row R2{a.stg.qx[sl2], a.stg.qy[sl2], a.stg.element[sl2]};
-                    double st1[GP], qs1[GP];
-                    load_xs(cell_of(R1, row_of(t + 1)), st1, qs1);
-                    const double ell = norm2(px - R0.qx, py - R0.qy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
-                    segment(cell_of(R0, r), ell, act, st0, qs0);
-                    lqx = R0.qx; lqy = R0.qy;
-                    R0 = R1; R1 = R2;
+                // One step: Ra holds row r(t), Rb row r(t + 1) and Rc — until this step's prefetch replaces it — row r(t − 1).  The
+                // loop is unrolled three times with the roles rotated, so that no row register is moved from one stage of the
+                // pipeline to the next; steps t >= maxcnt of the last round do nothing (act is false, their loads are clamped).
+                // Measured at C3, 7 groups, same box: rotating by moves 0.373 ms, three steps per round 0.358, six (the cross
+                // sections' two stages rotated as well; 32 scalar registers spilled) 0.366; one copy of the loop per direction
+                // (forward and backward waves of a CU then run different code) 0.396.
+                {
+                    const int DIR = dir;
+                    auto row_d = row_of;
+                    Row R0 = load_row(row_d(0)), R1 = load_row(row_d(1)), R2{0.0, 0.0, 0};
+                    double stA[GP], qsA[GP], stB[GP], qsB[GP];
+                    load_xs(cell_of(R0, row_d(0)), stA, qsA);
+                    auto step = [&](const int t, const Row &Ra, const Row &Rb, Row &Rc, const double (&st0)[GP], const double (&qs0)[GP],
+                                    double (&st1)[GP], double (&qs1)[GP]) {
+                        const int r = row_d(t);
+                        const bool act = r < cnt && t < maxcnt;
+                        // entry point: the previous record's exit point — forward the row before, backward the NEXT step's row — or,
+                        // for marked records (cell < 0: first record of a track, records of the generic step), the staged one
+                        double dx = (DIR ? Rb.qx : Rc.qx) - Ra.qx, dy = (DIR ? Rb.qy : Rc.qy) - Ra.qy;
+                        const int64_t sl0 = slot_cached(r, cj0, cid0);  // (outside the branch: see chunk_of)
+                        double px = 0.0, py = 0.0;
+                        const bool marked = act && Ra.el < 0;
+                        if (marked) { px = a.stg.px[sl0]; py = a.stg.py[sl0]; }
+                        const int64_t sl2 = slot_cached(row_d(t + 2), cj2, cid2);
+                        Rc = Row{a.stg.qx[sl2], a.stg.qy[sl2], a.stg.element[sl2]};
+                        load_xs(cell_of(Rb, row_d(t + 1)), st1, qs1);
+                        if (marked) { dx = px - Ra.qx; dy = py - Ra.qy; }
+                        const double ell = norm2(dx, dy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
+                        segment(cell_of(Ra, r), ell, act, st0, qs0);
+                    };
+                    for (int t = 0; t < maxcnt; t += 3) {
+                        step(t, R0, R1, R2, stA, qsA, stB, qsB);
+                        step(t + 1, R1, R2, R0, stB, qsB, stA, qsA);
+                        step(t + 2, R2, R0, R1, stA, qsA, stB, qsB);
 #pragma unroll
-                    for (int g = 0; g < GP; ++g) { st0[g] = st1[g]; qs0[g] = qs1[g]; }
+                        for (int g = 0; g < GP; ++g) { stA[g] = stB[g]; qsA[g] = qsB[g]; }
+                    }
                 }
             } else {
                 struct Rec { double ell; int32_t el; };
@@ -3217,7 +3239,8 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
                    b(t->spy) + b(t->sqx) + b(t->sqy) + b(t->sell) + b(t->volumes) + b(t->volumes_prev) + b(t->delta_s) + b(t->gpx) + b(t->gpy) +
                    b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +
                    b(t->w_base) + b(t->w_P) + b(t->s_el) + b(t->s_eq) + b(t->p_count) + b(t->p_flags) + b(t->p_valid) + b(t->p_rel) + b(t->s_px) +
-                   b(t->s_py) + b(t->s_qx) + b(t->s_qy) + b(t->s_ell) + b(t->p_sum);
+                   b(t->s_py) + b(t->s_qx) + b(t->s_qy) + b(t->s_ell) + b(t->p_sum) + b(t->vacc) + b(t->fst_i) + b(t->fst_v) + b(t->tau) +
+                   b(t->sigma_t) + b(t->sw_src) + b(t->sw_w) + b(t->sw_xs) + b(t->sw_psi_in) + b(t->sw_psi_out) + b(t->sw_phi);
     }
     return RT_SUCCESS;
 }
