@@ -695,6 +695,27 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     // (A) record n: where the line leaves the cell; its loads
                     const TopoGeo g = topo_geo(ts, c_hdr, c_x2, c_y2, tA, tB, tC);
                     const int32_t np = topo_next(g);
+#ifdef RT_STATS_DISTINCT
+                    {   // development: how many distinct successor records / exit edges the wave's cheap lanes fetch in this iteration
+                        auto distinct = [&](const int32_t key) -> int {
+                            unsigned long long act = __ballot(cheap);
+                            int nd = 0;
+                            while (act) {
+                                const int32_t v = __builtin_amdgcn_readlane(key, __ffsll((long long)act) - 1);
+                                act &= ~__ballot(key == v);
+                                ++nd;
+                            }
+                            return nd;
+                        };
+                        const int d1 = distinct(np), d2 = distinct(g.code), na = __popcll(__ballot(cheap));
+                        if (lane == 0) {
+                            atomicAdd(march_ctl() + 44 + (d1 < 8 ? d1 : 8), 1ull);       // 45..52: distinct successor records 1..8+
+                            atomicAdd(march_ctl() + 53 + (d2 < 8 ? d2 : 8), 1ull);       // 54..61: distinct exit edges 1..8+
+                            atomicAdd(march_ctl() + 62, (unsigned long long)na);         // cheap lanes
+                            atomicAdd(march_ctl() + 63, 1ull);                           // wave-iterations
+                        }
+                    }
+#endif
                     const RT_G TopoRec *Rn = trec_v + (np >= 0 ? np : 0);
                     const uint64_t n_hdr = Rn->hdr;
                     const double n_x2 = Rn->x2, n_y2 = Rn->y2;
@@ -2848,6 +2869,15 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     }
     fprintf(stderr, "[rt timing] per wave-iteration (lane-0 view, cycles): top+load %.0f | walk_step %.0f | emit %.0f | loop-back %.0f | iters/wave %.1f | loop cycles/wave %.0f\n",
             (double)fi[8] / fi[12], (double)fi[9] / fi[12], (double)fi[10] / fi[12], (double)fi[11] / fi[12], (double)fi[12] / fi[14], (double)fi[13] / fi[14]);
+#endif
+#ifdef RT_STATS_DISTINCT
+    {
+        fprintf(stderr, "[rt distinct] wave-iterations %llu, cheap lanes per iteration %.1f\n  distinct successor records 1..8+:", h_res[63], (double)h_res[62] / (double)std::max<unsigned long long>(1, h_res[63]));
+        for (int b = 1; b <= 8; ++b) fprintf(stderr, " %.3f", (double)h_res[44 + b] / (double)std::max<unsigned long long>(1, h_res[63]));
+        fprintf(stderr, "\n  distinct exit edges 1..8+:");
+        for (int b = 1; b <= 8; ++b) fprintf(stderr, " %.3f", (double)h_res[53 + b] / (double)std::max<unsigned long long>(1, h_res[63]));
+        fprintf(stderr, "\n");
+    }
 #endif
 #ifdef RT_STATS
     if (split)
