@@ -207,7 +207,10 @@ int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
  * i.e. ψ_out = ψ_in·e^{−τ} + (q/Σt)(1 − e^{−τ}); a cell with sigma_t = 0 leaves ψ unchanged.  The flux a track ends with is
  * handed to the entry of the linked track, in the linked direction, as that entry's incoming flux for the NEXT sweep — 0
  * behind a Vacuum boundary — so repeated calls with psi_in = NULL iterate on the device (Jacobi over the boundary fluxes).
- *   n_groups            G >= 1; changing it resets the boundary fluxes to 0
+ *   n_groups            G >= 1; changing it resets the boundary fluxes to 0.  A "group" is any independent flux component:
+ *                       a solver with polar angles θ_p passes G = groups x polar angles with sigma_t[e][(g, p)] = Σt_g / sin θ_p and
+ *                       source[e][(g, p)] = q_g / sin θ_p (the ratio q/Σt is unchanged, τ is the 3-D optical length) and applies
+ *                       the polar weights to φ when it folds the components
  *   sigma_t, source     [n_cells * G] total cross section and source per cell and group; NULL, NULL: those of the previous
  *                       call (source alone may be NULL: zero source)
  *   track_weight        [n_tracks] w[u]; NULL: the previous call's, or δs[azim_idx[u]] — the weight fill_volumes gives a
