@@ -174,6 +174,33 @@ def two_in_flight(tg, aq, dmesh, dt, steps, segments_per_step):
         return {"error": repr(e)}
 
 
+def stream_ordered_calls(rt, tg, aq, dmesh, dt, steps, segments_per_step):
+    """Extra, not `value`: the same K steps with the option "async" — rt_segmentize returns once the host knows total, status
+    summary and offsets (after the scan) while the compaction still runs, and the next call queues behind it: the ≈25 µs of host
+    turnaround between two synchronous calls disappear.  All K steps' kernels complete inside the timed region (rt_wait)."""
+    try:
+        import torch
+        seg = lambda: dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        dmesh.set_option("async", 1)
+        for _ in range(3):
+            seg()
+        dt.wait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            seg()
+        dt.wait()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        dmesh.set_option("async", 0)
+        seg()
+        return {"steps": steps, "ms_per_step": el / steps * 1e3, "value": segments_per_step * steps / el, "unit": "segments/s",
+                "note": "rt_set_option async=1: calls return after march + scan, the compaction overlaps the host's turnaround; not the headline value"}
+    except Exception as e:  # pragma: no cover
+        dmesh.set_option("async", 0)
+        return {"error": repr(e)}
+
+
 def boundary_costs(dt, total):
     """What the boundary adds around one step when the caller wants host arrays (never part of `value`): all eight result
     arrays through the handle's page-locked buffers in one call (rt_fetch_pinned), and the older pair of calls beside it."""
@@ -658,6 +685,7 @@ def _main(real_stdout):
             out["downstream_sweep"] = downstream_sweep
         if world == 1 and not dist_on and not args.no_concurrent:
             out["two_batches_in_flight"] = two_in_flight(tg, aq, dmesh, dt, args.steps, local_total)
+            out["stream_ordered_calls"] = stream_ordered_calls(rt, tg, aq, dmesh, dt, args.steps, local_total)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tg)
         real_stdout.write(json.dumps(out, ensure_ascii=False) + "\n")

@@ -143,6 +143,14 @@ int64_t rt_segmentize(rt_tracks *tracks, double tiny_step, int32_t k, double rto
 /* Number of tracks with status != RT_TRACK_OK after the last rt_segmentize, and the 1-based
  * uid of the first one (0 if none). */
 int32_t rt_failed_tracks(rt_tracks *tracks, int64_t *n_failed, int64_t *first_uid, int32_t *first_status);
+/* Stream-ordered calls — rt_set_option(mesh, "async", 1): rt_segmentize returns as soon as the host knows the total, the failure
+ * summary and that the offsets' scan has been issued; the compaction of the records (38 % of a step at the headline
+ * configuration) may still be running on the mesh's stream, and the next rt_segmentize queues behind it, so consecutive calls
+ * leave no host turnaround between their kernels.  Every entry point that reads results (rt_fetch_*, rt_device_pointers,
+ * rt_fill_tau, rt_sweep*, rt_last_timing, rt_tracks_destroy) first waits; a consumer with its own stream orders against
+ * rt_mesh_get_stream or calls rt_wait.  Default 0: segmentize! semantics, everything is complete at return.  Calls that march
+ * track pieces, or with the "timing" option on, always complete before they return. */
+int32_t rt_wait(rt_tracks *tracks);
 
 /* Copy results into caller-allocated host buffers (any pointer may be NULL to skip it). */
 int32_t rt_fetch_offsets(rt_tracks *tracks, int64_t *seg_offsets, int32_t *status);
@@ -346,6 +354,7 @@ void rt_msh_free(rt_msh *msh);
 
 /* Tunables (name/value); unknown names return RT_ERR_INVALID.  See DESIGN.md.  The ones a caller may want:
  *   "timing"   1: record HIP events for rt_last_timing (default 0)
+ *   "async"    1: stream-ordered calls, see rt_wait (default 0)
  *   "compact"  0: rt_segmentize stops after march + offsets scan — offsets, status and volumes are final, the 44-B records
  *                 stay in the march's staging rows (20 B/segment) and are only produced when somebody asks for them
  *                 (rt_fetch_segments*, rt_device_pointers, rt_fill_tau); rt_sweep reads the staged rows directly (default 1)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RT_SEGMENTIZE_LIB") or os.path.join(_CSRC, "librt_seg
 SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_status_message", "rt_device_count",
     "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_info", "rt_last_stats", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
-    "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks",
+    "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks", "rt_wait",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
     "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_multi_link_rates",
@@ -113,6 +113,8 @@ def lib():
     L.rt_tracks_destroy.argtypes = [_vp]
     L.rt_segmentize.restype = C.c_int64
     L.rt_segmentize.argtypes = [_vp, C.c_double, C.c_int32, C.c_double, _dp, C.c_int32]
+    L.rt_wait.restype = C.c_int32
+    L.rt_wait.argtypes = [_vp]
     L.rt_failed_tracks.restype = C.c_int32
     L.rt_failed_tracks.argtypes = [_vp, _lp, _lp, _ip]
     L.rt_fetch_offsets.restype = C.c_int32
@@ -305,6 +307,11 @@ class DeviceTracks:
         n, u, st = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         _check(lib().rt_failed_tracks(self._h, C.byref(n), C.byref(u), C.byref(st)))
         return n.value, u.value, st.value
+
+    def wait(self):
+        """``rt_wait``: with the mesh option ``"async"`` a ``segmentize`` returns while its compaction is still on the stream;
+        every accessor waits by itself, this is for consumers that use the device pointers on a stream of their own."""
+        _check(lib().rt_wait(self._h))
 
     def fetch_offsets(self):
         off = np.zeros(self.n + 1, np.int64)

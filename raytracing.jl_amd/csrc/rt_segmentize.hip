@@ -1328,7 +1328,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
                                                                unsigned int *__restrict__ ticket,
                                                                const unsigned long long *__restrict__ ctl,
                                                                unsigned long long *__restrict__ host_copy,
-                                                               unsigned long long *__restrict__ ctl_next, int32_t first_chunk_next) {
+                                                               unsigned long long *__restrict__ ctl_next, int32_t first_chunk_next,
+                                                               unsigned long long seq) {
     __shared__ int64_t red[kScanBlock / 64];
     __shared__ int64_t carry;
     __shared__ int last;
@@ -1375,6 +1376,13 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
         __syncthreads();
         __threadfence();
         if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __builtin_nontemporal_load(&ctl[threadIdx.x]);
+        // the call's sequence number behind the copy, written once the copy is visible to the host: a stream-ordered call
+        // (option "async") returns when it sees it, while the compaction is still running
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&host_copy[kCtlWords], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (ctl_next && threadIdx.x < kCtlWords) {
         const int i = threadIdx.x;
@@ -1804,6 +1812,8 @@ struct rt_mesh {
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
                            // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is
                            // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
+    int async_calls = 0;   // 1: rt_segmentize returns once total, status summary and offsets' scan are known to the host; the
+                           // compaction may still be running on the stream (every entry point that touches results waits)
     int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
     double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0;
@@ -1895,6 +1905,8 @@ struct rt_tracks {
         bool split = false, split_all = false, staged = false;  // staged: the last call left staged rows (single-pass mode)
     } cplan;
     bool compacted = false;  // the six record arrays hold the last call's records
+    bool in_flight = false;  // option "async": the last rt_segmentize returned while its compaction was still on the stream
+    unsigned long long call_seq = 0;  // sequence number the scan writes behind its host copy of the control block
     // rt_sweep: the gather map of the cyclic linking, per-track weights, cross sections, boundary fluxes, tallies
     DevBuf<int32_t> sw_src;
     DevBuf<double> sw_w, sw_xs, sw_psi_in, sw_psi_out, sw_phi;
@@ -1919,6 +1931,31 @@ hipError_t wait_stream(hipStream_t s) {
         if (e != hipErrorNotReady) return e;
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) return hipStreamSynchronize(s);
     }
+}
+
+// Stream-ordered calls (option "async"): wait until the scan's host copy of the control block carries this call's sequence number.
+// Falls back to waiting for the stream when the number does not arrive (a failed launch never writes it).
+hipError_t wait_seq(const unsigned long long *h_res, unsigned long long seq, hipStream_t s) {
+    const volatile unsigned long long *flag = h_res + rt::kCtlWords;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+        if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) {
+            const hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return e;
+            return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq ? hipSuccess : hipErrorUnknown;
+        }
+    }
+}
+
+// Every entry point that reads what a call produced first waits for a call that is still on the stream (option "async").
+int finish_call(rt_tracks *t) {
+    if (t && t->in_flight) {
+        RT_HIP(hipSetDevice(t->mesh->device));
+        RT_HIP(wait_stream(t->mesh->stream));
+        t->in_flight = false;
+    }
+    return RT_SUCCESS;
 }
 
 template <typename T>
@@ -2227,6 +2264,8 @@ void rt_mesh_destroy(rt_mesh *mesh) {
 
 int32_t rt_mesh_set_stream(rt_mesh *mesh, void *hip_stream) {
     if (!mesh) { set_error("null mesh"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(mesh->device));
+    RT_HIP(hipStreamSynchronize(mesh->stream));  // (a stream-ordered call, option "async", may still be on the old stream)
     mesh->stream = hip_stream ? (hipStream_t)hip_stream : mesh->own_stream;
     return RT_SUCCESS;
 }
@@ -2257,6 +2296,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "lds_records")) { mesh->lds_records = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "async")) { mesh->async_calls = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "hybrid")) { mesh->hybrid = value != 0; return RT_SUCCESS; }          // read by rt_tracks_create
     if (!strcmp(name, "hybrid_pct")) { mesh->hybrid_pct = (int)std::min<int64_t>(95, std::max<int64_t>(30, value)); return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
@@ -2429,6 +2469,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
 void rt_tracks_destroy(rt_tracks *tracks) {
     if (!tracks) return;
     (void)hipSetDevice(tracks->mesh->device);
+    (void)finish_call(tracks);
     free_tracks(tracks);
 }
 
@@ -2473,8 +2514,8 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     RT_HIP(t->ctl.reserve(2 * rt::kCtlWords));
     RT_HIP(t->vacc.reserve(m->n_cells));
     if (!t->h_ctl) {
-        RT_HIP(hipHostMalloc((void **)&t->h_ctl, 2 * rt::kCtlWords * sizeof(unsigned long long), hipHostMallocDefault));
-        for (int i = 0; i < 2 * rt::kCtlWords; ++i) t->h_ctl[i] = 0;
+        RT_HIP(hipHostMalloc((void **)&t->h_ctl, (2 * rt::kCtlWords + 8) * sizeof(unsigned long long), hipHostMallocDefault));
+        for (int i = 0; i < 2 * rt::kCtlWords + 8; ++i) t->h_ctl[i] = 0;  // (h_res[kCtlWords]: the sequence number of the call it holds)
         t->h_ctl[1] = ~0ull;  // first failing uid: atomicMin target
     }
     // the call's control block: calls alternate between two, and the scan of a call resets the other one for the next call —
@@ -2553,7 +2594,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, n_tiles, d_total, reinterpret_cast<unsigned int *>(d_ctl + 20),
                                (const unsigned long long *)d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
-                               copy_out ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call);
+                               copy_out ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, ++t->call_seq);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, d_total, t->offsets.p, scale ? t->volumes.p : (double *)nullptr, m->n_cells,
                                (double)n_azim_2, t->vacc.p);
@@ -2763,7 +2804,12 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             int32_t cur[4] = {0, 0, 0, 0};
             if (n == 0) RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
-            RT_HIP(wait_stream(s));
+            // option "async": back to the caller as soon as the scan's copy of the control block has arrived — total, failure
+            // summary and pool cursor are final then, the compaction goes on behind the call (whole-track calls without events)
+            const bool async_call = m->async_calls && !m->timing && n > 0 && !split && !hybrid;
+            if (async_call) RT_HIP(wait_seq(h_res, t->call_seq, s));
+            else RT_HIP(wait_stream(s));
+            t->in_flight = async_call;
 #ifdef RT_HOST_TIMING
             {
                 const double ht3 = ht_now();
@@ -2906,6 +2952,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     return total;
 }
 
+int32_t rt_wait(rt_tracks *t) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    return finish_call(t);
+}
+
 int32_t rt_failed_tracks(rt_tracks *t, int64_t *n_failed, int64_t *first_uid, int32_t *first_status) {
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
@@ -2918,6 +2969,7 @@ int32_t rt_failed_tracks(rt_tracks *t, int64_t *n_failed, int64_t *first_uid, in
 int32_t rt_fetch_offsets(rt_tracks *t, int64_t *seg_offsets, int32_t *status) {
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     if (seg_offsets) RT_HIP(hipMemcpy(seg_offsets, t->offsets.p, sizeof(int64_t) * (t->n + 1), hipMemcpyDeviceToHost));
     if (status && t->n) RT_HIP(hipMemcpy(status, t->status.p, sizeof(int32_t) * t->n, hipMemcpyDeviceToHost));
@@ -2928,6 +2980,7 @@ int32_t rt_fetch_segments(rt_tracks *t, double *px, double *py, double *qx, doub
                           int32_t *element) {
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     if (int rc = ensure_compacted(t)) return rc;
     const size_t nb = sizeof(double) * (size_t)t->total;
@@ -2969,6 +3022,7 @@ void pin_release_to_cache(rt_tracks *t) {
 int32_t rt_fetch_segments_pinned(rt_tracks *t, void **host_ptrs) {
     if (!t || !host_ptrs) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     if (int rc = ensure_compacted(t)) return rc;
     const size_t n = (size_t)t->total;
@@ -2999,6 +3053,7 @@ int32_t rt_fetch_segments_pinned(rt_tracks *t, void **host_ptrs) {
 int32_t rt_fetch_pinned(rt_tracks *t, void **host_ptrs) {
     if (!t || !host_ptrs) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     if (!t->pin_off) RT_HIP(hipHostMalloc((void **)&t->pin_off, sizeof(int64_t) * (size_t)(t->n + 1), hipHostMallocDefault));
     if (!t->pin_st) RT_HIP(hipHostMalloc((void **)&t->pin_st, sizeof(int32_t) * (size_t)std::max<int64_t>(t->n, 1), hipHostMallocDefault));
@@ -3015,6 +3070,7 @@ int32_t rt_fetch_pinned(rt_tracks *t, void **host_ptrs) {
 int32_t rt_fetch_volumes(rt_tracks *t, double *volumes) {
     if (!t || !volumes) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     RT_HIP(hipMemcpy(volumes, t->volumes.p, sizeof(double) * t->mesh->n_cells, hipMemcpyDeviceToHost));
     return RT_SUCCESS;
@@ -3024,6 +3080,7 @@ int32_t rt_fill_tau(rt_tracks *t, const double *sigma_t, int32_t n_groups, void 
     if (!t || !sigma_t || n_groups <= 0) { set_error("rt_fill_tau: bad arguments"); return RT_ERR_INVALID; }
     if (n_groups > 1024) { set_error("rt_fill_tau: at most 1024 groups"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     rt_mesh *m = t->mesh;
     RT_HIP(hipSetDevice(m->device));
     if (int rc = ensure_compacted(t)) return rc;
@@ -3051,6 +3108,7 @@ int32_t rt_fill_tau(rt_tracks *t, const double *sigma_t, int32_t n_groups, void 
 int32_t rt_fetch_tau(rt_tracks *t, double *tau) {
     if (!t || !tau) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized || t->tau_groups <= 0) { set_error("rt_fill_tau has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     const size_t n = (size_t)t->total * (size_t)t->tau_groups;
     if (n) RT_HIP(hipMemcpy(tau, t->tau.p, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -3180,6 +3238,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     RT_HIP(hipGetLastError());
     if (ms) { float f = 0; RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[7])); *ms = f; }
     t->sw_done = true;
+    t->in_flight = false;  // (the sweep waited for the stream)
     t->sw_last_input = staged ? 2 : 1; t->sw_last_gp = a.use_lds ? gp : 0; t->sw_last_passes = passes;
     return RT_SUCCESS;
 }
@@ -3207,6 +3266,7 @@ int32_t rt_sweep(rt_tracks *t, int32_t n_groups, const double *sigma_t, const do
 int32_t rt_sweep_fetch(rt_tracks *t, double *phi, double *psi_out, double *psi_next) {
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->sw_done) { set_error("rt_sweep has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     const size_t npsi = (size_t)(2 * t->n * t->sw_groups), nphi = (size_t)t->mesh->n_cells * t->sw_groups;
     if (phi) RT_HIP(hipMemcpy(phi, t->sw_phi.p, nphi * sizeof(double), hipMemcpyDeviceToHost));
@@ -3218,6 +3278,7 @@ int32_t rt_sweep_fetch(rt_tracks *t, double *phi, double *psi_out, double *psi_n
 int32_t rt_sweep_info(rt_tracks *t, void **ptrs_dev, int32_t *info) {
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->sw_done) { set_error("rt_sweep has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     if (ptrs_dev) { ptrs_dev[0] = t->sw_phi.p; ptrs_dev[1] = t->sw_psi_out.p; ptrs_dev[2] = t->sw_psi_in.p; }
     if (info) { info[0] = t->sw_last_input; info[1] = t->sw_last_gp; info[2] = t->sw_last_passes; info[3] = t->sw_groups; }
     return RT_SUCCESS;
@@ -3226,6 +3287,7 @@ int32_t rt_sweep_info(rt_tracks *t, void **ptrs_dev, int32_t *info) {
 int32_t rt_device_pointers(rt_tracks *t, void **p) {
     if (!t || !p) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     RT_HIP(hipSetDevice(t->mesh->device));
     if (int rc = ensure_compacted(t)) return rc;
     p[0] = t->offsets.p; p[1] = t->status.p; p[2] = t->spx.p; p[3] = t->spy.p; p[4] = t->sqx.p;
@@ -3278,6 +3340,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
 int32_t rt_last_timing(rt_tracks *t, double *ms, int32_t n) {
     if (!t || !ms || n < 6) { set_error("bad argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
     for (int i = 0; i < n && i < 8; ++i) ms[i] = t->ms[i];
     return RT_SUCCESS;
 }
