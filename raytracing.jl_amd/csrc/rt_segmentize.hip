@@ -3193,41 +3193,54 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     a.xs = as_global((const double *)t->sw_xs.p);
     a.psi_in = as_global((const double *)t->sw_psi_in.p); a.psi_out = as_global(t->sw_psi_out.p); a.phi = as_global(t->sw_phi.p);
     a.n = n; a.n_waves = (int32_t)((n + 63) / 64); a.n_cells = m->n_cells; a.G = G; a.debug = m->sweep_debug;
-    // groups per pass: as many as an LDS-private copy of their tallies allows (4, 2 or 1); none fits: global atomics
+    // groups per pass: as many as an LDS-private copy of their tallies allows (up to 4); none fits: global atomics.  The last pass
+    // takes what is left with the kernel compiled for that many groups (7 groups = 4 + 3: a padded fourth group was an eighth
+    // of the sweep's arithmetic).
     const size_t lds_cap = (size_t)std::min(m->lds_per_block, 160 * 1024) - 1024;
-    int gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
-    if (m->sweep_gp == 1 || m->sweep_gp == 2 || m->sweep_gp == 4) gp = m->sweep_gp;
-    while (gp > 1 && (size_t)m->n_cells * gp * sizeof(double) > lds_cap) gp >>= 1;
+    int gp = std::min(G, 4);
+    if (m->sweep_gp >= 1 && m->sweep_gp <= 4) gp = std::min(gp, m->sweep_gp);
+    while (gp > 1 && (size_t)m->n_cells * gp * sizeof(double) > lds_cap) --gp;
     a.use_lds = (size_t)m->n_cells * gp * sizeof(double) <= lds_cap ? 1 : 0;
-    if (!a.use_lds) gp = G >= 3 ? 4 : (G == 2 ? 2 : 1);
+    if (!a.use_lds) gp = std::min(G, 4);
     if (m->sweep_gp >= 8) a.use_lds = 0;  // experiment: tallies straight to HBM (measured 4x slower at C3: 2.1 ms against 0.48)
-    const size_t smem = a.use_lds ? (size_t)m->n_cells * gp * sizeof(double) : 0;
-    // one workgroup per CU (its tallies fill the LDS): sixteen waves when the rows are the staging rows (every load
-    // instruction reads four full lines), eight when they are the compact records (64 lanes, 64 lines: sixteen waves
-    // thrash the CU's L1 — 1.04 against 0.62 ms at C3); two or more workgroups per CU: eight waves each
-    int W = (smem > 79 * 1024 && staged) ? 16 : 8;
-    if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
-    const unsigned blocks = (unsigned)((2 * (int64_t)a.n_waves + W - 1) / W);
     RT_HIP(hipEventRecord(t->ev[0], s));
     RT_HIP(hipMemsetAsync(t->sw_phi.p, 0, nphi * sizeof(double), s));
     int passes = 0;
-    auto launch = [&]<bool STAGED, int GP, bool LDS>() -> int {
+    auto launch = [&]<bool STAGED, int GP, bool LDS>(int g0) -> int {
+        size_t smem = a.use_lds ? (size_t)m->n_cells * GP * sizeof(double) : 0;
+        // (compact records: more than one eight-wave workgroup per CU thrashes its L1 — a pass of few groups asks for LDS it
+        //  does not use, so that it still gets a CU to itself: 5 groups = 4 + 1 took 0.88 ms against 0.58 for 7 = 4 + 3)
+        if (!STAGED && a.use_lds) smem = std::max(smem, std::min(lds_cap, (size_t)81 * 1024));
+        // one workgroup per CU (its tallies fill the LDS): sixteen waves when the rows are the staging rows (every load
+        // instruction reads four full lines), eight when they are the compact records (64 lanes, 64 lines: sixteen waves
+        // thrash the CU's L1 — 1.04 against 0.62 ms at C3); two or more workgroups per CU: eight waves each
+        int W = (smem > 79 * 1024 && STAGED) ? 16 : 8;
+        if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
+        const unsigned blocks = (unsigned)((2 * (int64_t)a.n_waves + W - 1) / W);
         if (smem > 48 * 1024)
             RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        for (int g0 = 0; g0 < G; g0 += GP) {
-            a.g0 = g0; a.ng = std::min(GP, G - g0);
-            hipLaunchKernelGGL((rt::k_sweep<STAGED, GP, LDS>), dim3(blocks), dim3(64 * W), smem, s, a);
-            ++passes;
+        a.g0 = g0; a.ng = GP;
+        hipLaunchKernelGGL((rt::k_sweep<STAGED, GP, LDS>), dim3(blocks), dim3(64 * W), smem, s, a);
+        ++passes;
+        return RT_SUCCESS;
+    };
+    auto launch_all = [&]<bool STAGED, bool LDS>() -> int {
+        for (int g0 = 0; g0 < G;) {
+            const int take = std::min(gp, G - g0);
+            int rc;
+            if (take == 4) rc = launch.template operator()<STAGED, 4, LDS>(g0);
+            else if (take == 3) rc = launch.template operator()<STAGED, 3, LDS>(g0);
+            else if (take == 2) rc = launch.template operator()<STAGED, 2, LDS>(g0);
+            else rc = launch.template operator()<STAGED, 1, LDS>(g0);
+            if (rc) return rc;
+            g0 += take;
         }
         return RT_SUCCESS;
     };
-    auto launch_gp = [&]<bool STAGED, bool LDS>() -> int {
-        return gp == 4 ? launch.template operator()<STAGED, 4, LDS>() : (gp == 2 ? launch.template operator()<STAGED, 2, LDS>() : launch.template operator()<STAGED, 1, LDS>());
-    };
     if (n > 0) {
         int rc;
-        if (staged) rc = a.use_lds ? launch_gp.template operator()<true, true>() : launch_gp.template operator()<true, false>();
-        else rc = a.use_lds ? launch_gp.template operator()<false, true>() : launch_gp.template operator()<false, false>();
+        if (staged) rc = a.use_lds ? launch_all.template operator()<true, true>() : launch_all.template operator()<true, false>();
+        else rc = a.use_lds ? launch_all.template operator()<false, true>() : launch_all.template operator()<false, false>();
         if (rc) return rc;
         const int64_t nl = 2 * n * G;
         hipLaunchKernelGGL(rt::k_sweep_link, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, (const int32_t *)t->sw_src.p,
