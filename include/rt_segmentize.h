@@ -355,6 +355,8 @@ void rt_msh_free(rt_msh *msh);
 /* Tunables (name/value); unknown names return RT_ERR_INVALID.  See DESIGN.md.  The ones a caller may want:
  *   "timing"   1: record HIP events for rt_last_timing (default 0)
  *   "async"    1: stream-ordered calls, see rt_wait (default 0)
+ *   "sweep_ell" 0: every pass of rt_sweep over the staged rows derives ℓ from the exit points; default 1: the first pass after an
+ *                 rt_segmentize keeps ℓ per row (8 B per staging slot) and every later pass and sweep reads (ℓ, cell) rows
  *   "compact"  0: rt_segmentize stops after march + offsets scan — offsets, status and volumes are final, the 44-B records
  *                 stay in the march's staging rows (20 B/segment) and are only produced when somebody asks for them
  *                 (rt_fetch_segments*, rt_device_pointers, rt_fill_tau); rt_sweep reads the staged rows directly (default 1)

@@ -1539,6 +1539,8 @@ struct DSweep {
     int64_t n;
     int32_t n_waves, n_cells, G, g0, ng, use_lds;
     int32_t debug;  // development: bit 0 skip the tallies
+    RT_G double *ell_rows;  // STAGED: ℓ of every staged row, slot-indexed like the rows — written by the forward waves of a pass that
+                            // derives ℓ from the exit points (when non-null), read by the ELLROWS passes instead of the exit points
 };
 
 // Software pipeline (the row addresses do not depend on data, unlike the march's): in iteration t the rows of step t + 2 and
@@ -1546,8 +1548,9 @@ struct DSweep {
 // results masked) so that no wait is forced by a branch, and the one rare load inside a branch — the staged entry point of a
 // marked record — is issued BEFORE the iteration's prefetches: gfx950 returns loads in order, so waiting for it leaves the
 // prefetches in flight.  The wave's chunk ids sit in registers (lane j holds chunk j) and are read with v_readlane.
-template <bool STAGED, int GP, bool LDS>
+template <bool STAGED, int GP, bool LDS, bool ELLROWS>
 __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
+    static_assert(STAGED || !ELLROWS, "ℓ rows belong to the staging rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char sweep_smem[];
     double *hist = reinterpret_cast<double *>(sweep_smem);  // [n_cells * GP] when LDS
     const int lane = threadIdx.x & 63;
@@ -1688,7 +1691,7 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                 // Measured at C3, 7 groups, same box: rotating by moves 0.373 ms, three steps per round 0.358, six (the cross
                 // sections' two stages rotated as well; 32 scalar registers spilled) 0.366; one copy of the loop per direction
                 // (forward and backward waves of a CU then run different code) 0.396.
-                {
+                if constexpr (!ELLROWS) {
                     const int DIR = dir;
                     auto row_d = row_of;
                     Row R0 = load_row(row_d(0)), R1 = load_row(row_d(1)), R2{0.0, 0.0, 0};
@@ -1710,12 +1713,38 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                         load_xs(cell_of(Rb, row_d(t + 1)), st1, qs1);
                         if (marked) { dx = px - Ra.qx; dy = py - Ra.qy; }
                         const double ell = norm2(dx, dy);  // Segment ctor, src/segment.jl:31-33 (as k_compact3)
+                        if (a.ell_rows != nullptr && !DIR && act) a.ell_rows[sl0] = ell;  // (uniform && uniform && lane: for the ELLROWS passes)
                         segment(cell_of(Ra, r), ell, act, st0, qs0);
                     };
                     for (int t = 0; t < maxcnt; t += 3) {
                         step(t, R0, R1, R2, stA, qsA, stB, qsB);
                         step(t + 1, R1, R2, R0, stB, qsB, stA, qsA);
                         step(t + 2, R2, R0, R1, stA, qsA, stB, qsB);
+#pragma unroll
+                        for (int g = 0; g < GP; ++g) { stA[g] = stB[g]; qsA[g] = qsB[g]; }
+                    }
+                }
+                if constexpr (ELLROWS) {
+                    // the same pipeline over (ℓ, cell) rows — ℓ as an earlier pass over these staging rows left it: 12 B per row instead
+                    // of 20, no square root, no entry point to pick
+                    struct LRow { double ell; int32_t el; };
+                    auto load_lrow = [&](const int64_t sl) -> LRow { return LRow{a.ell_rows[sl], a.stg.element[sl]}; };
+                    auto lcell = [&](const LRow &R, const int r) -> int32_t { return r < cnt ? (R.el < 0 ? -R.el : R.el) - 1 : 0; };
+                    LRow L0 = load_lrow(slot_of(row_of(0))), L1 = load_lrow(slot_of(row_of(1))), L2{0.0, 0};
+                    double stA[GP], qsA[GP], stB[GP], qsB[GP];
+                    load_xs(lcell(L0, row_of(0)), stA, qsA);
+                    auto lstep = [&](const int t, const LRow &Ra, const LRow &Rb, LRow &Rc, const double (&st0)[GP], const double (&qs0)[GP],
+                                     double (&st1)[GP], double (&qs1)[GP]) {
+                        const int r = row_of(t);
+                        const bool act = r < cnt && t < maxcnt;
+                        Rc = load_lrow(slot_cached(row_of(t + 2), cj2, cid2));
+                        load_xs(lcell(Rb, row_of(t + 1)), st1, qs1);
+                        segment(lcell(Ra, r), Ra.ell, act, st0, qs0);
+                    };
+                    for (int t = 0; t < maxcnt; t += 3) {
+                        lstep(t, L0, L1, L2, stA, qsA, stB, qsB);
+                        lstep(t + 1, L1, L2, L0, stB, qsB, stA, qsA);
+                        lstep(t + 2, L2, L0, L1, stA, qsA, stB, qsB);
 #pragma unroll
                         for (int g = 0; g < GP; ++g) { stA[g] = stB[g]; qsA[g] = qsB[g]; }
                     }
@@ -1804,6 +1833,7 @@ struct rt_mesh {
     int n_cus = 256;
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
+    int sweep_ell = 1;  // rt_sweep over staged rows: keep ℓ of every row from the first pass for the later ones (0: every pass derives it)
     int sweep_debug = 0, compact_debug = 0;
     int march_waves = 0;     // 4 / 6: waves per workgroup of the fused march (0: automatic)
     int compact_kernel = 0;  // 4: k_compact4 (memory-order stores) for whole-track batches; else k_compact3
@@ -1910,6 +1940,8 @@ struct rt_tracks {
     // rt_sweep: the gather map of the cyclic linking, per-track weights, cross sections, boundary fluxes, tallies
     DevBuf<int32_t> sw_src;
     DevBuf<double> sw_w, sw_xs, sw_psi_in, sw_psi_out, sw_phi;
+    DevBuf<double> sw_ell;      // ℓ of every staged row (slot-indexed like the staging pool), left by the first staged pass after a call
+    bool sw_ell_valid = false;  // ... of the last rt_segmentize
     bool sw_links = false, sw_has_w = false, sw_has_xs = false, sw_done = false;
     int32_t sw_groups = 0, sw_last_input = 0, sw_last_gp = 0, sw_last_passes = 0;
     int64_t refusals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // cheap-step refusals of the last call by certificate term
@@ -2287,6 +2319,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "fuse_volumes")) { mesh->fuse_volumes = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "compact")) { mesh->compact = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "sweep_ell")) { mesh->sweep_ell = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_debug")) { mesh->compact_debug = (int)value; return RT_SUCCESS; }
@@ -2611,6 +2644,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         return RT_SUCCESS;
     };
     t->compacted = false;
+    t->sw_ell_valid = false;
     t->cplan = rt_tracks::CompactPlan{};
     // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
     bool fused_volumes_this_call = false;
@@ -3206,6 +3240,16 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     RT_HIP(hipEventRecord(t->ev[0], s));
     RT_HIP(hipMemsetAsync(t->sw_phi.p, 0, nphi * sizeof(double), s));
     int passes = 0;
+    // Staged rows: the first pass after an rt_segmentize derives ℓ from the exit points and leaves it in `sw_ell`, slot-indexed
+    // like the rows; every later pass — of this sweep and of all following sweeps over the same segmentation — reads (ℓ, cell)
+    // rows instead (12 B instead of 20, no square root, no entry point).  Option "sweep_ell" = 0 switches this off.
+    bool ell_rows = false;
+    if (staged && m->sweep_ell) {
+        const size_t slots = (size_t)t->pool_chunks * rt::kChunkRows * 64;
+        if (t->sw_ell.reserve(slots > 0 ? slots : 1) == hipSuccess) ell_rows = true;
+        else (void)hipGetLastError();  // (no memory for it: every pass derives ℓ itself)
+    }
+    a.ell_rows = ell_rows ? as_global(t->sw_ell.p) : nullptr;
     auto launch = [&]<bool STAGED, int GP, bool LDS>(int g0) -> int {
         size_t smem = a.use_lds ? (size_t)m->n_cells * GP * sizeof(double) : 0;
         // (compact records: more than one eight-wave workgroup per CU thrashes its L1 — a pass of few groups asks for LDS it
@@ -3217,10 +3261,19 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
         int W = (smem > 79 * 1024 && STAGED) ? 16 : 8;
         if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
         const unsigned blocks = (unsigned)((2 * (int64_t)a.n_waves + W - 1) / W);
-        if (smem > 48 * 1024)
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         a.g0 = g0; a.ng = GP;
-        hipLaunchKernelGGL((rt::k_sweep<STAGED, GP, LDS>), dim3(blocks), dim3(64 * W), smem, s, a);
+        if (STAGED && ell_rows && t->sw_ell_valid) {
+            if constexpr (STAGED) {
+                if (smem > 48 * 1024)
+                    RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<true, GP, LDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                hipLaunchKernelGGL((rt::k_sweep<true, GP, LDS, true>), dim3(blocks), dim3(64 * W), smem, s, a);
+            }
+        } else {
+            if (smem > 48 * 1024)
+                RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP, LDS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((rt::k_sweep<STAGED, GP, LDS, false>), dim3(blocks), dim3(64 * W), smem, s, a);
+            if (STAGED && ell_rows) t->sw_ell_valid = true;  // (the forward waves of this pass have written every row's ℓ)
+        }
         ++passes;
         return RT_SUCCESS;
     };
@@ -3345,7 +3398,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
                    b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +
                    b(t->w_base) + b(t->w_P) + b(t->s_el) + b(t->s_eq) + b(t->p_count) + b(t->p_flags) + b(t->p_valid) + b(t->p_rel) + b(t->s_px) +
                    b(t->s_py) + b(t->s_qx) + b(t->s_qy) + b(t->s_ell) + b(t->p_sum) + b(t->vacc) + b(t->fst_i) + b(t->fst_v) + b(t->tau) +
-                   b(t->sigma_t) + b(t->sw_src) + b(t->sw_w) + b(t->sw_xs) + b(t->sw_psi_in) + b(t->sw_psi_out) + b(t->sw_phi);
+                   b(t->sigma_t) + b(t->sw_src) + b(t->sw_w) + b(t->sw_xs) + b(t->sw_psi_in) + b(t->sw_psi_out) + b(t->sw_phi) + b(t->sw_ell);
     }
     return RT_SUCCESS;
 }

@@ -179,3 +179,27 @@ def test_sweep_properties_at_full_size(rt, mesh, n_azim, delta):
     assert np.allclose(rc["phi"], r["phi"], rtol=1e-11, atol=1e-300)
     print(f"{mesh} nφ={n_azim} δ={delta}: {dt.total} segments, staged {r['ms']:.3f} ms ({r['passes']} passes of {r['groups_per_pass']}), compact {rc['ms']:.3f} ms")
     dt.close(); dm.close()
+
+
+def test_ell_rows_of_the_first_staged_pass_change_nothing(rt):
+    """Staged input: the first pass after a segmentize leaves ℓ per row, later passes and sweeps read (ℓ, cell) rows (option
+    "sweep_ell", default 1).  Same bits as deriving ℓ from the exit points in every pass — also after a new rt_segmentize."""
+    model = rt.GmshDiscreteModel(rt.data_path("pincell.msh"))
+    tg = rt.TrackGenerator(model, 32, 5e-3, bcs=_bcs(rt, "mixed"))
+    rt.trace(tg)
+    G = 7
+    sigma_t, source, weight, psi_in = _problem(rt, tg, G, 11)
+    aq = tg.azimuthal_quadrature
+    res = []
+    for ell in (0, 1):
+        dm, dt = _device(rt, tg, 0, split=0, sweep_ell=ell)
+        a = dt.sweep(G, sigma_t, source, weight, psi_in, input="staged")
+        b = dt.sweep(G, input="staged")                       # second sweep: every pass on (ℓ, cell) rows
+        dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)  # the rows are rewritten: ℓ must be derived again
+        c = dt.sweep(G, None, None, None, psi_in, input="staged")
+        res.append((a, b, c))
+        dt.close(); dm.close()
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x["psi_out"], y["psi_out"])
+        _close(x["phi"], y["phi"], "phi")  # (the tallies add in another order from run to run)
+    assert np.array_equal(res[1][0]["psi_out"], res[1][2]["psi_out"])  # same fluxes in: the first sweep again
