@@ -97,14 +97,14 @@ def test_sweep_matches_sequential_sweep_over_oracle_records(rt, orc, mesh, n_azi
 
 
 def test_sweep_default_weight_and_group_slabs(rt, orc, traced, oracle_run):
-    """Default weights are fill_volumes' δs[azim_idx]; 1, 2 and 4 groups per pass (and global atomics) give the same tallies."""
+    """Default weights are fill_volumes' δs[azim_idx]; 1 to 4 groups per pass (and global atomics) give the same tallies."""
     tg = traced(16, 1e-2)
     ref = oracle_run(tg)
     G = 5
     sigma_t, source, _, psi_in = _problem(rt, tg, G, 11)
     aq = tg.azimuthal_quadrature
     phi, out = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, aq.delta_s[tg.azim_idx - 1], psi_in)
-    for gp in (0, 1, 2, 4):
+    for gp in (0, 1, 2, 3, 4):
         for waves in (0, 4):
             dm, dt = _device(rt, tg, 0, sweep_gp=gp, sweep_waves=waves)
             r = dt.sweep(G, sigma_t, source, None, psi_in)
