@@ -241,6 +241,11 @@ int32_t rt_sweep(rt_tracks *tracks, int32_t n_groups, const double *sigma_t, con
                  const double *track_weight, const double *psi_in, int32_t input, double *ms);
 int32_t rt_sweep_fetch(rt_tracks *tracks, double *phi, double *psi_out, double *psi_next);
 int32_t rt_sweep_info(rt_tracks *tracks, void **ptrs_dev, int32_t *info);
+/* The device copy of the cross sections as rt_sweep reads them: [n_cells * n_groups][2] doubles = {sigma_t, source / sigma_t}
+ * (0 for the second where sigma_t = 0).  A solver that updates its source on the device writes the second components there —
+ * ordered against rt_mesh_get_stream — and calls rt_sweep with sigma_t = source = NULL ("those of the previous call"): no
+ * host round trip between sweeps.  Valid until the group count changes. */
+int32_t rt_sweep_xs_pointer(rt_tracks *tracks, void **xs_dev);
 
 /*
  * HIP-event timings (milliseconds) of the last rt_segmentize on this handle, measured on

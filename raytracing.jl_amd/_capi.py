@@ -20,7 +20,7 @@ SYMBOLS = (
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks", "rt_wait",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
-    "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_multi_link_rates",
+    "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_sweep_xs_pointer", "rt_multi_link_rates",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
     "rt_multi_failed_tracks", "rt_multi_fetch_offsets", "rt_multi_fetch_segments", "rt_multi_fetch_volumes", "rt_multi_allgather",
     "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
@@ -145,6 +145,8 @@ def lib():
         L.rt_sweep.argtypes = [_vp, C.c_int32, _dp, _dp, _dp, _dp, C.c_int32, _dp]
         L.rt_sweep_fetch.restype = C.c_int32
         L.rt_sweep_fetch.argtypes = [_vp, _dp, _dp, _dp]
+        L.rt_sweep_xs_pointer.restype = C.c_int32
+        L.rt_sweep_xs_pointer.argtypes = [_vp, C.POINTER(_vp)]
         L.rt_sweep_info.restype = C.c_int32
         L.rt_sweep_info.argtypes = [_vp, C.POINTER(_vp), _ip]
         L.rt_multi_link_rates.restype = C.c_int32
@@ -447,6 +449,13 @@ class DeviceTracks:
         info = (C.c_int32 * 4)()
         _check(lib().rt_sweep_info(self._h, ptrs, info))
         return dict(phi=ptrs[0] or 0, psi_out=ptrs[1] or 0, psi_in=ptrs[2] or 0, groups=int(info[3]))
+
+    def sweep_xs_pointer(self) -> int:
+        """``rt_sweep_xs_pointer``: device address of the cross sections as the sweep reads them, [n_cells * G][2] =
+        {Σt, q/Σt} — a solver updates the sources there and sweeps again with ``sigma_t = source = None``."""
+        p = _vp()
+        _check(lib().rt_sweep_xs_pointer(self._h, C.byref(p)))
+        return p.value or 0
 
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""

@@ -3350,6 +3350,14 @@ int32_t rt_sweep_info(rt_tracks *t, void **ptrs_dev, int32_t *info) {
     return RT_SUCCESS;
 }
 
+int32_t rt_sweep_xs_pointer(rt_tracks *t, void **xs_dev) {
+    if (!t || !xs_dev) { set_error("null argument"); return RT_ERR_INVALID; }
+    if (!t->sw_has_xs) { set_error("rt_sweep has not been given cross sections yet"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
+    *xs_dev = t->sw_xs.p;
+    return RT_SUCCESS;
+}
+
 int32_t rt_device_pointers(rt_tracks *t, void **p) {
     if (!t || !p) { set_error("null argument"); return RT_ERR_INVALID; }
     if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }

@@ -203,3 +203,30 @@ def test_ell_rows_of_the_first_staged_pass_change_nothing(rt):
         assert np.array_equal(x["psi_out"], y["psi_out"])
         _close(x["phi"], y["phi"], "phi")  # (the tallies add in another order from run to run)
     assert np.array_equal(res[1][0]["psi_out"], res[1][2]["psi_out"])  # same fluxes in: the first sweep again
+
+
+def test_source_updated_on_the_device(rt):
+    """rt_sweep_xs_pointer: a solver writes q/Σt into the sweep's device copy of the cross sections (torch here) and sweeps again
+    with sigma_t = source = None — the same result as handing the new source over from the host."""
+    import torch
+    from raytracing_jl_amd import distributed as rtd
+
+    model = rt.GmshDiscreteModel(rt.data_path("pincell.msh"))
+    tg = rt.TrackGenerator(model, 16, 1e-2, bcs=_bcs(rt, "reflective"))
+    rt.trace(tg)
+    G = 3
+    sigma_t, source, weight, psi_in = _problem(rt, tg, G, 5)
+    source2 = source[::-1].copy() * 0.5
+    dm, dt = _device(rt, tg, 0, split=0)
+    dt.sweep(G, sigma_t, source, weight, psi_in)
+    want = dt.sweep(G, sigma_t, source2, None, psi_in)      # new source from the host
+    dt.sweep(G, sigma_t, source, None, psi_in)               # back to the first one
+    nc = tg.mesh.num_cells
+    xs = torch.as_tensor(rtd.DevArray(dt.sweep_xs_pointer(), nc * G * 2, "<f8", dt), device="cuda:0").view(nc * G, 2)
+    assert np.array_equal(xs[:, 0].cpu().numpy().reshape(nc, G), sigma_t)
+    xs[:, 1] = torch.as_tensor((source2 / sigma_t).reshape(-1), device="cuda:0")
+    torch.cuda.synchronize()
+    got = dt.sweep(G, None, None, None, psi_in)              # cross sections "of the previous call": the updated device copy
+    assert np.array_equal(got["psi_out"], want["psi_out"])
+    _close(got["phi"], want["phi"], "phi")
+    dt.close(); dm.close()
