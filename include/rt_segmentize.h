@@ -148,7 +148,9 @@ int32_t rt_failed_tracks(rt_tracks *tracks, int64_t *n_failed, int64_t *first_ui
  * configuration) may still be running on the mesh's stream, and the next rt_segmentize queues behind it, so consecutive calls
  * leave no host turnaround between their kernels.  Every entry point that reads results (rt_fetch_*, rt_device_pointers,
  * rt_fill_tau, rt_sweep*, rt_last_timing, rt_tracks_destroy) first waits; a consumer with its own stream orders against
- * rt_mesh_get_stream or calls rt_wait.  Default 0: segmentize! semantics, everything is complete at return.  Calls that march
+ * rt_mesh_get_stream or calls rt_wait.  rt_sweep behaves the same way under the option: its kernels are queued and it returns
+ * (ms = 0), so that consecutive sweeps — with the source updated through rt_sweep_xs_pointer on the same stream — run without a
+ * host turnaround.  Default 0: segmentize! semantics, everything is complete at return.  Calls that march
  * track pieces, or with the "timing" option on, always complete before they return. */
 int32_t rt_wait(rt_tracks *tracks);
 

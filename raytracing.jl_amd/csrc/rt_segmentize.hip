@@ -3210,6 +3210,10 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
         t->sw_has_w = true;
     }
     if (psi_in && n > 0) RT_HIP(hipMemcpyAsync(t->sw_psi_in.p, psi_in, (size_t)(2 * n * G) * sizeof(double), hipMemcpyHostToDevice, s));
+    // option "async": the sweep's kernels are queued and the call returns (no events, no wait) — what was handed over in host
+    // arrays has to be on the device before that
+    const bool async_sweep = m->async_calls && !m->timing;
+    if (async_sweep && (track_weight || (psi_in && n > 0))) RT_HIP(hipStreamSynchronize(s));
     // which records: the march's staging rows (whole-track single-pass calls leave them behind) or the compact CSR arrays
     const bool staged_ok = t->cplan.staged && !t->cplan.split && t->cplan.n_whole_waves == (n + 63) / 64;
     if (input == 2 && !staged_ok) { set_error("rt_sweep: the last rt_segmentize left no whole-track staging rows (track pieces or two-pass mode)"); return RT_ERR_INVALID; }
@@ -3237,7 +3241,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     a.use_lds = (size_t)m->n_cells * gp * sizeof(double) <= lds_cap ? 1 : 0;
     if (!a.use_lds) gp = std::min(G, 4);
     if (m->sweep_gp >= 8) a.use_lds = 0;  // experiment: tallies straight to HBM (measured 4x slower at C3: 2.1 ms against 0.48)
-    RT_HIP(hipEventRecord(t->ev[0], s));
+    if (!async_sweep) RT_HIP(hipEventRecord(t->ev[0], s));
     RT_HIP(hipMemsetAsync(t->sw_phi.p, 0, nphi * sizeof(double), s));
     int passes = 0;
     // Staged rows: the first pass after an rt_segmentize derives ℓ from the exit points and leaves it in `sw_ell`, slot-indexed
@@ -3299,12 +3303,18 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
         hipLaunchKernelGGL(rt::k_sweep_link, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, (const int32_t *)t->sw_src.p,
                            (const double *)t->sw_psi_out.p, t->sw_psi_in.p, 2 * n, G, n);
     }
-    RT_HIP(hipEventRecord(t->ev[7], s));
-    RT_HIP(wait_stream(s));
-    RT_HIP(hipGetLastError());
-    if (ms) { float f = 0; RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[7])); *ms = f; }
+    if (async_sweep) {
+        RT_HIP(hipGetLastError());
+        if (ms) *ms = 0.0;
+        t->in_flight = true;  // (every accessor waits; a consumer with its own stream orders against rt_mesh_get_stream / rt_wait)
+    } else {
+        RT_HIP(hipEventRecord(t->ev[7], s));
+        RT_HIP(wait_stream(s));
+        RT_HIP(hipGetLastError());
+        if (ms) { float f = 0; RT_HIP(hipEventElapsedTime(&f, t->ev[0], t->ev[7])); *ms = f; }
+        t->in_flight = false;  // (the sweep waited for the stream)
+    }
     t->sw_done = true;
-    t->in_flight = false;  // (the sweep waited for the stream)
     t->sw_last_input = staged ? 2 : 1; t->sw_last_gp = a.use_lds ? gp : 0; t->sw_last_passes = passes;
     return RT_SUCCESS;
 }
@@ -3344,7 +3354,7 @@ int32_t rt_sweep_fetch(rt_tracks *t, double *phi, double *psi_out, double *psi_n
 int32_t rt_sweep_info(rt_tracks *t, void **ptrs_dev, int32_t *info) {
     if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
     if (!t->sw_done) { set_error("rt_sweep has not run"); return RT_ERR_NOT_SEGMENTIZED; }
-    if (int rc = finish_call(t)) return rc;
+    // (no wait here: addresses and counts only — under "async" the caller orders its reads against the mesh's stream or rt_wait)
     if (ptrs_dev) { ptrs_dev[0] = t->sw_phi.p; ptrs_dev[1] = t->sw_psi_out.p; ptrs_dev[2] = t->sw_psi_in.p; }
     if (info) { info[0] = t->sw_last_input; info[1] = t->sw_last_gp; info[2] = t->sw_last_passes; info[3] = t->sw_groups; }
     return RT_SUCCESS;

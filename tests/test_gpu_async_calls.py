@@ -78,3 +78,29 @@ def test_async_call_then_sweep_over_the_staged_rows(rt):
     for r in out[1:]:
         assert np.array_equal(r["psi_out"], out[0]["psi_out"])
         assert np.allclose(r["phi"], out[0]["phi"], rtol=1e-13, atol=0)
+
+
+def test_async_sweeps_back_to_back(rt):
+    """Under "async" rt_sweep queues its kernels and returns; consecutive sweeps iterate on the device; fetching waits."""
+    model = rt.GmshDiscreteModel(rt.data_path("pincell.msh"))
+    B = rt.BoundaryConditions
+    tg = rt.TrackGenerator(model, 32, 5e-3, bcs=B(top=rt.Reflective, bottom=rt.Reflective, left=rt.Periodic, right=rt.Periodic))
+    rt.trace(tg)
+    aq = tg.azimuthal_quadrature
+    G, nc = 5, tg.mesh.num_cells
+    sig = np.linspace(0.2, 1.6, nc * G).reshape(nc, G)
+    src = np.linspace(0.0, 1.0, nc * G).reshape(nc, G)
+    psi = np.ones((2, tg.n_total_tracks, G))
+    out = []
+    for a in (0, 1):
+        dm, dt = _handles(rt, tg, split=0, compact=0, **{"async": a})
+        dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        dt.sweep_set_links(tg)
+        dt.sweep(G, sig, src, None, psi, fetch=False)
+        for _ in range(4):
+            dt.sweep(G, fetch=False)      # four more iterations over the boundary fluxes, queued back to back when async
+        out.append(dt.sweep(G))           # (fetching waits)
+        dt.close(); dm.close()
+    assert np.array_equal(out[0]["psi_out"], out[1]["psi_out"]) and np.array_equal(out[0]["psi_next"], out[1]["psi_next"])
+    scale = float(np.abs(out[0]["phi"]).max())
+    assert float(np.abs(out[0]["phi"] - out[1]["phi"]).max()) <= 1e-12 * scale
