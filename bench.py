@@ -621,7 +621,9 @@ def _main(real_stdout):
             per_kernel.append({"kernel": names[key], "ms_avg": ms, "bytes_per_segment": bps,
                                "achieved_GBs": bps * local_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                                "traffic": traffic.get(names[key]) if wkey == "c3" and world == 1 else None})
-        dom_k = max(per_kernel, key=lambda k: k["ms_avg"])
+        # (the scan moves no per-segment bytes: it is reported, never the roofline's kernel — on a GPU shared by two rehearsal
+        #  ranks its events can span the other rank's kernels)
+        dom_k = max((k for k in per_kernel if k["bytes_per_segment"] > 0), key=lambda k: k["ms_avg"])
         achieved = dom_k["achieved_GBs"]
         step_GBs = STEP_BYTES_PER_SEGMENT * global_segments / (ms_per_step * 1e-3) / 1e9
         tr_all = [k["traffic"] for k in per_kernel]

@@ -34,4 +34,4 @@ def test_bench_two_ranks_rehearsal():
     assert abs(pr["segments"][0] - pr["segments"][1]) < 0.02 * 114447177  # Σℓ-balanced uid ranges: segments ∝ ℓ
     assert "allreduce_ms_exposed" in d and "ms" in d["allgather"], d.get("allgather")
     assert d["allgather"]["bytes_received_per_rank"] == 44.0 * pr["segments"][1]  # rank 0 receives rank 1's shard
-    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "rehearsal" in d
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "rehearsal" in d, (d.get("kernel_ms"), d["roofline"], d.get("per_rank"), r.stderr[-1500:])
