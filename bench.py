@@ -332,6 +332,9 @@ def _main(real_stdout):
                     help="N > 1: also time the sharded transport sweep (rt_sweep per rank + point-to-point exchange of the fluxes that leave a "
                          "shard); off by default: its RCCL exchange has only run over gloo and a one-rank group so far, and the headline line "
                          "must not depend on it")
+    ap.add_argument("--extras-timeout", type=int, default=300,
+                    help="N > 1: seconds after which rank 0 prints the headline line without the extras (all-gather-v, same problem on one "
+                         "GPU) if they have not returned, and every rank leaves; 0: wait for ever")
     ap.add_argument("--force-dist", action="store_true", help="development: run the multi-GPU code path with a one-rank RCCL group")
     args = ap.parse_args()
 
@@ -491,6 +494,44 @@ def _main(real_stdout):
     t_max = float(t_max.item())
     global_segments = float(tot[0].item())
     failed_tracks = int(tot[1].item())
+
+    # ---- N > 1: nothing after the timed region may cost the run its line.  The extras below use collectives that have never run
+    #      between several GPUs here (point-to-point all-gather-v); should one of them not return, rank 0 prints the headline
+    #      line without them after `--extras-timeout` seconds and every rank leaves.
+    import threading
+    line_lock = threading.Lock()
+    line_printed = [False]
+    watchdog = None
+    if world > 1 and args.extras_timeout > 0:
+        def _give_up():
+            with line_lock:
+                if line_printed[0]:
+                    return
+                line_printed[0] = True
+                if rank == 0:
+                    ms_step = t_max / args.steps * 1e3
+                    per_k = {key: kern[key] / args.steps for key in ("march", "compact")}
+                    dom = max(per_k, key=per_k.get)
+                    ach = BYTES_PER_SEGMENT[dom] * local_total / (per_k[dom] * 1e-3) / 1e9 if per_k[dom] > 0 else 0.0
+                    fb = {"metric": "segments/sec (whole node)", "value": global_segments * args.steps / t_max, "unit": "segments/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                          "data": "synthetic (deterministic tracks from trace! on the mesh; no RNG)",
+                          "config": {"workload": "%s; FIXED global problem split over %d GPUs (strong scaling)" % (wl["name"], world),
+                                     "tracks_global": int(tg.n_total_tracks), "segments_global": int(global_segments),
+                                     "failed_tracks": failed_tracks},
+                          "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_segment": BYTES_PER_SEGMENT[dom],
+                                       "segments_per_launch": int(local_total), "kernel_ms_avg": per_k[dom]},
+                          "kernel_ms": {k: v / args.steps for k, v in kern.items()}, "per_rank": per_rank,
+                          "allreduce_ms_exposed": allreduce_exposed_ms,
+                          "extras": "not reported: an extra after the timed region did not return within %d s" % args.extras_timeout}
+                    real_stdout.write(json.dumps(fb, ensure_ascii=False) + "\n")
+                    real_stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.extras_timeout, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     # ---- N > 1: reassemble the global segment list on every rank (RCCL all-gather-v), always reported
     allgather = None
@@ -702,8 +743,13 @@ def _main(real_stdout):
             out["stream_ordered_calls"] = stream_ordered_calls(rt, tg, aq, dmesh, dt, args.steps, local_total)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tg)
-        real_stdout.write(json.dumps(out, ensure_ascii=False) + "\n")
-        real_stdout.flush()
+        with line_lock:
+            if not line_printed[0]:
+                line_printed[0] = True
+                real_stdout.write(json.dumps(out, ensure_ascii=False) + "\n")
+                real_stdout.flush()
+    if watchdog is not None:
+        watchdog.cancel()
     if dist_on:
         dmesh.set_enqueue_hook(None)
         dist.destroy_process_group()

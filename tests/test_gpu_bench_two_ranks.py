@@ -35,3 +35,24 @@ def test_bench_two_ranks_rehearsal():
     assert "allreduce_ms_exposed" in d and "ms" in d["allgather"], d.get("allgather")
     assert d["allgather"]["bytes_received_per_rank"] == 44.0 * pr["segments"][1]  # rank 0 receives rank 1's shard
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "rehearsal" in d, (d.get("kernel_ms"), d["roofline"], d.get("per_rank"), r.stderr[-1500:])
+
+
+def test_bench_two_ranks_extras_watchdog():
+    """An extra after the timed region that does not return in time must not cost the run its line: with a 1-s limit the gloo
+    all-gather of the 5-GB global list is still running when rank 0 prints the headline line without the extras and every rank
+    leaves with exit code 0."""
+    env = dict(os.environ)
+    env["RT_BENCH_REHEARSAL"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--extras-timeout", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["config"]["segments_global"] == 114447177 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert "extras" in d and "allgather" not in d
