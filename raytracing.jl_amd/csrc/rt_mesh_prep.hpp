@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <exception>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -150,17 +151,25 @@ inline void parallel_cells(int32_t n_cells, F f) {
     if (nt == 1) { f(0, n_cells); return; }
     std::vector<std::thread> th;
     th.reserve(nt);
+    // what a worker (or the caller's own share) throws — bad_alloc from its scratch vectors — is carried to the caller's
+    // thread and rethrown after every thread has been joined: the C ABI's guards turn it into rt_last_error
+    std::vector<std::exception_ptr> err(nt);
     int32_t done = 0;
     try {
         for (unsigned t = 0; t + 1 < nt; ++t) {
             const int32_t c0 = (int32_t)((int64_t)n_cells * t / nt), c1 = (int32_t)((int64_t)n_cells * (t + 1) / nt);
-            th.emplace_back([=, &f]() { f(c0, c1); });
+            std::exception_ptr *slot = &err[t];
+            th.emplace_back([=, &f]() {
+                try { f(c0, c1); } catch (...) { *slot = std::current_exception(); }
+            });
             done = c1;
         }
     } catch (...) {  // no thread to be had: the caller's thread does the rest
     }
-    f(done, n_cells);
+    try { f(done, n_cells); } catch (...) { err[nt - 1] = std::current_exception(); }
     for (auto &t : th) t.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
 }
 
 // A convex polygon of a few vertices (a triangle clipped by at most three half-planes), without heap traffic: the

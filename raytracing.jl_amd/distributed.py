@@ -311,6 +311,10 @@ class ShardedSweep:
         import torch
         import torch.distributed as dist
 
+        # rt_sweep wrote phi / psi_out / psi_in on the MESH's stream (and, under the option "async", has only queued its
+        # kernels): wait for it before torch's stream reads or writes these buffers
+        if self.dt is not None:
+            self.dt.wait()
         phi, psi_out, psi_in = self._views(G)
         if self._idx is None or self._idx[0] != psi_out.device:
             dev = psi_out.device
@@ -331,6 +335,9 @@ class ShardedSweep:
             psi_in[idx] = bufs[p]
         if self.world > 1:
             dist.all_reduce(phi, op=dist.ReduceOp.SUM, group=self.group)
+        # ... and the next rt_sweep (mesh stream) must see the scattered fluxes: torch's stream is drained here
+        if psi_in.is_cuda:
+            torch.cuda.current_stream(psi_in.device).synchronize()
         return phi, psi_out, psi_in
 
     def sweep(self, G, sigma_t=None, source=None, track_weight=None, psi_in=None, input="auto"):

@@ -1,8 +1,12 @@
 """Full-size and sharded runs of the HIP segmentize! path — GPU only.
 
 At BASELINE.json's largest configuration (config 5: BWR-like mesh, nφ=128, δ=5e-4, ≈1.04 M tracks,
-≈1.1·10⁸ segments) the oracle would need minutes, so the results are checked through properties
-that do not depend on size, evaluated on the device:
+≈1.1·10⁸ segments) the results are checked twice.  Record for record against the oracle on a sample of uids
+(``test_bwr_config5_records_equal_the_oracle_on_a_uid_sample``: tracks are independent, ``src/trackgenerator.jl:362-364``, so
+the oracle's march of every 16th track is an exact comparison for those tracks of the FULL GPU run — the regime with 16 k
+march waves, eight rounds deep, and the compaction in output order; ``RT_C5_STRIDE=1`` compares all 114 M records where the
+host has the cores and ≈12 GB of memory for it).  And, for all tracks, through properties that do not depend on size,
+evaluated on the device:
 
 * the reference's own invariants (``test/runtests.jl:30-43``): first segment starts at the track's
   ``p``, Σℓ of a track's segments ≈ the track's ℓ (this is also the reference's run-time check,
@@ -87,16 +91,71 @@ def test_sharded_march_equals_unsharded(rt, traced, oracle_run, world):
     assert np.allclose(cat["volumes"].cpu().numpy(), ref["volumes"], rtol=1e-10, atol=0)
 
 
+_C5 = {}
+
+
+def _config5(rt):
+    """BASELINE configs[4], traced once per session."""
+    if "tg" not in _C5:
+        model = rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
+        tg = rt.TrackGenerator(model, 128, 5e-4)
+        rt.trace(tg)
+        assert tg.n_total_tracks == 1_043_212  # SURVEY §8a
+        _C5["tg"] = tg
+    return _C5["tg"]
+
+
+def test_bwr_config5_records_equal_the_oracle_on_a_uid_sample(rt, orc):
+    """The FULL config-5 march on one GPU (16 k march waves, many rounds, compaction in output order), compared record for
+    record — offsets, status, element ids and the five coordinate arrays, bit for bit — with the oracle's march
+    (oracle/rt_oracle.c, following src/track.jl:106-178) of every 16th uid: ≈65 k tracks, ≈7 M segments."""
+    import os
+
+    import torch
+
+    from raytracing_jl_amd import _capi
+
+    tg = _config5(rt)
+    aq = tg.azimuthal_quadrature
+    stride = int(os.environ.get("RT_C5_STRIDE", "16"))
+    sel = np.arange(0, tg.n_total_tracks, stride)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px[sel], tg.py[sel], tg.phi[sel], tg.A[sel], tg.B[sel], tg.C[sel], tg.ell[sel],
+                        cos_phi=tg.cos_phi[sel], sin_phi=tg.sin_phi[sel], tiny_step=tg.tiny_step, n_threads=0)
+    dmesh = _capi.DeviceMesh(tg.mesh, 0)
+    dt = _capi.DeviceTracks(dmesh, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+    assert total > 1.0e8
+    st = dt.stats()
+    v = _device_views(dt)
+    dev = v["ell"].device
+    off = v["offsets"]
+    tsel = torch.as_tensor(sel, device=dev)
+    cnt = (off[1:] - off[:-1])[tsel]
+    assert np.array_equal(cnt.cpu().numpy(), np.diff(ref["offsets"])), "segment counts of the sampled uids"
+    assert np.array_equal(v["status"][tsel].cpu().numpy(), ref["status"]), "per-track status of the sampled uids"
+    # positions of the sampled tracks' records inside the full CSR arrays
+    starts = off[:-1][tsel]
+    ref_off = torch.as_tensor(ref["offsets"][:-1], device=dev)
+    idx = torch.repeat_interleave(starts - ref_off, cnt) + torch.arange(int(cnt.sum().item()), device=dev)
+    assert idx.numel() == len(ref["element"])
+    assert np.array_equal(v["element"][idx].cpu().numpy(), ref["element"]), "element ids"
+    for name in ("px", "py", "qx", "qy", "ell"):
+        got = v[name][idx].cpu().numpy()
+        assert np.array_equal(got.view(np.int64), ref[name].view(np.int64)), name  # bit for bit
+    print(f"config 5: {total} segments on the GPU ({st['cheap_records']} by cheap steps); {len(sel)} sampled tracks "
+          f"(every {stride}th uid), {idx.numel()} records equal the oracle's bit for bit")
+    dt.close()
+    torch.cuda.empty_cache()
+
+
 def test_bwr_config5_full_size_properties(rt):
     """BASELINE config 5 on one GPU (the 8-GPU run marches 1/8 of it per rank)."""
     import torch
 
     from raytracing_jl_amd import _capi
 
-    model = rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
-    tg = rt.TrackGenerator(model, 128, 5e-4)
-    rt.trace(tg)
-    assert tg.n_total_tracks == 1_043_212  # SURVEY §8a
+    tg = _config5(rt)
     aq = tg.azimuthal_quadrature
     dmesh = _capi.DeviceMesh(tg.mesh, 0)
     dt = _capi.DeviceTracks(dmesh, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell,
