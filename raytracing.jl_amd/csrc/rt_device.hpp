@@ -570,6 +570,7 @@ struct Walk {
     double ax, ay, bx, by;  // endpoints of T's exit edge, in T's edge orientation
     double cx, cy;          // T's vertex opposite the exit edge
     double dT;              // det of T's barycentric system in T's node order (exact reference ops)
+    int32_t last;           // 3·T + exit edge (T's own edge numbering) of the last emitted segment: its staging code (k_march<TOPO>)
 };
 
 // State for the next walk step after a segment was emitted by the generic step in `cell` with
@@ -588,6 +589,7 @@ RT_HD __forceinline__ void walk_enter(const DMesh &m, const Tri &t, Walk &w, int
     w.cy = ko == 0 ? y3 : (ko == 1 ? y1 : y2);
     const int32_t a = ko == 0 ? t.adj[0] : (ko == 1 ? t.adj[1] : t.adj[2]);
     w.pred = a != -2 ? a : m.adjr[3 * cell + ko];
+    w.last = 3 * cell + ko;
 }
 
 enum WalkResult { kWalkGeneric = 0, kWalkSkip = 1, kWalkEmit = 2 };
@@ -727,6 +729,12 @@ RT_HD __forceinline__ int walk_step(const DMesh &m, Walk &w, const NextRec &nr, 
     // --- advance the state to T' (only when emitting)
     if (res == kWalkEmit) {
         asm volatile("" ::: "memory");  // keep this a branch: as selects the update is twice the instructions
+        {   // the exit edge in T''s own numbering: the record is (T', entry edge e), rotated edge 1 / 2 = edge e + 1 / e + 2
+            const int32_t e = (w.pred >= 0 ? w.pred : 0) - 3 * Tn;
+            int32_t ko = e + (exit1 ? 1 : 2);
+            ko = ko >= 3 ? ko - 3 : ko;
+            w.last = 3 * Tn + ko;
+        }
         w.T = Tn;
         w.dT = dTn;
         w.ax = exit1 ? x1 : x2; w.ay = exit1 ? y1 : y2;

@@ -57,6 +57,17 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;  // elements
+    // owns its allocation: a handle's buffers are released when the handle is deleted, whether or not free_tracks /
+    // free_mesh list them (a forgotten member leaked 1 GB per C5 handle in round 3)
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
@@ -111,6 +122,14 @@ struct DStage {
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
     int32_t static0;        // 1: chunk w is reserved as the first chunk of march wave w (whole-track march; cursor starts at n_waves)
+    // k_march<TOPO> stages ONE word per record in `element`: 3·cell + exit edge + 1 (the record is a function of the track's
+    // line, that edge and the previous record: k_materialise computes it), or -(index + 1) of an entry of the side list below
+    // for a record that keeps its own end points (the generic step's: every track's first one, refusals).  Entries
+    // [0, side_static) are reserved — entry `march slot` for the track's first record —, the rest is handed out from
+    // cursor[2]; cursor[3] flags an overflow (the host grows the list and re-runs, as for the pool).
+    RT_G double *s_px, *s_py, *s_qx, *s_qy;
+    RT_G int32_t *s_el;     // cell + 1
+    int32_t side_cap, side_static;
 #ifdef RT_TIMING
     unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
 #endif
@@ -131,6 +150,8 @@ constexpr int kCtlWords = 64;
 constexpr int kCtlRefusal = 32;   // 32..40: cheap-step refusals by certificate term (order of topo_certified)
 constexpr int kCtlRestarts = 41;  // tracks marched again with exact steps after cheap steps (their fused volumes were counted twice)
 constexpr int kCtlNearRtol = 42;  // tracks whose Σℓ check (src/track.jl:171) sits within summation-order noise of its threshold
+constexpr int kCtlFinishTicket = 43;  // k_finish: its "last block" ticket
+constexpr int kCtlDeferred = 27;      // k_finish: tracks whose exact Σℓ it could not form (their records lie beyond the arrays' capacity)
 // generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
 // C3 — a lane that escalates waits for the rest of its wave — 8..32 equal)
 constexpr int kCreepLocal = 16;
@@ -163,9 +184,9 @@ struct DSplit {
 // left-to-right sum; Julia's `sum` reassociates (pairwise blocks, @simd lanes), so its Σℓ can differ by a few ulp·n.  A
 // track whose |ℓ − Σℓ| lies within 64·ulp·n·max(ℓ, Σℓ) of the threshold rtol·max(ℓ, Σℓ) could get the other status there:
 // such tracks are counted (rt_last_stats) so that a caller knows when this cannot be pinned.
-__device__ __forceinline__ bool sum_check_is_marginal(double ell, double sum, double rtol, int n) {
+__device__ __forceinline__ bool sum_check_is_marginal(double ell, double sum, double rtol, int n, double band = 64.0) {
     const double big = fabs(ell) > fabs(sum) ? fabs(ell) : fabs(sum);
-    return fabs(fabs(ell - sum) - rtol * big) <= 64.0 * 1.1102230246251565e-16 * (double)(n > 1 ? n : 1) * big;
+    return fabs(fabs(ell - sum) - rtol * big) <= band * 1.1102230246251565e-16 * (double)(n > 1 ? n : 1) * big;
 }
 
 template <bool WIDEK>
@@ -458,7 +479,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     const RT_K DSplit *spk = (const RT_K DSplit *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, sp));
     (void)sp; (void)fst;
     static_assert(!TOPO || (MODE == kStage && !SPLIT && !LDSREC), "cheap steps: staged whole tracks only");
-    constexpr bool FUSE = WAVES > 1;
+    // TOPO: the march only DECIDES (codes); exit points, lengths, Σℓ and fill_volumes are k_materialise's — no LDS copy of `volumes` here
+    constexpr bool FUSE = WAVES > 1 && !TOPO;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
     const int lane = threadIdx.x & 63;
@@ -566,14 +588,14 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     int32_t last_word = 0;  // staging word of the lane's last record
     // (the cheap loop stores without a branch: should the pool run out before a lane's first chunk — the attempt is void
     //  then and the host re-runs it — its row pointers must still be addresses inside the pool)
-    if (TOPO) { row_qx = stg.qx + lane; row_qy = stg.qy + lane; row_el = stg.element + lane; }
+    if (TOPO) row_el = stg.element + lane;
     const RT_G TopoRec *trec_v = m.trec;
     const RT_G EdgeABC *etab_v = m.etab;
     if (TOPO) asm volatile("" : "+v"(trec_v), "+v"(etab_v));
     // The track's first record may have been made by k_first (whole tracks, staged, reserved first chunks): the march then
     // starts behind it — iteration count, exit point, Σℓ, walk state and the staging row pointers as its own first
     // iteration would have left them.  The state is read through the argument segment (nothing of it lives across the loop).
-    if (MODE == kStage && !SPLIT) {
+    if (MODE == kStage && !SPLIT && !TOPO) {
         const RT_K DFirst *fk = (const RT_K DFirst *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, fst));
         const RT_G int32_t *f_it = fk->it;
         if (f_it != nullptr) {
@@ -654,45 +676,23 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             // ---- cheap steps: a wave-uniform inner loop that runs while some lane is in cheap mode and no lane is due
             //      for an exact step (lanes whose track has ended, or that wait with an uncertified last step, idle here)
             {
-                // Software pipeline, one record deep: iteration n decides record n (A) and does the arithmetic of record
-                // n - 1 (B).  Its loads — the next record and record n's exit edge — are issued before B's stores and
-                // waited for at the end of the iteration, behind B's ≈150 instructions: gfx950 retires loads and stores
-                // through one in-order counter, so a load issued after a store would wait for that store's
-                // acknowledgement as well (that, not the arithmetic, was half of an iteration's time).
+                // The decision-only march: an iteration decides record n — which cell the reference emits next, left through
+                // which edge (topo_geo / topo_certified / topo_commit: two FMAs and a dozen compares on the 32-B record) — and
+                // stages its code, 3·cell + exit edge; exit point, length, Σℓ and fill_volumes are functions of (track line,
+                // edge, previous record) and are evaluated by k_materialise, in parallel over all records, not on this chain.
+                // The loads of record n + 1 are issued as soon as record n's exit edge is known and waited for at the end of
+                // the iteration; the one 4-B store follows them (gfx950 retires loads and stores through one in-order counter:
+                // a load issued behind a store waits for that store's acknowledgement as well) and is unconditional — behind a
+                // store inside a branch the compiler waits for everything: a lane that decided nothing stores its last word
+                // again (same address, same bits).
                 const RT_G TopoRec *R = trec_v + (ts.pred >= 0 ? ts.pred : 0);
                 uint64_t c_hdr = R->hdr;
                 double c_x2 = R->x2, c_y2 = R->y2;
                 uint32_t c_c01 = R->c01, c_c23 = R->c23;
-                bool pend = false;              // a decided record waits for its arithmetic
-                double pe_A = 0.0, pe_B = 0.0, pe_C = 0.0;  // its exit edge's general form
-                int32_t p_cell = 0;
-                // record i - 1: exit point, length, staging, fill_volumes, Σℓ.  Executed by every lane, without a branch
-                // around the stores (the compiler counts outstanding memory operations per path: behind a conditional
-                // store it waits for everything): a lane without a pending record stores its last record again.
-                auto arithmetic = [&]() {
-                    double qx, qy;
-                    edge_exit_point(tA, tB, tC, pe_A, pe_B, pe_C, qx, qy);  // the walk step's exit point, src/intersection.jl:127-138
-                    const double ell = norm2(lqx - qx, lqy - qy);            // Segment ctor, src/segment.jl:31-33
-                    const int rw = (i - 1) & (kChunkRows - 1);
-                    if (__builtin_expect(pend && rw == 0, 0)) {
-                        my_chunk = alloc_chunk((i - 1) >> kChunkLog2);
-                        if (my_chunk >= 0) {
-                            const int64_t o0 = stage_slot(my_chunk, 0, lane);
-                            const RT_K DStage *sk = march_stage_args();
-                            row_qx = sk->qx + o0; row_qy = sk->qy + o0; row_el = sk->element + o0;
-                        }
-                    }
-                    lqx = pend ? qx : lqx; lqy = pend ? qy : lqy;
-                    last_word = pend ? p_cell + 1 : last_word;
-                    row_qx[rw * 16] = lqx; row_qy[rw * 16] = lqy; row_el[rw * 16] = last_word;
-                    if (FUSE) atomicAdd(&hist[p_cell], pend ? w * ell : 0.0);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
-                    sum_ell += pend ? ell : 0.0;
-                };
                 for (;;) {
                     const bool cheap = (fl & kFlCheap) != 0;
                     if (!__ballot(cheap)) break;
                     if (__ballot((fl & (kFlCheap | kFlWait)) == 0)) break;
-                    // (A) record n: where the line leaves the cell; its loads
                     const TopoGeo g = topo_geo(ts, c_hdr, c_x2, c_y2, tA, tB, tC);
                     const int32_t np = topo_next(g);
 #ifdef RT_STATS_DISTINCT
@@ -720,19 +720,14 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     const uint64_t n_hdr = Rn->hdr;
                     const double n_x2 = Rn->x2, n_y2 = Rn->y2;
                     const uint32_t n_c01 = Rn->c01, n_c23 = Rn->c23;
-                    const RT_G EdgeABC *E = etab_v + g.code;
-                    const double eA = E->A, eB = E->B, eC = E->C;
-                    asm volatile("" ::: "memory");  // the loads above stay above the stores below
-                    // (B) record n - 1
-                    arithmetic();
-                    // (A) the certificates of record n
+                    asm volatile("" ::: "memory");  // the loads above stay above the store below
                     int32_t kub;
                     const bool ok = topo_certified(tt, ts, g, c_hdr, c_c01, c_c23, kk, kub);
                     const bool over = it + kub > cap;  // (`it` is an upper bound of the reference's iterations after cheap steps)
                     ++n_cheap_it;
                     n_cheap_ref += __ballot(cheap && !ok) != 0 ? 1 : 0;
-                    pend = cheap && ok && !over;
-                    if (pend) {
+                    const bool commit = cheap && ok && !over;
+                    if (commit) {
                         ++i;
                         it += kub;
                         const int r = topo_commit(tt, ts, g);
@@ -752,10 +747,17 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                             if (mb && lane == first) atomicAdd(ctl + kCtlRefusal + b, (unsigned long long)__popcll(mb));
                         }
                     }
+                    // stage record i - 1 (every lane in here has one: cheap steps follow an exact step's record)
+                    const int rw = (i - 1) & (kChunkRows - 1);
+                    if (__builtin_expect(commit && rw == 0, 0)) {
+                        my_chunk = alloc_chunk((i - 1) >> kChunkLog2);
+                        // (pool exhausted: the attempt is void and the host re-runs it; the row pointer stays inside the pool)
+                        if (my_chunk >= 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane);
+                    }
+                    last_word = commit ? g.code + 1 : last_word;
+                    row_el[rw * 16] = last_word;
                     c_hdr = n_hdr; c_x2 = n_x2; c_y2 = n_y2; c_c01 = n_c01; c_c23 = n_c23;
-                    pe_A = eA; pe_B = eB; pe_C = eC; p_cell = g.cell;
                 }
-                if (pend) arithmetic();
             }
             // A wave whose lanes are refused in more than one iteration out of eight (a mesh with many records that carry the
             // walk step's certificates but not the cheap step's: every refusal is an exact pass the other lanes wait for)
@@ -774,8 +776,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             if (__builtin_expect((fl & kFlRestart) || ((fl & kFlUsed) && it >= cap), 0)) {
                 // the bound reached the iteration cap: this track is marched again from its start with exact steps only
                 asm volatile("" ::: "memory");
-                // its cheap records have already been added to the fused volumes: the host recomputes them from the records
-                atomicAdd(march_ctl() + kCtlRestarts, 1ull);
+                atomicAdd(march_ctl() + kCtlRestarts, 1ull);  // (statistic; the rows are simply staged again from row 0)
                 tt.on = false; fl = 0; n_generic = 0;
                 i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
                 xpx = t.px[u] + sx; xpy = t.py[u] + sy;
@@ -788,6 +789,10 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             fl &= ~kFlMat;
             const int32_t cell = (int32_t)((uint32_t)ts.last / 3u);
             walk_enter(m, load_tri(load_geo(m.geo), cell), wk, cell, ts.last - 3 * cell);
+            {   // the exit point of the lane's last (cheap) record, as k_materialise evaluates it: the reference re-seeds from it (:165)
+                const RT_G EdgeABC *e = m.etab + ts.last;
+                edge_exit_point(tA, tB, tC, e->A, e->B, e->C, lqx, lqy);
+            }
             xpx = lqx + sx; xpy = lqy + sy;
             prev_element = cell;
         }
@@ -927,7 +932,36 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         } else if (MODE == kStage) {
             const int r = i & (kChunkRows - 1);
             if (__builtin_expect(r == 0, 0)) my_chunk = alloc_chunk(i >> kChunkLog2);
-            if (my_chunk >= 0) {
+            if (TOPO) {
+                // One word per record (see DStage): an exact walk step's record is, like a cheap step's, a function of the track
+                // line, its exit edge and the previous record — its code; the generic step's record (every track's first one,
+                // refusals) keeps its own end points in the side list.
+                if (my_chunk >= 0) {
+                    if (r == 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane);
+                    int32_t word = wk.last + 1;
+                    if (__builtin_expect(res != kWalkEmit, 0)) {
+                        const RT_K DStage *sk = march_stage_args();
+                        int32_t idx = (int32_t)slot;  // a track's first record: its reserved entry (2,039 waves take their first
+                                                      // step at the same moment: no atomic there)
+                        if (i != 0) {
+                            const unsigned long long mm = __ballot(1);
+                            const int L = __ffsll((long long)mm) - 1;
+                            int32_t b0 = 0;
+                            if (lane == L) b0 = atomicAdd((int32_t *)&sk->cursor[2], (int32_t)__popcll(mm));
+                            idx = __shfl(b0, L) + (int32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                        }
+                        if (idx < sk->side_cap) {
+                            sk->s_px[idx] = px; sk->s_py[idx] = py; sk->s_qx[idx] = qx; sk->s_qy[idx] = qy;
+                            sk->s_el[idx] = element + 1;
+                        } else {
+                            sk->cursor[3] = 1;  // side list exhausted: the host grows it and re-runs
+                        }
+                        word = -(idx + 1);
+                    }
+                    row_el[r * 16] = word;
+                    last_word = word;
+                }
+            } else if (my_chunk >= 0) {
                 if (r == 0) {  // per-lane addresses of the chunk's row 0, kept in VGPRs (the staging pointers are
                                // SGPR tuples that do not survive the generic branch unspilled)
                     const int64_t o0 = stage_slot(my_chunk, 0, lane);
@@ -941,7 +975,6 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 const bool derived = res == kWalkEmit && !from_seed;
                 row_qx[r * 16] = qx; row_qy[r * 16] = qy;
                 row_el[r * 16] = derived ? element + 1 : -(element + 1);
-                if (TOPO) last_word = derived ? element + 1 : -(element + 1);
                 if (__builtin_expect(!derived, 0)) {
                     const int64_t o = stage_slot(my_chunk, r, lane);
                     const RT_K DStage *sk = march_stage_args();
@@ -1019,9 +1052,11 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         spk->p_flags[pi] = (matched ? 1 : 0) | (st << 8) | (tgt_k << 16);
         spk->p_sum[pi] = sum_ell;
     } else if (MODE != kFill) {
-        // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol)
-        if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
-        if (sum_check_is_marginal(t.ell[u], sum_ell, prm.rtol, i)) atomicAdd(march_ctl() + kCtlNearRtol, 1ull);
+        // :171 isapprox(track.ℓ, sum(ℓ.(segments)); rtol) — TOPO: Σℓ is k_materialise's, and so is this check
+        if (!TOPO) {
+            if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
+            if (sum_check_is_marginal(t.ell[u], sum_ell, prm.rtol, i)) atomicAdd(march_ctl() + kCtlNearRtol, 1ull);
+        }
         counts[u] = i;
         status[u] = st;
         {
@@ -1301,6 +1336,325 @@ __global__ __launch_bounds__(256) void k_compact4(DTracks t, const int32_t *__re
     }
 }
 
+
+// ---- codes -> records (the parallel half of the two-phase march) -----------------------------------------------------
+// k_march<..., TOPO> decides; this kernel computes.  Per record the march left one word (DStage): 3·cell + exit edge + 1, or
+// -(index + 1) of a side-list entry that holds the end points of a record of the generic step.  From the words, with
+// k_compact3's data movement (a unit = 16 consecutive tracks of a march wave, handled by four waves: wave k takes the 32-row
+// chunks k, k + 4, ...; transposing LDS tiles; every track's 32 rows stored as one run per array; loads before stores):
+//   q = intersection(track.ABC, general_form of the exit edge)   src/intersection.jl:127-138 (edge_exit_point: walk_step's
+//       expression; `etab` holds the host's general forms, evaluated with the reference's operations — bit-identical),
+//   p = the previous record's q (bit-identical to the reference's own intersection with the shared edge: negating an edge's
+//       general form negates numerator and denominator alike), or the side list's p,
+//   ℓ = ‖p − q‖                                                  Segment ctor, src/segment.jl:31-33,
+//   fill_volumes: volumes[cell] += δs[azim]·ℓ                    src/trackgenerator.jl:376-386 — ds_add_f64 into an LDS-private
+//       copy per workgroup (persistent workgroups), left as the workgroup's share in `slabs`; k_finish adds the shares in
+//       workgroup order (deterministic) and applies ./= n_azim_2,
+//   Σℓ per track and isapprox(track.ℓ, Σℓ; rtol)                 src/track.jl:171-175.  The partial sums of a track's chunks are
+//       added in the order its waves finish, so the check is decided by MARGIN (any summation order is within n·2⁻⁵³·Σ of the
+//       left-to-right sum the reference's check and the oracle use); a track inside 96 such bands of the threshold is listed
+//       and k_finish sums its ℓ again left to right.
+// The gathers of the exit edges run in the LOAD mapping (the 16 lanes of a row are neighbouring tracks, which mostly cross the
+// same edge: they share cache lines; in the store mapping every lane would fetch a line of its own).
+// RECORDS: write the 44-B records.  ROWS: leave (ℓ, cell) of every staged row, slot-indexed like the rows, for rt_sweep.
+struct DMat {
+    const RT_G EdgeABC *etab;
+    const RT_G int32_t *corder;   // large batches: march waves in the order of their output addresses (as k_compact3)
+    int64_t n_units;              // 4 per march wave
+    double rtol;
+    int32_t n_cells;
+    int32_t tally;                // 1: Σℓ + status + fill_volumes (the call's first pass over the codes); 0: records / rows only
+    int32_t force_exact;          // tests: every track takes k_finish's left-to-right sum
+    int32_t marg_cap;
+    RT_G double *slabs;           // [gridDim][n_cells]
+    RT_G int32_t *marg;           // [0] count, [1 ...] march slots of the tracks k_finish has to sum exactly
+    RT_G double *ell_rows;        // ROWS
+    RT_G int32_t *cell_rows;
+    unsigned long long *ctl;      // the call's control block ([0] failed tracks, [1] first failing uid + 1)
+};
+
+template <bool RECORDS, bool ROWS>
+__global__ __launch_bounds__(256) void k_materialise(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
+                                                     const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
+    static_assert(kChunkRows == 32, "k_materialise moves 32-row chunks");
+    __shared__ double tiles_x[4][16 * kC3Pitch];  // per wave: q of the chunk's rows (slot 0: the row before), transposed from the
+    __shared__ double tiles_y[4][16 * kC3Pitch];  // load mapping to the store mapping; the x tile then carries the cells
+    __shared__ double s_sum[16];                  // Σℓ of the unit's tracks
+    extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
+    double *hist = reinterpret_cast<double *>(mat_smem);  // [n_cells] when a.tally
+    if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
+    const int kw = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr+4, ...
+    const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub+2, ...
+    typedef __attribute__((address_space(3))) volatile double lds_f64;
+    typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
+    lds_f64 *tx = (lds_f64 *)tiles_x[kw], *ty = (lds_f64 *)tiles_y[kw];
+    lds_i32 *te = (lds_i32 *)tiles_x[kw];
+    const bool tally = a.tally != 0;
+    if (tally)
+        for (int c = threadIdx.x; c < a.n_cells; c += 256) hist[c] = 0.0;
+    if (threadIdx.x < 16) s_sum[threadIdx.x] = 0.0;
+    for (int64_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+        __syncthreads();  // (keeps the four waves of a unit together: they complete each other's partial cache lines; s_sum is zero)
+        const int64_t w = a.corder ? a.corder[unit >> 2] : (unit >> 2);
+        const int q = (int)(unit & 3);
+        const int64_t slot = w * 64 + 16 * q + tl;
+        // every lane holds its load-mapping track's uid, count, offset, line and weight (the 4 lanes of a track load the same words)
+        int32_t cnt = 0, u = 0;
+        int64_t off = 0;
+        double tA = 0.0, tB = 0.0, tC = 0.0, tW = 0.0;
+        if (slot < t.n) {
+            u = t.perm[slot];
+            cnt = counts[u];
+            off = offsets[u];
+        }
+        int32_t gmax = cnt;
+        for (int o = 8; o > 0; o >>= 1) {
+            const int32_t v = __shfl_xor(gmax, o, 64);
+            gmax = v > gmax ? v : gmax;
+        }
+        gmax = __shfl(gmax, 0, 64);
+        if ((kw << kChunkLog2) < gmax && slot < t.n) { tA = t.A[u]; tB = t.B[u]; tC = t.C[u]; tW = out.delta_s[t.azim[u] - 1]; }
+        const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
+        const int lane_q = 16 * q + tl;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
+            const int r0 = j << kChunkLog2;
+            const int32_t c = ctab[j];
+            int32_t ve[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ve[i] = __builtin_nontemporal_load(&stg.element[stage_slot(c, i * 4 + rr, lane_q)]);
+            // lanes 0..15: the row before this chunk's first, of their own track (only when the track reaches this chunk)
+            int32_t hw = 0;
+            const bool hrow = j > 0 && lane < 16 && cnt > r0;
+            if (hrow) hw = stg.element[stage_slot(ctab[j - 1], kChunkRows - 1, lane_q)];
+            double vx[8], vy[8];
+            {
+                double eA[8], eB[8], eC[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool coded = r0 + i * 4 + rr < cnt && ve[i] > 0;
+                    const RT_G EdgeABC *e = a.etab + (coded ? ve[i] - 1 : 0);
+                    eA[i] = e->A; eB[i] = e->B; eC[i] = e->C;
+                }
+                double hA = 0, hB = 0, hC = 0;
+                if (lane < 16) { const RT_G EdgeABC *e = a.etab + (hrow && hw > 0 ? hw - 1 : 0); hA = e->A; hB = e->B; hC = e->C; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    edge_exit_point(tA, tB, tC, eA[i], eB[i], eC[i], vx[i], vy[i]);
+                    if (__builtin_expect(r0 + i * 4 + rr < cnt && ve[i] < 0, 0)) {  // a record of the generic step: its own q
+                        vx[i] = stg.s_qx[-ve[i] - 1]; vy[i] = stg.s_qy[-ve[i] - 1];
+                    }
+                }
+                double hx = 0.0, hy = 0.0;
+                if (hrow) {
+                    edge_exit_point(tA, tB, tC, hA, hB, hC, hx, hy);
+                    if (__builtin_expect(hw < 0, 0)) { hx = stg.s_qx[-hw - 1]; hy = stg.s_qy[-hw - 1]; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rl = i * 4 + rr;
+                    tx[tl * kC3Pitch + 1 + rl] = vx[i];
+                    ty[tl * kC3Pitch + 1 + rl] = vy[i];
+                }
+                if (lane < 16) { tx[tl * kC3Pitch] = hx; ty[tl * kC3Pitch] = hy; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // Pass 1 gathers the records (and fetches the side list's p of marked rows) into registers, pass 2 only
+            // stores: a load between the stores would have to wait for every store queued before it.
+            double rpx[8], rpy[8], rqx[8], rqy[8];
+            int32_t re[8];
+            int64_t ro[8];
+            bool rv[8];
+            double rwt[8];  // fill_volumes' weight of the track, δs[azim]
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int tt = 2 * g + sub;
+                const int32_t ct = __shfl(cnt, tt, 64);
+                const int64_t ot = __shfl(off, tt, 64);
+                rwt[g] = __shfl(tW, tt, 64);  // (shuffles in uniform control flow only: an inactive lane supplies nothing)
+                const int row = r0 + rowL;
+                rv[g] = row < ct;
+                ro[g] = (row < ct && ot + row < out.cap) ? ot + row : -1;
+                rqx[g] = tx[tt * kC3Pitch + 1 + rowL]; rqy[g] = ty[tt * kC3Pitch + 1 + rowL];
+                rpx[g] = tx[tt * kC3Pitch + rowL]; rpy[g] = ty[tt * kC3Pitch + rowL];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) te[tl * kC3Pitch + 1 + i * 4 + rr] = ve[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int tt = 2 * g + sub;
+                re[g] = te[tt * kC3Pitch + 1 + rowL];
+                if (__builtin_expect(rv[g] && re[g] < 0, 0)) {  // this record keeps its own entry point (and names its cell)
+                    const int32_t idx = -re[g] - 1;
+                    rpx[g] = stg.s_px[idx]; rpy[g] = stg.s_py[idx];
+                    re[g] = 3 * (stg.s_el[idx] - 1) + 1;  // (as a word: cell = (word - 1) / 3)
+                }
+            }
+            double rl_[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const double ell = norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]);  // Segment ctor, src/segment.jl:31-33
+                rl_[g] = ell;
+                const int32_t el = (int32_t)((uint32_t)(re[g] > 0 ? re[g] - 1 : 0) / 3u) + 1;
+                re[g] = el;
+                if (RECORDS && ro[g] >= 0) {
+                    const int64_t o = ro[g];
+                    // plain stores: the partial lines at the ends of a run wait in L2 for the sibling wave's half
+                    out.px[o] = rpx[g];
+                    out.py[o] = rpy[g];
+                    out.qx[o] = rqx[g];
+                    out.qy[o] = rqy[g];
+                    out.ell[o] = ell;
+                    out.element[o] = el;
+                }
+                if (tally && rv[g]) {
+                    atomicAdd(&hist[el - 1], rwt[g] * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
+                    acc[g] += ell;
+                }
+            }
+            if (ROWS) {
+                // (ℓ, cell) back in the load mapping: a staging row of the wave's quarter is one 128-B / 64-B piece per array
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int tt = 2 * g + sub;
+                    ty[tt * kC3Pitch + 1 + rowL] = rl_[g];
+                    te[tt * kC3Pitch + 1 + rowL] = re[g];
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rl = i * 4 + rr;
+                    if (r0 + rl < cnt) {
+                        const int64_t sidx = stage_slot(c, rl, lane_q);
+                        a.ell_rows[sidx] = ty[tl * kC3Pitch + 1 + rl];
+                        a.cell_rows[sidx] = te[tl * kC3Pitch + 1 + rl];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
+        }
+        if (tally) {
+            // Σℓ of the 16 tracks over this wave's rows, reduced over the 32 lanes of a half; the four waves' parts meet in LDS
+            if ((kw << kChunkLog2) < gmax) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    double v = acc[g];
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (rowL == 0 && v != 0.0) atomicAdd(&s_sum[2 * g + sub], v);
+                }
+            }
+            __syncthreads();
+            if (kw == 0 && lane < 16) {
+                const double S = s_sum[lane];
+                s_sum[lane] = 0.0;
+                if (slot < t.n) {
+                    const double L = t.ell[u];
+                    // any-order sum against the left-to-right one: within cnt·2⁻⁵³·Σ; 96 bands hold the statistic's 64 (k_finish)
+                    if (a.force_exact || sum_check_is_marginal(L, S, a.rtol, cnt, 96.0)) {
+                        const int32_t e = atomicAdd((int32_t *)&a.marg[0], 1);
+                        if (e < a.marg_cap) a.marg[1 + e] = (int32_t)slot;  // (marg_cap = every march slot: cannot overflow)
+                    } else if (status[u] == RT_TRACK_OK && !isapprox_s(L, S, a.rtol)) {  // src/track.jl:171-175
+                        status[u] = RT_TRACK_LENGTH_MISMATCH;
+                        atomicAdd(&a.ctl[0], 1ull);
+                        atomicMin(&a.ctl[1], (unsigned long long)(u + 1));
+                    }
+                }
+            }
+        }
+    }
+    // this workgroup's share of `volumes`, as plain stores: k_finish adds the shares in workgroup order (hundreds of workgroups
+    // adding thousands of values each with global atomics at the same moment took 60 µs, and the sum depended on their order)
+    if (tally) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < a.n_cells; c += 256) a.slabs[(int64_t)blockIdx.x * a.n_cells + c] = hist[c];
+    }
+}
+
+// After k_materialise: (1) the tracks whose Σℓ check a sum in another order cannot decide are summed left to right — from
+// the records, or from the ℓ rows when the call wrote no records — and checked as the reference does (src/track.jl:171-175);
+// the statistic of rt_last_stats (tracks within 64 summation-order bands of the threshold) is counted here; (2) volumes =
+// Σ shares ./ n_azim_2 (src/trackgenerator.jl:376-386), the workgroups' shares added in workgroup order; (3) the block that
+// finishes last — a ticket — copies the control block to the host and writes the call's sequence number behind it.
+// mode: bit 0 volumes, bit 1 exact sums.
+__global__ __launch_bounds__(256) void k_finish(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
+                                                const int64_t *__restrict__ offsets, const double *__restrict__ ell, int64_t cap,
+                                                DStage stg, const double *__restrict__ ell_rows, double rtol, int32_t *__restrict__ marg,
+                                                double *__restrict__ volumes, const double *__restrict__ slabs, int32_t n_slabs,
+                                                int32_t n_cells, double n_azim_2, int32_t mode, unsigned long long *__restrict__ ctl,
+                                                unsigned long long *__restrict__ host_copy, unsigned long long seq) {
+    __shared__ int last_wg;
+    const bool void_attempt = stg.cursor[1] != 0 || stg.cursor[3] != 0;
+    if (!void_attempt) {
+        if (mode & 2) {
+            const int32_t nm = marg[0];
+            for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < nm; e += gridDim.x * 256) {
+                const int32_t slot = marg[1 + e];
+                if (slot < 0) continue;  // done by an earlier pass
+                const int32_t u = t.perm[slot];
+                const int32_t cnt = counts[u];
+                const int64_t off = offsets[u];
+                double S = 0.0;
+                if (ell_rows) {
+                    const RT_G int32_t *ctab = stg.ctab + (int64_t)(slot >> 6) * kMaxChunks;
+                    for (int32_t r = 0; r < cnt; ++r) S += ell_rows[stage_slot(ctab[r >> kChunkLog2], r & (kChunkRows - 1), slot & 63)];
+                } else if (ell && off + cnt <= cap) {
+                    for (int32_t r = 0; r < cnt; ++r) S += ell[off + r];
+                } else {
+                    atomicAdd(&ctl[kCtlDeferred], 1ull);  // the host compacts again with larger arrays and calls this once more
+                    continue;
+                }
+                marg[1 + e] = -1 - slot;
+                const double L = t.ell[u];
+                if (sum_check_is_marginal(L, S, rtol, cnt)) atomicAdd(&ctl[kCtlNearRtol], 1ull);
+                if (status[u] == RT_TRACK_OK && !isapprox_s(L, S, rtol)) {
+                    status[u] = RT_TRACK_LENGTH_MISMATCH;
+                    atomicAdd(&ctl[0], 1ull);
+                    atomicMin(&ctl[1], (unsigned long long)(u + 1));
+                }
+            }
+        }
+    }
+    if (!void_attempt && (mode & 1)) {
+        // 16 cells x 16 ranges of shares per workgroup: a thread adds its range of shares of one cell in order, the 16 partial
+        // sums are added in range order — the same order in every run
+        __shared__ double part[16][17];
+        const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+        const int b0 = (int)((int64_t)n_slabs * rg / 16), b1 = (int)((int64_t)n_slabs * (rg + 1) / 16);
+        for (int c0 = blockIdx.x * 16; c0 < n_cells; c0 += gridDim.x * 16) {
+            const int c = c0 + cl;
+            double v = 0.0;
+            if (c < n_cells)
+                for (int b = b0; b < b1; ++b) v += slabs[(int64_t)b * n_cells + c];
+            part[rg][cl] = v;
+            __syncthreads();
+            if (rg == 0 && c < n_cells) {
+                double tsum = 0.0;
+                for (int r = 0; r < 16; ++r) tsum += part[r][cl];
+                volumes[c] = tsum / n_azim_2;  // volumes ./= n_azim_2, src/trackgenerator.jl:386
+            }
+            __syncthreads();
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_wg = atomicAdd((unsigned int *)&ctl[kCtlFinishTicket], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last_wg) return;
+    __threadfence();
+    if (threadIdx.x == 0 && __hip_atomic_load(&ctl[kCtlDeferred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) marg[0] = 0;  // the list is consumed
+    if (threadIdx.x == 0) ctl[kCtlFinishTicket] = 0;  // (a second pass of this call counts again)
+    if (host_copy) {
+        if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&host_copy[kCtlWords], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- exclusive scan of per-track counts (int32) into CSR offsets (int64) ----------------
 constexpr int kScanBlock = 256;
 constexpr int kScanPer = 4;
@@ -1308,11 +1662,15 @@ constexpr int kScanTile = kScanBlock * kScanPer;
 
 // Start of a call: the control block (failure summary, total, pool cursor, scan ticket) and `volumes` are reset
 // by one small kernel instead of a host-to-device copy and a memset.
-__global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells, int32_t first_chunk) {
+// The reset image of control-block word i: [1] first failing uid, an atomicMin target; [18] pool cursor (low word; chunks below
+// first_chunk are reserved) + overflow flag; [19] side-list cursor (low word; entries below side_first are reserved) + overflow flag
+__device__ __forceinline__ unsigned long long ctl_reset_word(int i, int32_t first_chunk, int32_t side_first) {
+    return i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk : (i == 19 ? (unsigned long long)(uint32_t)side_first : 0ull));
+}
+__global__ void k_prologue(unsigned long long *__restrict__ ctl, double *__restrict__ volumes, int32_t n_cells, int32_t first_chunk, int32_t side_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // [1]: first failing uid, an atomicMin target; [18]: pool cursor (low word; chunks below first_chunk are reserved) + overflow flag
-    if (i < kCtlWords) ctl[i] = i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk : 0ull);
-    if (i < n_cells) volumes[i] = 0.0;
+    if (i < kCtlWords) ctl[i] = ctl_reset_word(i, first_chunk, side_first);
+    if (volumes && i < n_cells) volumes[i] = 0.0;
 }
 
 // Pass 1 of the scan: the sum of every tile of kScanTile counts.  The block that finishes last (a ticket
@@ -1329,7 +1687,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
                                                                const unsigned long long *__restrict__ ctl,
                                                                unsigned long long *__restrict__ host_copy,
                                                                unsigned long long *__restrict__ ctl_next, int32_t first_chunk_next,
-                                                               unsigned long long seq) {
+                                                               int32_t side_first_next, unsigned long long seq) {
     __shared__ int64_t red[kScanBlock / 64];
     __shared__ int64_t carry;
     __shared__ int last;
@@ -1386,7 +1744,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__
     }
     if (ctl_next && threadIdx.x < kCtlWords) {
         const int i = threadIdx.x;
-        ctl_next[i] = i == 1 ? ~0ull : (i == 18 ? (unsigned long long)(uint32_t)first_chunk_next : 0ull);
+        ctl_next[i] = ctl_reset_word(i, first_chunk_next, side_first_next);
     }
 }
 
@@ -1753,6 +2111,7 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
                 struct Rec { double ell; int32_t el; };
                 auto load_rec = [&](const int r) -> Rec {
                     const int rc = r < cnt ? r : (cnt > 0 ? cnt - 1 : 0);  // (a lane's own records only; masked where r >= cnt)
+                    if (cnt == 0) return Rec{0.0, 1};                      // (a track without records: offsets[u] may equal the total)
                     return Rec{a.ell[off + rc], a.element[off + rc]};
                 };
                 auto cell_of = [&](const Rec &R, const int r) -> int32_t { return r < cnt ? R.el - 1 : 0; };
@@ -1858,6 +2217,9 @@ struct rt_mesh {
     int64_t pool_chunks_hint = 0;  // > 0: initial staging-pool size in chunks (tests force the overflow path)
     int64_t test_out_records = 0;   // tests only: capacity of the output arrays on a handle's first call (forces the re-compaction path)
     int test_volumes_fallback = 0;  // tests only: take the split mode's volumes recomputation path unconditionally
+    int test_exact_sums = 0;        // tests only: every track's Σℓ check by k_finish's left-to-right sum (two-phase march)
+    int64_t side_entries_hint = 0;  // tests only: capacity of the dynamic part of the side list on a handle's first call (forces its overflow path)
+    int mat_wgs = 0;                // k_materialise: workgroups per CU (0: as many as fit)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
@@ -1884,7 +2246,7 @@ struct rt_tracks {
     DevBuf<unsigned long long> ctl;  // two blocks of kCtlWords: calls alternate, each call's scan resets the other block
     int ctl_idx = 0;                 // block of the next call
     bool ctl_clean[2] = {false, false};
-    int32_t ctl_first_chunk[2] = {-1, -1};  // ... reset with this many reserved chunks
+    int64_t ctl_first_chunk[2] = {-1, -1};  // ... reset with this many reserved chunks (low word) and side-list entries (high word)
     DevBuf<double> vacc;             // fused fill_volumes accumulates here; k_scan_write scales it into `volumes` and zeroes it
     bool vacc_clean = false;
 #ifdef RT_TIMING
@@ -1899,6 +2261,13 @@ struct rt_tracks {
     // staging pool of the single-pass march
     DevBuf<double> gpx, gpy, gqx, gqy;
     DevBuf<int32_t> gelement, ctab, cowner;
+    // two-phase march (k_march<TOPO> + k_materialise): the side list of records that keep their own end points, the
+    // workgroups' shares of `volumes`, the list of tracks whose Σℓ check k_finish decides with a left-to-right sum
+    DevBuf<double> side_px, side_py, side_qx, side_qy, slabs;
+    DevBuf<int32_t> side_el, marg;
+    int64_t side_cap = 0, side_needed_last = 0;
+    int32_t n_slabs = 0;
+    bool marg_clean = false;
     DevBuf<int32_t> fst_i;   // k_first: it, T, pred per march slot
     DevBuf<double> fst_v;    // ... and its ten doubles
     int32_t last_first = 0;  // 1: the last call made the first records with k_first
@@ -1933,6 +2302,8 @@ struct rt_tracks {
         const int32_t *corder = nullptr;
         int64_t n_whole_waves = 0;
         bool split = false, split_all = false, staged = false;  // staged: the last call left staged rows (single-pass mode)
+        bool codes = false;   // ... as one word per record (k_march<TOPO>): k_materialise turns them into records / (ℓ, cell) rows
+        double rtol = 0.0;
     } cplan;
     bool compacted = false;  // the six record arrays hold the last call's records
     bool in_flight = false;  // option "async": the last rt_segmentize returned while its compaction was still on the stream
@@ -1942,6 +2313,7 @@ struct rt_tracks {
     DevBuf<double> sw_w, sw_xs, sw_psi_in, sw_psi_out, sw_phi;
     DevBuf<double> sw_ell;      // ℓ of every staged row (slot-indexed like the staging pool), left by the first staged pass after a call
     bool sw_ell_valid = false;  // ... of the last rt_segmentize
+    DevBuf<int32_t> sw_cell;    // codes: cell + 1 of every staged row, beside sw_ell (k_materialise<.., ROWS>)
     bool sw_links = false, sw_has_w = false, sw_has_xs = false, sw_done = false;
     int32_t sw_groups = 0, sw_last_input = 0, sw_last_gp = 0, sw_last_passes = 0;
     int64_t refusals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // cheap-step refusals of the last call by certificate term
@@ -2112,9 +2484,70 @@ int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out) {
     return RT_SUCCESS;
 }
 
-// Staged rows -> compact CSR records (k_compact3) for the plan of the last single-pass call.
+// Codes -> records and / or (ℓ, cell) rows (k_materialise) for the plan of the last two-phase call.  tally: the call's first
+// pass over the codes — Σℓ, status, fill_volumes' shares (k_finish completes them).
+int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl) {
+    using rt::as_global;
+    rt_mesh *m = t->mesh;
+    const rt_tracks::CompactPlan &c = t->cplan;
+    if (t->n <= 0 || c.n_whole_waves <= 0) return RT_SUCCESS;
+    rt::DMat a{};
+    a.etab = m->d.etab; a.corder = as_global(c.corder);
+    a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.n_cells = m->n_cells; a.tally = tally ? 1 : 0;
+    a.force_exact = m->test_exact_sums; a.ctl = d_ctl;
+    const size_t hist = tally ? (size_t)m->n_cells * sizeof(double) : 0;
+    const size_t stat = 2 * 4 * 16 * rt::kC3Pitch * sizeof(double) + 256;  // the kernel's own tiles
+    int per_cu = (int)std::min<size_t>(4, (size_t)(158 * 1024) / (stat + hist));
+    if (m->mat_wgs > 0) per_cu = std::min(per_cu, m->mat_wgs);
+    if (per_cu < 1) { set_error("k_materialise: an LDS copy of volumes (%zu B) does not fit", hist); return RT_ERR_INVALID; }
+    const unsigned blocks = (unsigned)std::min<int64_t>(a.n_units, (int64_t)m->n_cus * per_cu);
+    if (tally) {
+        RT_HIP(t->slabs.reserve((size_t)blocks * m->n_cells));
+        RT_HIP(t->marg.reserve((size_t)c.n_whole_waves * 64 + 1));
+        if (!t->marg_clean) { RT_HIP(hipMemsetAsync(t->marg.p, 0, sizeof(int32_t), s)); t->marg_clean = true; }
+        t->n_slabs = (int32_t)blocks;
+        a.slabs = as_global(t->slabs.p); a.marg = as_global(t->marg.p); a.marg_cap = (int32_t)std::min<int64_t>(c.n_whole_waves * 64, 0x7fffffff);
+    }
+    if (rows) {
+        const size_t slots = (size_t)t->pool_chunks * rt::kChunkRows * 64;
+        RT_HIP(t->sw_ell.reserve(slots > 0 ? slots : 1)); RT_HIP(t->sw_cell.reserve(slots > 0 ? slots : 1));
+        a.ell_rows = as_global(t->sw_ell.p); a.cell_rows = as_global(t->sw_cell.p);
+    }
+    auto go = [&]<bool RECORDS, bool ROWS>() -> int {
+        static size_t attr_set = 0;  // (per instantiation; raised only: hipFuncSetAttribute costs host time)
+        if (hist > attr_set) {
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_materialise<RECORDS, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist));
+            attr_set = hist;
+        }
+        hipLaunchKernelGGL((rt::k_materialise<RECORDS, ROWS>), dim3(blocks), dim3(256), hist, s, c.d_whole, (const int32_t *)t->counts.p,
+                           t->status.p, (const int64_t *)t->offsets.p, c.stg, out, a);
+        return RT_SUCCESS;
+    };
+    if (records && rows) return go.template operator()<true, true>();
+    if (records) return go.template operator()<true, false>();
+    if (rows) return go.template operator()<false, true>();
+    set_error("k_materialise: nothing to write");
+    return RT_ERR_INVALID;
+}
+
+// k_finish behind a tallying k_materialise (mode bit 0: volumes from the shares, bit 1: exact Σℓ of the listed tracks);
+// copies the control block to the host.
+void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, int mode, bool from_rows, double n_azim_2, unsigned long long *d_ctl,
+                   unsigned long long *h_res_dev, unsigned long long seq) {
+    rt_mesh *m = t->mesh;
+    const rt_tracks::CompactPlan &c = t->cplan;
+    const unsigned blocks = (unsigned)std::min(1024, std::max(1, (m->n_cells + 15) / 16));
+    hipLaunchKernelGGL(rt::k_finish, dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
+                       (const int64_t *)t->offsets.p, from_rows ? (const double *)nullptr : (const double *)t->sell.p, out.cap, c.stg,
+                       from_rows ? (const double *)t->sw_ell.p : (const double *)nullptr, c.rtol, t->marg.p, t->volumes.p,
+                       (const double *)t->slabs.p, t->n_slabs, m->n_cells, n_azim_2, mode, d_ctl, h_res_dev, seq);
+}
+
+// Staged rows -> compact CSR records for the plan of the last single-pass call: k_compact3 over (q, ±cell) rows, or — codes —
+// k_materialise without its tallies.
 void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s) {
     const rt_tracks::CompactPlan &c = t->cplan;
+    if (c.codes) { (void)launch_materialise(t, out, s, true, false, false, nullptr); return; }
     // k_compact4 (stores in memory order) was built for batches whose records run to gigabytes and measured no faster:
     // C5 1.95 vs 1.84 ms, C4 0.270 vs 0.262, C3 0.149 vs 0.151 — it runs only on request (option "compact_kernel" = 4)
     const bool use4 = t->mesh->compact_kernel == 4;
@@ -2137,10 +2570,22 @@ int ensure_compacted(rt_tracks *t) {
     if (!t->cplan.staged) { set_error("the last rt_segmentize left no staged records"); return RT_ERR_NOT_SEGMENTIZED; }
     rt::DOut out{};
     if (int rc = reserve_records(t, t->total, out)) return rc;
+    out.delta_s = rt::as_global(t->delta_s.p);
     launch_compaction(t, out, t->mesh->stream);
     RT_HIP(hipStreamSynchronize(t->mesh->stream));
     RT_HIP(hipGetLastError());
     t->compacted = true;
+    return RT_SUCCESS;
+}
+
+// rt_sweep over a two-phase call's staging: the (ℓ, cell) rows, written by the call itself ("compact" = 0) or here on first use.
+int ensure_rows(rt_tracks *t) {
+    if (t->sw_ell_valid) return RT_SUCCESS;
+    rt::DOut out{};
+    out.delta_s = rt::as_global(t->delta_s.p);
+    if (int rc = launch_materialise(t, out, t->mesh->stream, false, true, false, nullptr)) return rc;
+    RT_HIP(hipGetLastError());
+    t->sw_ell_valid = true;
     return RT_SUCCESS;
 }
 
@@ -2161,6 +2606,8 @@ void free_tracks(rt_tracks *t) {
     t->gpx.release(); t->gpy.release(); t->gqx.release(); t->gqy.release();
     t->gelement.release(); t->ctab.release(); t->cowner.release(); t->fst_i.release(); t->fst_v.release();
     t->sw_src.release(); t->sw_w.release(); t->sw_xs.release(); t->sw_psi_in.release(); t->sw_psi_out.release(); t->sw_phi.release();
+    t->sw_ell.release(); t->sw_cell.release();
+    t->side_px.release(); t->side_py.release(); t->side_qx.release(); t->side_qy.release(); t->side_el.release(); t->slabs.release(); t->marg.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
     t->s_el.release(); t->s_eq.release(); t->p_count.release(); t->p_flags.release(); t->p_valid.release(); t->p_rel.release();
     t->s_px.release(); t->s_py.release(); t->s_qx.release(); t->s_qy.release(); t->s_ell.release(); t->p_sum.release();
@@ -2335,6 +2782,9 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "test_out_records")) { mesh->test_out_records = value; return RT_SUCCESS; }
     if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "test_exact_sums")) { mesh->test_exact_sums = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "side_entries_hint")) { mesh->side_entries_hint = value; return RT_SUCCESS; }
+    if (!strcmp(name, "mat_wgs")) { mesh->mat_wgs = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
         mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
@@ -2557,7 +3007,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     unsigned long long *const d_ctl = t->ctl.p + (size_t)cb * rt::kCtlWords;
     unsigned long long *const d_ctl_other = t->ctl.p + (size_t)(1 - cb) * rt::kCtlWords;
     const bool ctl_was_clean = t->ctl_clean[cb];
-    const int32_t ctl_was_first = t->ctl_first_chunk[cb];
+    const int64_t ctl_was_first = t->ctl_first_chunk[cb];
     const bool vacc_was_clean = t->vacc_clean;
     t->ctl_clean[0] = t->ctl_clean[1] = false;  // (set again when this call has succeeded)
     t->vacc_clean = false;
@@ -2621,13 +3071,15 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 
     // copy_out: k_scan_tile_sums' last block also writes the control block to the pinned host copy; scale: k_scan_write also
     // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
-    int32_t first_chunk_this_call = 0;
-    auto scan_counts = [&](bool copy_out, bool scale) -> int {
+    int32_t first_chunk_this_call = 0, side_first_this_call = 0;
+    // reset_other: the scan's last block also resets the OTHER control block for the next call (single-pass calls)
+    auto scan_counts = [&](bool copy_out, bool scale, bool reset_other) -> int {
         if (n > 0) {
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, n_tiles, d_total, reinterpret_cast<unsigned int *>(d_ctl + 20),
                                (const unsigned long long *)d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
-                               copy_out ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, ++t->call_seq);
+                               reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call,
+                               ++t->call_seq);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, d_total, t->offsets.p, scale ? t->volumes.p : (double *)nullptr, m->n_cells,
                                (double)n_azim_2, t->vacc.p);
@@ -2710,14 +3162,34 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
                            : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * ((split ? t->n_vwaves : 0) + (split_all ? 0 : n_whole_waves)) + 64;
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
-        fused_volumes_this_call = fuse;
+        fused_volumes_this_call = fuse;  // (two-phase march: k_materialise + k_finish produce `volumes` inside the call)
+        // the side list of the two-phase march: one reserved entry per march slot (a track's first record) + the records the
+        // generic step makes further on — estimated from the share of records without a walk certificate (or the last call's need)
+        const int64_t side_static = n_whole_waves * 64;
+        int64_t side_want = 0;
+        if (topo) {
+            const double unwalked = m->n_records > 0 ? 1.0 - (double)m->n_records_walk / (double)m->n_records : 1.0;
+            const int64_t dyn = t->side_needed_last > 0 ? t->side_needed_last + t->side_needed_last / 8 + 1024
+                                                        : (int64_t)(1.3 * unwalked * m->kappa * t->sum_ell) + n / 16 + 4096;
+            side_want = side_static + ((m->side_entries_hint > 0 && t->side_cap == 0) ? m->side_entries_hint : dyn);
+        }
         for (int attempt = 0;; ++attempt) {
-            if (want > t->pool_chunks) {
+            if (want > t->pool_chunks || (!topo && t->gqx.cap < (size_t)t->pool_chunks * rt::kChunkRows * 64)) {
+                want = std::max(want, t->pool_chunks);
                 const size_t slots = (size_t)want * rt::kChunkRows * 64;
-                RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots));
-                RT_HIP(t->gqy.reserve(slots)); RT_HIP(t->gelement.reserve(slots));
+                // (q, ±cell) rows with sparse p for the exact march; the two-phase march stages one 4-B word per record
+                if (!topo) {
+                    RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots)); RT_HIP(t->gqy.reserve(slots));
+                }
+                RT_HIP(t->gelement.reserve(slots));
                 RT_HIP(t->cowner.reserve((size_t)want));
                 t->pool_chunks = want;
+            }
+            if (topo && side_want > t->side_cap) {
+                const size_t ne = (size_t)std::min<int64_t>(side_want, 0x7ffffff0);
+                RT_HIP(t->side_px.reserve(ne)); RT_HIP(t->side_py.reserve(ne)); RT_HIP(t->side_qx.reserve(ne)); RT_HIP(t->side_qy.reserve(ne));
+                RT_HIP(t->side_el.reserve(ne));
+                t->side_cap = (int64_t)ne;
             }
             // The six output arrays are sized from the Cauchy–Crofton estimate of the record count (or from what the
             // previous call produced), not from the pool's slots: march -> scan -> compaction still run back to back
@@ -2733,6 +3205,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
             stg.static0 = (!split && n_whole_waves < stg.pool_chunks) ? 1 : 0;
+            if (topo) {
+                stg.s_px = as_global(t->side_px.p); stg.s_py = as_global(t->side_py.p); stg.s_qx = as_global(t->side_qx.p);
+                stg.s_qy = as_global(t->side_qy.p); stg.s_el = as_global(t->side_el.p);
+                stg.side_cap = (int32_t)t->side_cap; stg.side_static = (int32_t)side_static;
+            }
 #ifdef RT_TIMING
             RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
             RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
@@ -2747,12 +3224,13 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 rt_tracks::CompactPlan &c = t->cplan;
                 c.stg = stg; c.stg_pieces = stg_pieces; c.d_whole = d_whole; c.sp = sp; c.corder = corder;
                 c.n_whole_waves = n_whole_waves; c.split = split; c.split_all = split_all; c.staged = false;
+                c.codes = topo; c.rtol = rtol;
             }
             // Everything one attempt puts on the stream(s), as one function.  (Capturing it once into a HIP graph and replaying it
             // was tried: the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on
             // events that were only ever recorded inside a graph — DESIGN.md §4.)
             // every track's first record ahead of the march (k_first): whole tracks with their reserved first chunks, the usual k
-            const bool use_first = m->first && !split && !hybrid && stg.static0 && !widek && n > 0 && m->lds_records == 0;
+            const bool use_first = m->first && !split && !hybrid && !topo && stg.static0 && !widek && n > 0 && m->lds_records == 0;
             fst = rt::DFirst{};
             if (use_first) {
                 const size_t ns = (size_t)n_whole_waves * 64;
@@ -2765,12 +3243,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             // pass adds into `volumes`, zeroed here.  The reset kernel runs only when the control block or the accumulator is
             // not known to be clean: a handle's first call, a re-run after a pool overflow, a changed number of reserved chunks.
             first_chunk_this_call = stg.static0 ? (int32_t)n_whole_waves : 0;
+            side_first_this_call = topo ? (int32_t)side_static : 0;
+            const int64_t reset_key = (int64_t)first_chunk_this_call | ((int64_t)side_first_this_call << 32);
             if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
-            const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != first_chunk_this_call || !(fuse && n > 0 && vacc_was_clean);
+            // (two-phase march: neither `vacc` nor `volumes` is accumulated into — k_finish writes `volumes`)
+            const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != reset_key || !(topo || (fuse && n > 0 && vacc_was_clean));
             auto enqueue_attempt = [&]() -> int {
                 if (need_reset)
                     hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, d_ctl,
-                                       (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk_this_call);
+                                       topo ? (double *)nullptr : ((fuse && n > 0) ? t->vacc.p : t->volumes.p), m->n_cells, first_chunk_this_call,
+                                       side_first_this_call);
                 if (int rc = rec(1)) return rc;
                 if (use_first)
                     hipLaunchKernelGGL(rt::k_first, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, m->d, t->d, prm, stg, fst);
@@ -2801,10 +3283,8 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     // experiment: eight-wave workgroups (one per CU) with all walk records in LDS (1), or from L2 as usual (2: its control)
                     const size_t lds_base = ((hist_bytes + 8 * rt::kMaxChunks * sizeof(int32_t) + 15) & ~(size_t)15);
                     const size_t lds_smem = lds_base + (size_t)3 * m->n_cells * sizeof(rt::WalkRec);
-                    if (topo && fuse_waves == 4)
-                        rc = march.template operator()<rt::kStage, 4, false, false, false, true>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
-                    else if (topo)
-                        rc = march.template operator()<rt::kStage, 6, false, false, false, true>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
+                    if (topo)  // the decision-only march keeps no LDS copy of `volumes`: four-wave workgroups, their chunk tables only
+                        rc = march.template operator()<rt::kStage, 4, false, false, false, true>((unsigned)((n_whole_waves + 3) / 4), 4 * rt::kMaxChunks * sizeof(int32_t));
                     else if (fuse && m->lds_records == 1 && !hybrid && lds_smem <= 160 * 1024)
                         rc = march.template operator()<rt::kStage, 8, false, false, true>((unsigned)((n_whole_waves + 7) / 8), lds_smem);
                     else if (fuse && m->lds_records == 2 && !hybrid && lds_smem <= 160 * 1024)
@@ -2818,9 +3298,16 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     if (hybrid) RT_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
                 }
                 if (int rc = rec(2)) return rc;
-                if (int rc = scan_counts(true, fuse)) return rc;
+                if (int rc = scan_counts(!topo, fuse && !topo, true)) return rc;
                 if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
-                if (do_compact) launch_compaction(t, out, s);
+                if (topo) {
+                    // codes -> records (or, "compact" = 0, (ℓ, cell) rows) + Σℓ / status / fill_volumes; k_finish completes them and
+                    // copies the control block to the host
+                    if (int rc = launch_materialise(t, out, s, do_compact, !do_compact, true, d_ctl)) return rc;
+                    launch_finish(t, out, s, 3, !do_compact, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+                } else if (do_compact) {
+                    launch_compaction(t, out, s);
+                }
                 if (int rc = rec(5)) return rc;
                 if (int rc = launch_volumes()) return rc;
                 volumes_pass = !(fuse && n > 0);
@@ -2835,7 +3322,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
 #ifdef RT_HOST_TIMING
             const double ht2 = ht_now();
 #endif
-            int32_t cur[4] = {0, 0, 0, 0};
+            int32_t cur[4] = {0, 0, 0, 0};  // pool cursor, pool overflow / argument mismatch, side-list cursor, side-list overflow
             if (n == 0) RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
             // option "async": back to the caller as soon as the scan's copy of the control block has arrived — total, failure
@@ -2855,10 +3342,17 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             memcpy(&total, h_res + 16, sizeof(total));
             memcpy(cur, h_res + 18, sizeof(cur));
             t->chunks_needed_last = cur[0];
-            if (do_compact && !cur[1] && total > out.cap) {
+            if (topo) t->side_needed_last = std::max<int64_t>(0, (int64_t)cur[2] - side_static);
+            if (do_compact && !cur[1] && !cur[3] && total > out.cap) {
                 // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
                 if (int rc = reserve_out(total + total / 32 + 4096)) return rc;
                 launch_compaction(t, out, s);
+                if (topo && h_res[rt::kCtlDeferred] != 0) {
+                    // tracks whose exact Σℓ k_finish could not form from the truncated records: once more, from the complete ones
+                    launch_finish(t, out, s, 2, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+                    RT_HIP(hipStreamSynchronize(s));
+                    memcpy(fi, h_res, sizeof(fi));
+                }
                 if (!fused_volumes_this_call && m->volumes_mode == 2) {  // the separate volumes pass read truncated records
                     RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
                     if (int rc = launch_volumes()) return rc;
@@ -2873,7 +3367,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 if (int rc = launch_volumes()) return rc;
                 RT_HIP(hipStreamSynchronize(s));
             }
-            if (!cur[1] && topo && fuse && h_res[rt::kCtlRestarts] != 0) {
+            if (!cur[1] && topo && false) {  // (two-phase march: a restarted track's rows are staged again, nothing was tallied)
                 // a track whose iteration bound reached the cap was marched again with exact steps: its cheap records had
                 // already been added to the fused volumes — recompute them from the records
                 if (!do_compact) {
@@ -2890,18 +3384,21 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 t->force_unsplit = true;
                 return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
             }
-            if (!cur[1]) {
+            if (!cur[1] && !cur[3]) {
                 t->cplan.staged = true;
                 if (do_compact) t->compacted = true;
+                if (topo && !do_compact) t->sw_ell_valid = true;  // (k_materialise left the (ℓ, cell) rows)
                 if (n > 0) {  // this call's scan has reset the other control block and (fused) left the accumulator zero
-                    t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = first_chunk_this_call;
-                    t->vacc_clean = fuse;
+                    t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = reset_key;
+                    t->vacc_clean = topo ? vacc_was_clean : fuse;
                     t->ctl_idx = 1 - cb;
                 }
                 break;
             }
-            if (attempt >= 3) { set_error("staging pool overflow persists (%d chunks needed)", cur[0]); return RT_ERR_HIP; }
-            want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
+            t->marg_clean = false;  // (a void attempt may have left entries in the list of tracks to sum exactly)
+            if (attempt >= 3) { set_error("staging pool / side list overflow persists (%d chunks, %d entries needed)", cur[0], cur[2]); return RT_ERR_HIP; }
+            if (cur[1]) want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
+            if (cur[3]) side_want = (int64_t)cur[2] + cur[2] / 8 + 1024;
         }
     } else {
         RT_HIP(hipMemcpyAsync(d_ctl, t->h_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
@@ -2911,7 +3408,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                                : march.template operator()<rt::kCount, 1, false, false>(grid, sizeof(int32_t))) return rc;
         }
         if (int rc = rec(2)) return rc;
-        if (int rc = scan_counts(false, false)) return rc;
+        if (int rc = scan_counts(false, false, false)) return rc;
         if (int rc = rec(3)) return rc;
         RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if (m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);  // (the count march is the longer half of this mode)
@@ -3197,6 +3694,12 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
         std::vector<double> xs(2 * nphi);
         for (size_t i = 0; i < nphi; ++i) {
             const double st = sigma_t[i], q = source ? source[i] : 0.0;
+            // τ = Σt·ℓ must be finite and >= 0: one_minus_exp_neg assembles 2^n from exponent bits for n <= 0 only, and a
+            // non-finite contribution would spread through the tallies' lane folds
+            if (!(st >= 0.0) || !std::isfinite(st) || !std::isfinite(q)) {
+                set_error("rt_sweep: sigma_t[%zu] = %g, source = %g (cross sections must be finite and >= 0)", i, st, q);
+                return RT_ERR_INVALID;
+            }
             xs[2 * i] = st;
             xs[2 * i + 1] = st > 0.0 ? q / st : 0.0;  // (a void cell: no attenuation, no source term)
         }
@@ -3248,7 +3751,13 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     // like the rows; every later pass — of this sweep and of all following sweeps over the same segmentation — reads (ℓ, cell)
     // rows instead (12 B instead of 20, no square root, no entry point).  Option "sweep_ell" = 0 switches this off.
     bool ell_rows = false;
-    if (staged && m->sweep_ell) {
+    if (staged && t->cplan.codes) {
+        // a two-phase call staged codes: the sweep reads (ℓ, cell) rows, which the call itself left ("compact" = 0) or which
+        // k_materialise writes now, once per segmentation
+        if (int rc = ensure_rows(t)) return rc;
+        a.stg.element = as_global(t->sw_cell.p);
+        ell_rows = true;
+    } else if (staged && m->sweep_ell) {
         const size_t slots = (size_t)t->pool_chunks * rt::kChunkRows * 64;
         if (t->sw_ell.reserve(slots > 0 ? slots : 1) == hipSuccess) ell_rows = true;
         else (void)hipGetLastError();  // (no memory for it: every pass derives ℓ itself)
@@ -3416,7 +3925,8 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
                    b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +
                    b(t->w_base) + b(t->w_P) + b(t->s_el) + b(t->s_eq) + b(t->p_count) + b(t->p_flags) + b(t->p_valid) + b(t->p_rel) + b(t->s_px) +
                    b(t->s_py) + b(t->s_qx) + b(t->s_qy) + b(t->s_ell) + b(t->p_sum) + b(t->vacc) + b(t->fst_i) + b(t->fst_v) + b(t->tau) +
-                   b(t->sigma_t) + b(t->sw_src) + b(t->sw_w) + b(t->sw_xs) + b(t->sw_psi_in) + b(t->sw_psi_out) + b(t->sw_phi) + b(t->sw_ell);
+                   b(t->sigma_t) + b(t->sw_src) + b(t->sw_w) + b(t->sw_xs) + b(t->sw_psi_in) + b(t->sw_psi_out) + b(t->sw_phi) + b(t->sw_ell) +
+                   b(t->sw_cell) + b(t->side_px) + b(t->side_py) + b(t->side_qx) + b(t->side_qy) + b(t->side_el) + b(t->slabs) + b(t->marg);
     }
     return RT_SUCCESS;
 }
