@@ -1373,37 +1373,54 @@ struct DMat {
     unsigned long long *ctl;      // the call's control block ([0] failed tracks, [1] first failing uid + 1)
 };
 
-template <bool RECORDS, bool ROWS>
-__global__ __launch_bounds__(256) void k_materialise(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
-                                                     const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
+// Shape: a workgroup = TEAMS teams of four waves sharing ONE LDS copy of `volumes`; a team takes a unit (wave k its chunks k,
+// k + 4, ...).  A wave works through a chunk in two passes of 16 rows, with two 2.5-KB LDS tiles of its own: the pass's exit
+// points (x, y; slot 0 of a track: the row before, i.e. the first row's entry point) go in in the load mapping and come out
+// in the store mapping, then the lengths and the cells take the same way — so only a few values per lane are live at a time
+// (the first version held a chunk's records in registers: 243 VGPRs, one or two waves per SIMD, twice the compaction's time).
+constexpr int kMatRows = 16;            // rows per pass
+constexpr int kMatPitch = kMatRows + 4; // doubles per track in a tile: slot 0 = the row before, slots 1..16 = the pass's rows
+#ifndef RT_MAT_OCC
+#define RT_MAT_OCC 4  // waves per SIMD the kernel is compiled for
+#endif
+template <bool RECORDS, bool ROWS, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS, RT_MAT_OCC) void k_materialise(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
+                                                             const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
     static_assert(kChunkRows == 32, "k_materialise moves 32-row chunks");
-    __shared__ double tiles_x[4][16 * kC3Pitch];  // per wave: q of the chunk's rows (slot 0: the row before), transposed from the
-    __shared__ double tiles_y[4][16 * kC3Pitch];  // load mapping to the store mapping; the x tile then carries the cells
-    __shared__ double s_sum[16];                  // Σℓ of the unit's tracks
+    __shared__ double tiles_x[4 * TEAMS][16 * kMatPitch];
+    __shared__ double tiles_y[4 * TEAMS][16 * kMatPitch];
+    __shared__ double s_sum[TEAMS][16];  // Σℓ of the units' tracks
     extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
     double *hist = reinterpret_cast<double *>(mat_smem);  // [n_cells] when a.tally
     if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
-    const int kw = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr+4, ...
-    const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub+2, ...
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int team = wv >> 2, kw = wv & 3;
+    const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr + 4, rr + 8, rr + 12 of the pass
+    const int rowL = lane & 15, sub = lane >> 4;  // store mapping: row rowL of tracks sub, sub + 4, sub + 8, sub + 12
     typedef __attribute__((address_space(3))) volatile double lds_f64;
     typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
-    lds_f64 *tx = (lds_f64 *)tiles_x[kw], *ty = (lds_f64 *)tiles_y[kw];
-    lds_i32 *te = (lds_i32 *)tiles_x[kw];
+    lds_f64 *X = (lds_f64 *)tiles_x[wv], *Y = (lds_f64 *)tiles_y[wv];
+    lds_i32 *Yi = (lds_i32 *)tiles_y[wv];
     const bool tally = a.tally != 0;
     if (tally)
-        for (int c = threadIdx.x; c < a.n_cells; c += 256) hist[c] = 0.0;
-    if (threadIdx.x < 16) s_sum[threadIdx.x] = 0.0;
-    for (int64_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+        for (int c = threadIdx.x; c < a.n_cells; c += 256 * TEAMS) hist[c] = 0.0;
+    if (threadIdx.x < 16 * TEAMS) (&s_sum[0][0])[threadIdx.x] = 0.0;
+    const int64_t per_round = (int64_t)gridDim.x * TEAMS;
+    const int64_t n_rounds = (a.n_units + per_round - 1) / per_round;
+    const int tb = tl * kMatPitch;
+    for (int64_t round = 0; round < n_rounds; ++round) {
         __syncthreads();  // (keeps the four waves of a unit together: they complete each other's partial cache lines; s_sum is zero)
-        const int64_t w = a.corder ? a.corder[unit >> 2] : (unit >> 2);
+        const int64_t unit = (round * gridDim.x + blockIdx.x) * TEAMS + team;  // (the teams of a workgroup: quarters of one march wave)
+        const bool have_unit = unit < a.n_units;
+        const int64_t w = !have_unit ? 0 : (a.corder ? a.corder[unit >> 2] : (unit >> 2));
         const int q = (int)(unit & 3);
         const int64_t slot = w * 64 + 16 * q + tl;
         // every lane holds its load-mapping track's uid, count, offset, line and weight (the 4 lanes of a track load the same words)
         int32_t cnt = 0, u = 0;
         int64_t off = 0;
         double tA = 0.0, tB = 0.0, tC = 0.0, tW = 0.0;
-        if (slot < t.n) {
+        const bool have = have_unit && slot < t.n;
+        if (have) {
             u = t.perm[slot];
             cnt = counts[u];
             off = offsets[u];
@@ -1414,144 +1431,152 @@ __global__ __launch_bounds__(256) void k_materialise(DTracks t, const int32_t *_
             gmax = v > gmax ? v : gmax;
         }
         gmax = __shfl(gmax, 0, 64);
-        if ((kw << kChunkLog2) < gmax && slot < t.n) { tA = t.A[u]; tB = t.B[u]; tC = t.C[u]; tW = out.delta_s[t.azim[u] - 1]; }
+        if ((kw << kChunkLog2) < gmax && have) { tA = t.A[u]; tB = t.B[u]; tC = t.C[u]; tW = out.delta_s[t.azim[u] - 1]; }
+        // (a unit's tracks are mostly, not always, consecutive uids: the march order packs a batch's last, partial wave of uids
+        //  between full ones, and the waves behind it straddle two of them — positions are absolute)
         const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
         const int lane_q = 16 * q + tl;
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double acc = 0.0;  // Σℓ of this lane's rows of its load-mapping track
         for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
-            const int r0 = j << kChunkLog2;
             const int32_t c = ctab[j];
-            int32_t ve[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ve[i] = __builtin_nontemporal_load(&stg.element[stage_slot(c, i * 4 + rr, lane_q)]);
-            // lanes 0..15: the row before this chunk's first, of their own track (only when the track reaches this chunk)
-            int32_t hw = 0;
-            const bool hrow = j > 0 && lane < 16 && cnt > r0;
-            if (hrow) hw = stg.element[stage_slot(ctab[j - 1], kChunkRows - 1, lane_q)];
-            double vx[8], vy[8];
+            // lanes 0..15 also hold the entry point of the pass's first row: the exit point of the row before or, for a record
+            // that keeps its own end points, the side list's p
+            double hx = 0.0, hy = 0.0;
             {
-                double eA[8], eB[8], eC[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool coded = r0 + i * 4 + rr < cnt && ve[i] > 0;
-                    const RT_G EdgeABC *e = a.etab + (coded ? ve[i] - 1 : 0);
-                    eA[i] = e->A; eB[i] = e->B; eC[i] = e->C;
-                }
-                double hA = 0, hB = 0, hC = 0;
-                if (lane < 16) { const RT_G EdgeABC *e = a.etab + (hrow && hw > 0 ? hw - 1 : 0); hA = e->A; hB = e->B; hC = e->C; }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    edge_exit_point(tA, tB, tC, eA[i], eB[i], eC[i], vx[i], vy[i]);
-                    if (__builtin_expect(r0 + i * 4 + rr < cnt && ve[i] < 0, 0)) {  // a record of the generic step: its own q
-                        vx[i] = stg.s_qx[-ve[i] - 1]; vy[i] = stg.s_qy[-ve[i] - 1];
-                    }
-                }
-                double hx = 0.0, hy = 0.0;
-                if (hrow) {
+                int32_t hw = 0;
+                const bool hrow = j > 0 && lane < 16 && cnt > (j << kChunkLog2);
+                if (hrow) hw = stg.element[stage_slot(ctab[j - 1], kChunkRows - 1, lane_q)];
+                if (j > 0) {  // (uniform; a track's first chunk starts with a record of the generic step)
+                    const RT_G EdgeABC *he = a.etab + (hw > 0 ? hw - 1 : 0);
+                    const double hA = he->A, hB = he->B, hC = he->C;
                     edge_exit_point(tA, tB, tC, hA, hB, hC, hx, hy);
                     if (__builtin_expect(hw < 0, 0)) { hx = stg.s_qx[-hw - 1]; hy = stg.s_qy[-hw - 1]; }
                 }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rl = i * 4 + rr;
-                    tx[tl * kC3Pitch + 1 + rl] = vx[i];
-                    ty[tl * kC3Pitch + 1 + rl] = vy[i];
-                }
-                if (lane < 16) { tx[tl * kC3Pitch] = hx; ty[tl * kC3Pitch] = hy; }
             }
-            __builtin_amdgcn_wave_barrier();
-            // Pass 1 gathers the records (and fetches the side list's p of marked rows) into registers, pass 2 only
-            // stores: a load between the stores would have to wait for every store queued before it.
-            double rpx[8], rpy[8], rqx[8], rqy[8];
-            int32_t re[8];
-            int64_t ro[8];
-            bool rv[8];
-            double rwt[8];  // fill_volumes' weight of the track, δs[azim]
+#pragma nounroll
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = (j << kChunkLog2) + 16 * h;  // first row of the pass
+                if (r0 >= gmax) break;  // (uniform)
+                // ---- the pass's words, in the load mapping (lane = track tl, rows 4 i + rr of the pass)
+                int32_t ve[4];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int tt = 2 * g + sub;
-                const int32_t ct = __shfl(cnt, tt, 64);
-                const int64_t ot = __shfl(off, tt, 64);
-                rwt[g] = __shfl(tW, tt, 64);  // (shuffles in uniform control flow only: an inactive lane supplies nothing)
-                const int row = r0 + rowL;
-                rv[g] = row < ct;
-                ro[g] = (row < ct && ot + row < out.cap) ? ot + row : -1;
-                rqx[g] = tx[tt * kC3Pitch + 1 + rowL]; rqy[g] = ty[tt * kC3Pitch + 1 + rowL];
-                rpx[g] = tx[tt * kC3Pitch + rowL]; rpy[g] = ty[tt * kC3Pitch + rowL];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) te[tl * kC3Pitch + 1 + i * 4 + rr] = ve[i];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int tt = 2 * g + sub;
-                re[g] = te[tt * kC3Pitch + 1 + rowL];
-                if (__builtin_expect(rv[g] && re[g] < 0, 0)) {  // this record keeps its own entry point (and names its cell)
-                    const int32_t idx = -re[g] - 1;
-                    rpx[g] = stg.s_px[idx]; rpy[g] = stg.s_py[idx];
-                    re[g] = 3 * (stg.s_el[idx] - 1) + 1;  // (as a word: cell = (word - 1) / 3)
+                for (int i = 0; i < 4; ++i) {
+                    ve[i] = __builtin_nontemporal_load(&stg.element[stage_slot(c, 16 * h + 4 * i + rr, lane_q)]);
+                    if (!(r0 + 4 * i + rr < cnt)) ve[i] = 0;  // beyond the track's end: no record
                 }
-            }
-            double rl_[8];
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const double ell = norm2(rpx[g] - rqx[g], rpy[g] - rqy[g]);  // Segment ctor, src/segment.jl:31-33
-                rl_[g] = ell;
-                const int32_t el = (int32_t)((uint32_t)(re[g] > 0 ? re[g] - 1 : 0) / 3u) + 1;
-                re[g] = el;
-                if (RECORDS && ro[g] >= 0) {
-                    const int64_t o = ro[g];
-                    // plain stores: the partial lines at the ends of a run wait in L2 for the sibling wave's half
-                    out.px[o] = rpx[g];
-                    out.py[o] = rpy[g];
-                    out.qx[o] = rqx[g];
-                    out.qy[o] = rqy[g];
-                    out.ell[o] = ell;
-                    out.element[o] = el;
+                bool slow = false;  // a marked record that is not its pass's first row: its entry point is fetched where it is needed
+                if (lane < 16 && ve[0] < 0) {  // the pass's first row keeps its own entry point (every track's first record: chunk 0)
+                    const int32_t idx = -ve[0] - 1;
+                    hx = stg.s_px[idx]; hy = stg.s_py[idx];
                 }
-                if (tally && rv[g]) {
-                    atomicAdd(&hist[el - 1], rwt[g] * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
-                    acc[g] += ell;
-                }
-            }
-            if (ROWS) {
-                // (ℓ, cell) back in the load mapping: a staging row of the wave's quarter is one 128-B / 64-B piece per array
-                __builtin_amdgcn_wave_barrier();
+                // ---- exit points
+                {
+                    double eA[4], eB[4], eC[4];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int tt = 2 * g + sub;
-                    ty[tt * kC3Pitch + 1 + rowL] = rl_[g];
-                    te[tt * kC3Pitch + 1 + rowL] = re[g];
-                }
-                __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < 4; ++i) {
+                        const RT_G EdgeABC *e = a.etab + (ve[i] > 0 ? ve[i] - 1 : 0);
+                        eA[i] = e->A; eB[i] = e->B; eC[i] = e->C;
+                    }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rl = i * 4 + rr;
-                    if (r0 + rl < cnt) {
-                        const int64_t sidx = stage_slot(c, rl, lane_q);
-                        a.ell_rows[sidx] = ty[tl * kC3Pitch + 1 + rl];
-                        a.cell_rows[sidx] = te[tl * kC3Pitch + 1 + rl];
+                    for (int i = 0; i < 4; ++i) {
+                        double qx, qy;
+                        edge_exit_point(tA, tB, tC, eA[i], eB[i], eC[i], qx, qy);  // src/intersection.jl:127-138
+                        if (__builtin_expect(ve[i] < 0, 0)) {  // a record of the generic step: its own q (and cell)
+                            const int32_t idx = -ve[i] - 1;
+                            qx = stg.s_qx[idx]; qy = stg.s_qy[idx];
+                            if (i == 0 && rr == 0) ve[i] = 3 * (stg.s_el[idx] - 1) + 1;  // (its p sits in slot 0: from here on an ordinary word)
+                            else slow = true;
+                        }
+                        X[tb + 1 + 4 * i + rr] = qx;
+                        Y[tb + 1 + 4 * i + rr] = qy;
                     }
                 }
+                if (lane < 16) { X[tb] = hx; Y[tb] = hy; }
+                const bool any_slow = __ballot(slow) != 0;
+                __builtin_amdgcn_wave_barrier();
+                // ---- ℓ = ‖p − q‖ (Segment ctor, src/segment.jl:31-33) in the load mapping; p, q to the output in the store mapping
+                double dl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rl = 4 * i + rr;
+                    double px = X[tb + rl], py = Y[tb + rl];
+                    const double qx = X[tb + rl + 1], qy = Y[tb + rl + 1];
+                    if (__builtin_expect(any_slow, 0))
+                        if (ve[i] < 0) { px = stg.s_px[-ve[i] - 1]; py = stg.s_py[-ve[i] - 1]; }
+                    dl[i] = norm2(px - qx, py - qy);
+                    acc += ve[i] != 0 ? dl[i] : 0.0;
+                }
+                if (lane < 16) { hx = X[tb + kMatRows]; hy = Y[tb + kMatRows]; }  // the next pass's "row before"
+                // positions in the unit's span, store mapping: >= 0 store there; -1 beyond the arrays' capacity (the host compacts
+                // again); -2 no record
+                int64_t ro[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int tt = 4 * g + sub;
+                    const int32_t ct = __shfl(cnt, tt, 64);  // (shuffles in uniform control flow only: an inactive lane supplies nothing)
+                    const int64_t ot = __shfl(off, tt, 64);
+                    const int row = r0 + rowL;
+                    ro[g] = row < ct ? (ot + row < out.cap ? ot + row : -1) : -2;
+                }
+                if (RECORDS) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int sb = (4 * g + sub) * kMatPitch + rowL;
+                        const double px = X[sb], qx = X[sb + 1], py = Y[sb], qy = Y[sb + 1];
+                        if (ro[g] >= 0) { out.px[ro[g]] = px; out.py[ro[g]] = py; out.qx[ro[g]] = qx; out.qy[ro[g]] = qy; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- lengths and cells through the tiles; fill_volumes in the store mapping (its 16 rows of a track are 16 cells:
+                //      no two lanes of a quarter add to one address, as the 16 neighbouring tracks of a row would)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int32_t wd = ve[i];
+                    if (__builtin_expect(any_slow, 0))
+                        if (wd < 0) wd = 3 * (stg.s_el[-wd - 1] - 1) + 1;
+                    const int32_t cell = (int32_t)((uint32_t)(wd > 0 ? wd - 1 : 0) / 3u) + 1;
+                    X[tb + 1 + 4 * i + rr] = dl[i];
+                    Yi[tb + 1 + 4 * i + rr] = cell;
+                    if (ROWS && wd != 0) {
+                        const int64_t sidx = stage_slot(c, 16 * h + 4 * i + rr, lane_q);
+                        a.ell_rows[sidx] = dl[i];
+                        a.cell_rows[sidx] = cell;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int sb = (4 * g + sub) * kMatPitch + 1 + rowL;
+                    const double ell = X[sb];
+                    const int32_t el = Yi[sb];
+                    const double wt = __shfl(tW, 4 * g + sub, 64);
+                    if (RECORDS && ro[g] >= 0) { out.ell[ro[g]] = ell; out.element[ro[g]] = el; }
+                    if (tally && ro[g] >= -1) atomicAdd(&hist[el - 1], wt * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
+                }
+                if (RECORDS && __builtin_expect(any_slow, 0)) {
+                    // the entry points of marked records that are not their pass's first row, straight from the load mapping
+                    // (stores to the same addresses as above, later in program order: these stay)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ve[i] < 0 && off + r0 + 4 * i + rr < out.cap) {
+                            const int32_t idx = -ve[i] - 1;
+                            out.px[off + r0 + 4 * i + rr] = stg.s_px[idx];
+                            out.py[off + r0 + 4 * i + rr] = stg.s_py[idx];
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();  // the tiles are rewritten by the next pass
             }
-            __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
         }
         if (tally) {
-            // Σℓ of the 16 tracks over this wave's rows, reduced over the 32 lanes of a half; the four waves' parts meet in LDS
-            if ((kw << kChunkLog2) < gmax) {
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    double v = acc[g];
-                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    if (rowL == 0 && v != 0.0) atomicAdd(&s_sum[2 * g + sub], v);
-                }
-            }
+            // Σℓ of the 16 tracks over this wave's rows: the four lanes of a track, then the four waves' parts in LDS
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < 16 && acc != 0.0) atomicAdd(&s_sum[team][lane], acc);
             __syncthreads();
             if (kw == 0 && lane < 16) {
-                const double S = s_sum[lane];
-                s_sum[lane] = 0.0;
-                if (slot < t.n) {
+                const double S = s_sum[team][lane];
+                s_sum[team][lane] = 0.0;
+                if (have) {
                     const double L = t.ell[u];
                     // any-order sum against the left-to-right one: within cnt·2⁻⁵³·Σ; 96 bands hold the statistic's 64 (k_finish)
                     if (a.force_exact || sum_check_is_marginal(L, S, a.rtol, cnt, 96.0)) {
@@ -1570,7 +1595,7 @@ __global__ __launch_bounds__(256) void k_materialise(DTracks t, const int32_t *_
     // adding thousands of values each with global atomics at the same moment took 60 µs, and the sum depended on their order)
     if (tally) {
         __syncthreads();
-        for (int c = threadIdx.x; c < a.n_cells; c += 256) a.slabs[(int64_t)blockIdx.x * a.n_cells + c] = hist[c];
+        for (int c = threadIdx.x; c < a.n_cells; c += 256 * TEAMS) a.slabs[(int64_t)blockIdx.x * a.n_cells + c] = hist[c];
     }
 }
 
@@ -2220,6 +2245,7 @@ struct rt_mesh {
     int test_exact_sums = 0;        // tests only: every track's Σℓ check by k_finish's left-to-right sum (two-phase march)
     int64_t side_entries_hint = 0;  // tests only: capacity of the dynamic part of the side list on a handle's first call (forces its overflow path)
     int mat_wgs = 0;                // k_materialise: workgroups per CU (0: as many as fit)
+    int mat_teams = 0;              // ... teams of four waves per workgroup (0: automatic; 1, 2, 4)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
@@ -2496,11 +2522,27 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
     a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.n_cells = m->n_cells; a.tally = tally ? 1 : 0;
     a.force_exact = m->test_exact_sums; a.ctl = d_ctl;
     const size_t hist = tally ? (size_t)m->n_cells * sizeof(double) : 0;
-    const size_t stat = 2 * 4 * 16 * rt::kC3Pitch * sizeof(double) + 256;  // the kernel's own tiles
-    int per_cu = (int)std::min<size_t>(4, (size_t)(158 * 1024) / (stat + hist));
+    // Shape: teams of four waves (one unit each) per workgroup, sharing the workgroup's LDS copy of `volumes`; as many waves per CU
+    // as LDS allows, up to 16 (the kernel's registers allow four per SIMD), with the fewest teams that get there.
+    int teams = 1, per_cu = 0;
+    {
+        int best_waves = 0;
+        const int max_teams_cu = RT_MAT_OCC;  // (teams of four waves per CU the registers allow)
+        for (int tm : {1, 2, 3, 4}) {
+            if (tm > max_teams_cu) break;
+            const size_t stat = (size_t)tm * 4 * 2 * 16 * rt::kMatPitch * sizeof(double) + 512;  // the kernel's own tiles
+            const int pc = (int)std::min<size_t>((size_t)(max_teams_cu / tm), (size_t)(158 * 1024) / (stat + hist));
+            if (pc * tm * 4 > best_waves) { best_waves = pc * tm * 4; teams = tm; per_cu = pc; }
+        }
+        if (m->mat_teams >= 1 && m->mat_teams <= max_teams_cu) {  // (experiments)
+            teams = m->mat_teams;
+            const size_t stat = (size_t)teams * 4 * 2 * 16 * rt::kMatPitch * sizeof(double) + 512;
+            per_cu = (int)std::min<size_t>((size_t)(max_teams_cu / teams), (size_t)(158 * 1024) / (stat + hist));
+        }
+    }
     if (m->mat_wgs > 0) per_cu = std::min(per_cu, m->mat_wgs);
     if (per_cu < 1) { set_error("k_materialise: an LDS copy of volumes (%zu B) does not fit", hist); return RT_ERR_INVALID; }
-    const unsigned blocks = (unsigned)std::min<int64_t>(a.n_units, (int64_t)m->n_cus * per_cu);
+    const unsigned blocks = (unsigned)std::min<int64_t>((a.n_units + teams - 1) / teams, (int64_t)m->n_cus * per_cu);
     if (tally) {
         RT_HIP(t->slabs.reserve((size_t)blocks * m->n_cells));
         RT_HIP(t->marg.reserve((size_t)c.n_whole_waves * 64 + 1));
@@ -2513,19 +2555,25 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
         RT_HIP(t->sw_ell.reserve(slots > 0 ? slots : 1)); RT_HIP(t->sw_cell.reserve(slots > 0 ? slots : 1));
         a.ell_rows = as_global(t->sw_ell.p); a.cell_rows = as_global(t->sw_cell.p);
     }
-    auto go = [&]<bool RECORDS, bool ROWS>() -> int {
+    auto go = [&]<bool RECORDS, bool ROWS, int TEAMS>() -> int {
         static size_t attr_set = 0;  // (per instantiation; raised only: hipFuncSetAttribute costs host time)
         if (hist > attr_set) {
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_materialise<RECORDS, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist));
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_materialise<RECORDS, ROWS, TEAMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist));
             attr_set = hist;
         }
-        hipLaunchKernelGGL((rt::k_materialise<RECORDS, ROWS>), dim3(blocks), dim3(256), hist, s, c.d_whole, (const int32_t *)t->counts.p,
-                           t->status.p, (const int64_t *)t->offsets.p, c.stg, out, a);
+        hipLaunchKernelGGL((rt::k_materialise<RECORDS, ROWS, TEAMS>), dim3(blocks), dim3(256 * TEAMS), hist, s, c.d_whole,
+                           (const int32_t *)t->counts.p, t->status.p, (const int64_t *)t->offsets.p, c.stg, out, a);
         return RT_SUCCESS;
     };
-    if (records && rows) return go.template operator()<true, true>();
-    if (records) return go.template operator()<true, false>();
-    if (rows) return go.template operator()<false, true>();
+    auto shape = [&]<bool RECORDS, bool ROWS>() -> int {
+        if (teams == 4) return go.template operator()<RECORDS, ROWS, 4>();
+        if (teams == 3) return go.template operator()<RECORDS, ROWS, 3>();
+        if (teams == 2) return go.template operator()<RECORDS, ROWS, 2>();
+        return go.template operator()<RECORDS, ROWS, 1>();
+    };
+    if (records && rows) return shape.template operator()<true, true>();
+    if (records) return shape.template operator()<true, false>();
+    if (rows) return shape.template operator()<false, true>();
     set_error("k_materialise: nothing to write");
     return RT_ERR_INVALID;
 }
@@ -2785,6 +2833,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "test_exact_sums")) { mesh->test_exact_sums = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "side_entries_hint")) { mesh->side_entries_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "mat_wgs")) { mesh->mat_wgs = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "mat_teams")) { mesh->mat_teams = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
         mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
