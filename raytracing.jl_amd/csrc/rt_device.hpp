@@ -129,6 +129,8 @@ struct DParams {
     double topo_tiny_max, topo_rmax, topo_end_err;  // cheap steps (topo_track); unused elsewhere
     int32_t topo_force;  // 1: option "topo" = 2 — a wave that is refused often does NOT hand back to exact steps
     int32_t pad_;
+    double tally_tau;    // cheap records whose exit edge's end points are closer than this across the track line are tallied
+                         // (fill_volumes) by k_materialise from the record's exact length (rt_mesh_prep.hpp); ∞: all of them
 };
 
 // ---------------------------------------------------------------- Base.isapprox ----------

@@ -115,6 +115,8 @@ struct Prep {
     double topo_tiny_max = 0.0;     // the cheap step's certificates hold for tiny_step <= this
     double topo_rmax = 0.0;         // order guard: a track needs |s_v| >= lc * max(1, topo_rmax / |cos ϕ|)
     double topo_end_err = 0.0;      // |computed exit coordinate - border| bound on border edges
+    double tally_tau = INFINITY;    // fill_volumes of cheap records from the vertices' distances (k_march): exact enough where the exit
+                                    // edge's end points lie at least this far apart across the track line (see prepare)
     int64_t n_records_topo = 0;
     // node grid
     int gnx = 1, gny = 1;
@@ -339,6 +341,29 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         if (R.cls == 2) { ++P.n_cells_wild; wild.push_back(c); }
     }
     P.kappa = area > 0 ? perim / (3.141592653589793 * area) : 0.0;
+    {
+        // fill_volumes (src/trackgenerator.jl:376-386) sums δs·ℓ per cell and is compared at 1e-10, not bit for bit.  For a cheap
+        // record the march adds the chord between the two edge crossings, each interpolated from the signed distances s and the
+        // positions t along the line of the edge's end points: t = (s_p·t_q − s_q·t_p)/(s_p − s_q).  With R the largest
+        // coordinate norm, the inputs carry |δs| <= 3uR, |δt| <= 2uR, the expression 3uR, and ∂t/∂s <= l_max/D_x (D_x = |s_p −
+        // s_q|, the end points' distance across the line): a chord differs from the record's ‖p − q‖ by at most
+        // 2uR·(7 + 6·l_max/D_x) — the reference's own points carry the same kind of error.  Relative to a cell's volume the sum
+        // of such differences is at most that over the cell's mean chord, π·area/perimeter (Cauchy).  Budget: 2e-11 for the
+        // part that does not depend on the crossing (16uR / smallest mean chord — a mesh that exceeds it gets tally_tau = ∞:
+        // every cheap record is then tallied exactly, by k_materialise), 2e-11 for shallow crossings: records with D_x below
+        // tally_tau are tallied exactly as well.
+        double chord_min = INFINITY;
+        for (int32_t c = 0; c < n_cells; ++c) {
+            const CellRecHost &R = P.rec[c];
+            if (R.cls != 0) continue;  // (cheap records neither enter nor leave fragile / degenerate cells)
+            double per = 0;
+            for (int k = 0; k < 3; ++k) per += std::hypot(R.vx[k] - R.vx[(k + 1) % 3], R.vy[k] - R.vy[(k + 1) % 3]);
+            if (per > 0) chord_min = std::min(chord_min, 3.141592653589793 * 0.5 * R.area2 / per);
+        }
+        const double Rfar = std::hypot(cmax_x, cmax_y);
+        const double floor_rel = chord_min > 0 && std::isfinite(chord_min) ? 16.0 * kUlp * Rfar / chord_min : INFINITY;
+        P.tally_tau = floor_rel <= 2e-11 ? 16.0 * kUlp * Rfar * l_max / (2e-11 * chord_min) : INFINITY;
+    }
     if (wild.size() > 4096) { P.walk_ok = false; P.note = "too many degenerate cells for the walk certificates"; }
     {
         // The track line must clear every vertex of the cell by d_vertex.  What depends on it:

@@ -113,6 +113,7 @@ constexpr int kChunkLog2 = RT_CHUNK_LOG2;
 constexpr int kChunkRows = 1 << kChunkLog2;
 constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
 
+constexpr int32_t kWordExactTally = 1 << 30;  // staged word of a cheap record whose fill_volumes term k_materialise adds (see DStage)
 struct DStage {
     RT_G double *qx, *qy;   // exit point of every record
     RT_G double *px, *py;   // entry point, only for records whose element is staged negative (see k_march)
@@ -124,7 +125,9 @@ struct DStage {
     int32_t static0;        // 1: chunk w is reserved as the first chunk of march wave w (whole-track march; cursor starts at n_waves)
     // k_march<TOPO> stages ONE word per record in `element`: 3·cell + exit edge + 1 (the record is a function of the track's
     // line, that edge and the previous record: k_materialise computes it), or -(index + 1) of an entry of the side list below
-    // for a record that keeps its own end points (the generic step's: every track's first one, refusals).  Entries
+    // for a record that keeps its own end points (the generic step's: every track's first one, refusals).  Bit 30 of a positive
+    // word: the march has NOT added the record to fill_volumes (a shallow crossing: its chord from the vertices' distances
+    // would be too inexact) — k_materialise adds δs·ℓ from the record's own length.  Entries
     // [0, side_static) are reserved — entry `march slot` for the track's first record —, the rest is handed out from
     // cursor[2]; cursor[3] flags an overflow (the host grows the list and re-runs, as for the pool).
     RT_G double *s_px, *s_py, *s_qx, *s_qy;
@@ -479,8 +482,10 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     const RT_K DSplit *spk = (const RT_K DSplit *)((const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MarchArgsLayout, sp));
     (void)sp; (void)fst;
     static_assert(!TOPO || (MODE == kStage && !SPLIT && !LDSREC), "cheap steps: staged whole tracks only");
-    // TOPO: the march only DECIDES (codes); exit points, lengths, Σℓ and fill_volumes are k_materialise's — no LDS copy of `volumes` here
-    constexpr bool FUSE = WAVES > 1 && !TOPO;
+    // (TOPO: the march DECIDES and stages codes; exit points, lengths and Σℓ are k_materialise's.  fill_volumes stays here, in the
+    //  LDS-private copy: its sum is compared at 1e-10, not bit for bit, so a cheap record's length comes from the vertices'
+    //  signed distances and positions along the line — one reciprocal — instead of the record's two divisions and square root.)
+    constexpr bool FUSE = WAVES > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char march_smem[];
     double *hist = reinterpret_cast<double *>(march_smem);  // [n_cells] when FUSE
     const int lane = threadIdx.x & 63;
@@ -584,6 +589,19 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     // has no cheap lane left (an uncertified last step, a finished track); kFlDone / kFlRestart: see below
     constexpr uint32_t kFlCheap = 1, kFlUsed = 2, kFlMat = 4, kFlWait = 8, kFlDone = 16, kFlRestart = 32;
     uint32_t fl = 0;
+    // positions along the track line, t(x, y) = B·x − A·y ((B, −A) is the line's direction; general_form normalises the whole
+    // (A, B, C), src/intersection.jl:11-18, so t is scaled by ‖(A, B)‖), of the end points of the lane's entry edge (as ts.sa /
+    // ts.sb) and of its last exit point: the chord a cheap record adds to fill_volumes is |Δt| / ‖(A, B)‖ — the scale rides in wq
+    double tta = 0.0, ttb = 0.0, ttp = 0.0;
+    const double nab = (TOPO && FUSE) ? sqrt(tA * tA + tB * tB) : 1.0;
+    const double wq = (TOPO && FUSE) ? w / nab : 0.0;
+    const double tau_s = (TOPO && FUSE) ? prm.tally_tau * nab : 0.0;  // (s is scaled by ‖(A, B)‖ as t is)
+    bool pin = false;  // the lane's last exit point came from a shallow crossing: the next chord starts there
+    auto topo_tally_enter = [&]() {
+        tta = __builtin_fma(tB, wk.ax, -(tA * wk.ay)); ttb = __builtin_fma(tB, wk.bx, -(tA * wk.by));
+        ttp = __builtin_fma(tB, lqx, -(tA * lqy));
+        pin = false;  // (an exact step's exit point)
+    };
     int32_t n_cheap_it = 0, n_cheap_ref = 0;  // wave-uniform: cheap iterations of this wave, and those in which a lane was refused
     int32_t last_word = 0;  // staging word of the lane's last record
     // (the cheap loop stores without a branch: should the pool run out before a lane's first chunk — the attempt is void
@@ -727,6 +745,26 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     ++n_cheap_it;
                     n_cheap_ref += __ballot(cheap && !ok) != 0 ? 1 : 0;
                     const bool commit = cheap && ok && !over;
+                    bool inexact = false;
+                    if (FUSE) {
+                        // fill_volumes (src/trackgenerator.jl:382) for this record: the line meets the exit edge (p, q) — end points on
+                        // opposite sides, |s_p − s_q| >= the record's k2 — at t = (s_p·t_q − s_q·t_p) / (s_p − s_q)
+                        const bool same = rec_same(c_hdr);
+                        const double t0 = same ? tta : ttb, t1 = same ? ttb : tta;
+                        const double t2 = __builtin_fma(tB, c_x2, -(tA * c_y2));
+                        const double sp = g.exit1 ? g.s1 : g.s2, sq = g.exit1 ? g.s2 : g.s0;
+                        const double tp = g.exit1 ? t1 : t2, tq = g.exit1 ? t2 : t0;
+                        const double den = sp - sq;
+                        double rc = __builtin_amdgcn_rcp(den);
+                        rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+                        rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+                        const double tx = (sp * tq - sq * tp) * rc;
+                        // (a chord one of whose ends is a shallow crossing is left to k_materialise: rt_mesh_prep.hpp, tally_tau)
+                        const bool shallow = !(fabs(den) >= tau_s);
+                        inexact = pin || shallow;
+                        atomicAdd(&hist[g.cell], (commit && !inexact) ? wq * fabs(tx - ttp) : 0.0);  // (LDS-private; a lane that decided nothing adds 0)
+                        if (commit) { ttp = tx; tta = tp; ttb = tq; pin = shallow; }
+                    }
                     if (commit) {
                         ++i;
                         it += kub;
@@ -754,7 +792,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                         // (pool exhausted: the attempt is void and the host re-runs it; the row pointer stays inside the pool)
                         if (my_chunk >= 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane);
                     }
-                    last_word = commit ? g.code + 1 : last_word;
+                    last_word = commit ? (g.code + 1) | (inexact ? kWordExactTally : 0) : last_word;
                     row_el[rw * 16] = last_word;
                     c_hdr = n_hdr; c_x2 = n_x2; c_y2 = n_y2; c_c01 = n_c01; c_c23 = n_c23;
                 }
@@ -776,7 +814,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             if (__builtin_expect((fl & kFlRestart) || ((fl & kFlUsed) && it >= cap), 0)) {
                 // the bound reached the iteration cap: this track is marched again from its start with exact steps only
                 asm volatile("" ::: "memory");
-                atomicAdd(march_ctl() + kCtlRestarts, 1ull);  // (statistic; the rows are simply staged again from row 0)
+                // its records have already been added to the fused volumes: the host recomputes them from the records
+                atomicAdd(march_ctl() + kCtlRestarts, 1ull);
                 tt.on = false; fl = 0; n_generic = 0;
                 i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
                 xpx = t.px[u] + sx; xpy = t.py[u] + sy;
@@ -992,7 +1031,10 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         xpx = qx + sx; xpy = qy + sy;  // :165
         prev_element = element;        // :166
         ++i;                           // :168
-        if (TOPO) fl = (fl & kFlUsed) | (topo_enter(mh, tt, wk, tA, tB, tC, ts) ? kFlCheap : 0u);
+        if (TOPO) {
+            fl = (fl & kFlUsed) | (topo_enter(mh, tt, wk, tA, tB, tC, ts) ? kFlCheap : 0u);
+            if (FUSE && (fl & kFlCheap)) topo_tally_enter();
+        }
     }
     // ---- cooperative creep: every lane of the wave is out of the march loop here
     unsigned long long need = __ballot(creep_escalate);
@@ -1340,20 +1382,20 @@ __global__ __launch_bounds__(256) void k_compact4(DTracks t, const int32_t *__re
 // ---- codes -> records (the parallel half of the two-phase march) -----------------------------------------------------
 // k_march<..., TOPO> decides; this kernel computes.  Per record the march left one word (DStage): 3·cell + exit edge + 1, or
 // -(index + 1) of a side-list entry that holds the end points of a record of the generic step.  From the words, with
-// k_compact3's data movement (a unit = 16 consecutive tracks of a march wave, handled by four waves: wave k takes the 32-row
-// chunks k, k + 4, ...; transposing LDS tiles; every track's 32 rows stored as one run per array; loads before stores):
+// k_compact3's data movement and shape (one 4-wave workgroup per unit = 16 tracks of a march wave, wave k takes the 32-row
+// chunks k, k + 4, ...; transposing LDS tiles; every track's 32 rows stored as one run per array; every global load of a chunk
+// before its first store — gfx950 retires both through one in-order counter, and the workgroups that follow hide the rest):
 //   q = intersection(track.ABC, general_form of the exit edge)   src/intersection.jl:127-138 (edge_exit_point: walk_step's
 //       expression; `etab` holds the host's general forms, evaluated with the reference's operations — bit-identical),
 //   p = the previous record's q (bit-identical to the reference's own intersection with the shared edge: negating an edge's
 //       general form negates numerator and denominator alike), or the side list's p,
 //   ℓ = ‖p − q‖                                                  Segment ctor, src/segment.jl:31-33,
-//   fill_volumes: volumes[cell] += δs[azim]·ℓ                    src/trackgenerator.jl:376-386 — ds_add_f64 into an LDS-private
-//       copy per workgroup (persistent workgroups), left as the workgroup's share in `slabs`; k_finish adds the shares in
-//       workgroup order (deterministic) and applies ./= n_azim_2,
 //   Σℓ per track and isapprox(track.ℓ, Σℓ; rtol)                 src/track.jl:171-175.  The partial sums of a track's chunks are
 //       added in the order its waves finish, so the check is decided by MARGIN (any summation order is within n·2⁻⁵³·Σ of the
-//       left-to-right sum the reference's check and the oracle use); a track inside 96 such bands of the threshold is listed
+//       left-to-right sum of the reference's check); a track inside 96 such bands of the threshold is listed
 //       and k_finish sums its ℓ again left to right.
+// (fill_volumes stays with the march: a persistent variant of this kernel with an LDS copy of `volumes` per workgroup was built
+//  and measured at twice the compaction's time — a wave's loads queue behind its own stores, chunk after chunk — DESIGN.md §4.)
 // The gathers of the exit edges run in the LOAD mapping (the 16 lanes of a row are neighbouring tracks, which mostly cross the
 // same edge: they share cache lines; in the store mapping every lane would fetch a line of its own).
 // RECORDS: write the 44-B records.  ROWS: leave (ℓ, cell) of every staged row, slot-indexed like the rows, for rt_sweep.
@@ -1362,306 +1404,271 @@ struct DMat {
     const RT_G int32_t *corder;   // large batches: march waves in the order of their output addresses (as k_compact3)
     int64_t n_units;              // 4 per march wave
     double rtol;
-    int32_t n_cells;
-    int32_t tally;                // 1: Σℓ + status + fill_volumes (the call's first pass over the codes); 0: records / rows only
+    int32_t tally;                // 1: Σℓ + status (the call's first pass over the codes); 0: records / rows only
     int32_t force_exact;          // tests: every track takes k_finish's left-to-right sum
     int32_t marg_cap;
-    RT_G double *slabs;           // [gridDim][n_cells]
     RT_G int32_t *marg;           // [0] count, [1 ...] march slots of the tracks k_finish has to sum exactly
     RT_G double *ell_rows;        // ROWS
     RT_G int32_t *cell_rows;
+    RT_G double *vacc;            // fill_volumes' accumulator: the terms of the records the march flagged (kWordExactTally) are added here
     unsigned long long *ctl;      // the call's control block ([0] failed tracks, [1] first failing uid + 1)
 };
 
-// Shape: a workgroup = TEAMS teams of four waves sharing ONE LDS copy of `volumes`; a team takes a unit (wave k its chunks k,
-// k + 4, ...).  A wave works through a chunk in two passes of 16 rows, with two 2.5-KB LDS tiles of its own: the pass's exit
-// points (x, y; slot 0 of a track: the row before, i.e. the first row's entry point) go in in the load mapping and come out
-// in the store mapping, then the lengths and the cells take the same way — so only a few values per lane are live at a time
-// (the first version held a chunk's records in registers: 243 VGPRs, one or two waves per SIMD, twice the compaction's time).
-constexpr int kMatRows = 16;            // rows per pass
-constexpr int kMatPitch = kMatRows + 4; // doubles per track in a tile: slot 0 = the row before, slots 1..16 = the pass's rows
 #ifndef RT_MAT_OCC
-#define RT_MAT_OCC 4  // waves per SIMD the kernel is compiled for
+#define RT_MAT_OCC 3  // waves per SIMD the kernel is compiled for
 #endif
-template <bool RECORDS, bool ROWS, int TEAMS>
-__global__ __launch_bounds__(256 * TEAMS, RT_MAT_OCC) void k_materialise(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
-                                                             const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
+template <bool RECORDS, bool ROWS>
+__global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
+                                                     const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
     static_assert(kChunkRows == 32, "k_materialise moves 32-row chunks");
-    __shared__ double tiles_x[4 * TEAMS][16 * kMatPitch];
-    __shared__ double tiles_y[4 * TEAMS][16 * kMatPitch];
-    __shared__ double s_sum[TEAMS][16];  // Σℓ of the units' tracks
-    extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
-    double *hist = reinterpret_cast<double *>(mat_smem);  // [n_cells] when a.tally
+    __shared__ double tiles_x[4][16 * kC3Pitch];  // per wave: the chunk's exit points (slot 0 of a track: the row before, i.e. the
+    __shared__ double tiles_y[4][16 * kC3Pitch];  // first row's entry point), then its lengths (x tile) and cells (y tile)
+    __shared__ double s_sum[16];                  // Σℓ of the unit's tracks
+    __shared__ int64_t s_off[16];
+    __shared__ int32_t s_cnt[16];
     if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int team = wv >> 2, kw = wv & 3;
-    const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr + 4, rr + 8, rr + 12 of the pass
-    const int rowL = lane & 15, sub = lane >> 4;  // store mapping: row rowL of tracks sub, sub + 4, sub + 8, sub + 12
+    const int kw = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr + 4, ...
+    const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub + 2, ...
     typedef __attribute__((address_space(3))) volatile double lds_f64;
     typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
-    lds_f64 *X = (lds_f64 *)tiles_x[wv], *Y = (lds_f64 *)tiles_y[wv];
-    lds_i32 *Yi = (lds_i32 *)tiles_y[wv];
-    const bool tally = a.tally != 0;
-    if (tally)
-        for (int c = threadIdx.x; c < a.n_cells; c += 256 * TEAMS) hist[c] = 0.0;
-    if (threadIdx.x < 16 * TEAMS) (&s_sum[0][0])[threadIdx.x] = 0.0;
-    const int64_t per_round = (int64_t)gridDim.x * TEAMS;
-    const int64_t n_rounds = (a.n_units + per_round - 1) / per_round;
-    const int tb = tl * kMatPitch;
-    for (int64_t round = 0; round < n_rounds; ++round) {
-        __syncthreads();  // (keeps the four waves of a unit together: they complete each other's partial cache lines; s_sum is zero)
-        const int64_t unit = (round * gridDim.x + blockIdx.x) * TEAMS + team;  // (the teams of a workgroup: quarters of one march wave)
-        const bool have_unit = unit < a.n_units;
-        const int64_t w = !have_unit ? 0 : (a.corder ? a.corder[unit >> 2] : (unit >> 2));
-        const int q = (int)(unit & 3);
-        const int64_t slot = w * 64 + 16 * q + tl;
-        // every lane holds its load-mapping track's uid, count, offset, line and weight (the 4 lanes of a track load the same words)
-        int32_t cnt = 0, u = 0;
-        int64_t off = 0;
-        double tA = 0.0, tB = 0.0, tC = 0.0, tW = 0.0;
-        const bool have = have_unit && slot < t.n;
-        if (have) {
-            u = t.perm[slot];
-            cnt = counts[u];
-            off = offsets[u];
-        }
-        int32_t gmax = cnt;
-        for (int o = 8; o > 0; o >>= 1) {
-            const int32_t v = __shfl_xor(gmax, o, 64);
-            gmax = v > gmax ? v : gmax;
-        }
-        gmax = __shfl(gmax, 0, 64);
-        if ((kw << kChunkLog2) < gmax && have) { tA = t.A[u]; tB = t.B[u]; tC = t.C[u]; tW = out.delta_s[t.azim[u] - 1]; }
-        // (a unit's tracks are mostly, not always, consecutive uids: the march order packs a batch's last, partial wave of uids
-        //  between full ones, and the waves behind it straddle two of them — positions are absolute)
-        const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
-        const int lane_q = 16 * q + tl;
-        double acc = 0.0;  // Σℓ of this lane's rows of its load-mapping track
-        for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
-            const int32_t c = ctab[j];
-            // lanes 0..15 also hold the entry point of the pass's first row: the exit point of the row before or, for a record
-            // that keeps its own end points, the side list's p
-            double hx = 0.0, hy = 0.0;
-            {
-                int32_t hw = 0;
-                const bool hrow = j > 0 && lane < 16 && cnt > (j << kChunkLog2);
-                if (hrow) hw = stg.element[stage_slot(ctab[j - 1], kChunkRows - 1, lane_q)];
-                if (j > 0) {  // (uniform; a track's first chunk starts with a record of the generic step)
-                    const RT_G EdgeABC *he = a.etab + (hw > 0 ? hw - 1 : 0);
-                    const double hA = he->A, hB = he->B, hC = he->C;
-                    edge_exit_point(tA, tB, tC, hA, hB, hC, hx, hy);
-                    if (__builtin_expect(hw < 0, 0)) { hx = stg.s_qx[-hw - 1]; hy = stg.s_qy[-hw - 1]; }
-                }
-            }
-#pragma nounroll
-            for (int h = 0; h < 2; ++h) {
-                const int r0 = (j << kChunkLog2) + 16 * h;  // first row of the pass
-                if (r0 >= gmax) break;  // (uniform)
-                // ---- the pass's words, in the load mapping (lane = track tl, rows 4 i + rr of the pass)
-                int32_t ve[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ve[i] = __builtin_nontemporal_load(&stg.element[stage_slot(c, 16 * h + 4 * i + rr, lane_q)]);
-                    if (!(r0 + 4 * i + rr < cnt)) ve[i] = 0;  // beyond the track's end: no record
-                }
-                bool slow = false;  // a marked record that is not its pass's first row: its entry point is fetched where it is needed
-                if (lane < 16 && ve[0] < 0) {  // the pass's first row keeps its own entry point (every track's first record: chunk 0)
-                    const int32_t idx = -ve[0] - 1;
-                    hx = stg.s_px[idx]; hy = stg.s_py[idx];
-                }
-                // ---- exit points
-                {
-                    double eA[4], eB[4], eC[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const RT_G EdgeABC *e = a.etab + (ve[i] > 0 ? ve[i] - 1 : 0);
-                        eA[i] = e->A; eB[i] = e->B; eC[i] = e->C;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        double qx, qy;
-                        edge_exit_point(tA, tB, tC, eA[i], eB[i], eC[i], qx, qy);  // src/intersection.jl:127-138
-                        if (__builtin_expect(ve[i] < 0, 0)) {  // a record of the generic step: its own q (and cell)
-                            const int32_t idx = -ve[i] - 1;
-                            qx = stg.s_qx[idx]; qy = stg.s_qy[idx];
-                            if (i == 0 && rr == 0) ve[i] = 3 * (stg.s_el[idx] - 1) + 1;  // (its p sits in slot 0: from here on an ordinary word)
-                            else slow = true;
-                        }
-                        X[tb + 1 + 4 * i + rr] = qx;
-                        Y[tb + 1 + 4 * i + rr] = qy;
-                    }
-                }
-                if (lane < 16) { X[tb] = hx; Y[tb] = hy; }
-                const bool any_slow = __ballot(slow) != 0;
-                __builtin_amdgcn_wave_barrier();
-                // ---- ℓ = ‖p − q‖ (Segment ctor, src/segment.jl:31-33) in the load mapping; p, q to the output in the store mapping
-                double dl[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rl = 4 * i + rr;
-                    double px = X[tb + rl], py = Y[tb + rl];
-                    const double qx = X[tb + rl + 1], qy = Y[tb + rl + 1];
-                    if (__builtin_expect(any_slow, 0))
-                        if (ve[i] < 0) { px = stg.s_px[-ve[i] - 1]; py = stg.s_py[-ve[i] - 1]; }
-                    dl[i] = norm2(px - qx, py - qy);
-                    acc += ve[i] != 0 ? dl[i] : 0.0;
-                }
-                if (lane < 16) { hx = X[tb + kMatRows]; hy = Y[tb + kMatRows]; }  // the next pass's "row before"
-                // positions in the unit's span, store mapping: >= 0 store there; -1 beyond the arrays' capacity (the host compacts
-                // again); -2 no record
-                int64_t ro[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int tt = 4 * g + sub;
-                    const int32_t ct = __shfl(cnt, tt, 64);  // (shuffles in uniform control flow only: an inactive lane supplies nothing)
-                    const int64_t ot = __shfl(off, tt, 64);
-                    const int row = r0 + rowL;
-                    ro[g] = row < ct ? (ot + row < out.cap ? ot + row : -1) : -2;
-                }
-                if (RECORDS) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int sb = (4 * g + sub) * kMatPitch + rowL;
-                        const double px = X[sb], qx = X[sb + 1], py = Y[sb], qy = Y[sb + 1];
-                        if (ro[g] >= 0) { out.px[ro[g]] = px; out.py[ro[g]] = py; out.qx[ro[g]] = qx; out.qy[ro[g]] = qy; }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // ---- lengths and cells through the tiles; fill_volumes in the store mapping (its 16 rows of a track are 16 cells:
-                //      no two lanes of a quarter add to one address, as the 16 neighbouring tracks of a row would)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int32_t wd = ve[i];
-                    if (__builtin_expect(any_slow, 0))
-                        if (wd < 0) wd = 3 * (stg.s_el[-wd - 1] - 1) + 1;
-                    const int32_t cell = (int32_t)((uint32_t)(wd > 0 ? wd - 1 : 0) / 3u) + 1;
-                    X[tb + 1 + 4 * i + rr] = dl[i];
-                    Yi[tb + 1 + 4 * i + rr] = cell;
-                    if (ROWS && wd != 0) {
-                        const int64_t sidx = stage_slot(c, 16 * h + 4 * i + rr, lane_q);
-                        a.ell_rows[sidx] = dl[i];
-                        a.cell_rows[sidx] = cell;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int sb = (4 * g + sub) * kMatPitch + 1 + rowL;
-                    const double ell = X[sb];
-                    const int32_t el = Yi[sb];
-                    const double wt = __shfl(tW, 4 * g + sub, 64);
-                    if (RECORDS && ro[g] >= 0) { out.ell[ro[g]] = ell; out.element[ro[g]] = el; }
-                    if (tally && ro[g] >= -1) atomicAdd(&hist[el - 1], wt * ell);  // fill_volumes, src/trackgenerator.jl:382 (LDS-private)
-                }
-                if (RECORDS && __builtin_expect(any_slow, 0)) {
-                    // the entry points of marked records that are not their pass's first row, straight from the load mapping
-                    // (stores to the same addresses as above, later in program order: these stay)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (ve[i] < 0 && off + r0 + 4 * i + rr < out.cap) {
-                            const int32_t idx = -ve[i] - 1;
-                            out.px[off + r0 + 4 * i + rr] = stg.s_px[idx];
-                            out.py[off + r0 + 4 * i + rr] = stg.s_py[idx];
-                        }
-                }
-                __builtin_amdgcn_wave_barrier();  // the tiles are rewritten by the next pass
-            }
-        }
-        if (tally) {
-            // Σℓ of the 16 tracks over this wave's rows: the four lanes of a track, then the four waves' parts in LDS
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
-            if (lane < 16 && acc != 0.0) atomicAdd(&s_sum[team][lane], acc);
-            __syncthreads();
-            if (kw == 0 && lane < 16) {
-                const double S = s_sum[team][lane];
-                s_sum[team][lane] = 0.0;
-                if (have) {
-                    const double L = t.ell[u];
-                    // any-order sum against the left-to-right one: within cnt·2⁻⁵³·Σ; 96 bands hold the statistic's 64 (k_finish)
-                    if (a.force_exact || sum_check_is_marginal(L, S, a.rtol, cnt, 96.0)) {
-                        const int32_t e = atomicAdd((int32_t *)&a.marg[0], 1);
-                        if (e < a.marg_cap) a.marg[1 + e] = (int32_t)slot;  // (marg_cap = every march slot: cannot overflow)
-                    } else if (status[u] == RT_TRACK_OK && !isapprox_s(L, S, a.rtol)) {  // src/track.jl:171-175
-                        status[u] = RT_TRACK_LENGTH_MISMATCH;
-                        atomicAdd(&a.ctl[0], 1ull);
-                        atomicMin(&a.ctl[1], (unsigned long long)(u + 1));
-                    }
-                }
-            }
-        }
+    typedef __attribute__((address_space(3))) volatile int64_t lds_i64;
+    lds_f64 *X = (lds_f64 *)tiles_x[kw], *Y = (lds_f64 *)tiles_y[kw];
+    lds_i32 *Yi = (lds_i32 *)tiles_y[kw];
+    lds_i32 *scnt = (lds_i32 *)s_cnt;
+    lds_i64 *soff = (lds_i64 *)s_off;
+    const int64_t unit = blockIdx.x;
+    const int64_t w = a.corder ? a.corder[unit >> 2] : (unit >> 2);
+    const int q = (int)(unit & 3);
+    const int64_t slot = w * 64 + 16 * q + tl;
+    // every lane holds its load-mapping track's uid, count, offset and line (the 4 lanes of a track load the same words)
+    int32_t cnt = 0, u = 0;
+    int64_t off = 0;
+    double tA = 0.0, tB = 0.0, tC = 0.0;
+    const bool have = slot < t.n;
+    if (have) {
+        u = t.perm[slot];
+        cnt = counts[u];
+        off = offsets[u];
     }
-    // this workgroup's share of `volumes`, as plain stores: k_finish adds the shares in workgroup order (hundreds of workgroups
-    // adding thousands of values each with global atomics at the same moment took 60 µs, and the sum depended on their order)
-    if (tally) {
+    if (threadIdx.x < 16) { scnt[tl] = cnt; soff[tl] = off; s_sum[tl] = 0.0; }
+    int32_t gmax = cnt;
+    for (int o = 8; o > 0; o >>= 1) {
+        const int32_t v = __shfl_xor(gmax, o, 64);
+        gmax = v > gmax ? v : gmax;
+    }
+    gmax = __shfl(gmax, 0, 64);
+    if ((kw << kChunkLog2) < gmax && have) { tA = t.A[u]; tB = t.B[u]; tC = t.C[u]; }
+    __syncthreads();
+    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
+    const int lane_q = 16 * q + tl;
+    const int tb = tl * kC3Pitch;
+    double acc = 0.0;  // Σℓ of this lane's rows of its load-mapping track
+    for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
+        const int r0 = j << kChunkLog2;
+        const int32_t c = ctab[j];
+        // ---- the chunk's words, in the load mapping (lane = track tl, rows 4 i + rr)
+        int32_t ve[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ve[i] = __builtin_nontemporal_load(&stg.element[stage_slot(c, 4 * i + rr, lane_q)]);
+        bool flagged = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!(r0 + 4 * i + rr < cnt)) ve[i] = 0;  // beyond the track's end: no record
+            flagged = flagged || (ve[i] > 0 && (ve[i] & kWordExactTally) != 0);
+        }
+        const bool any_flagged = a.tally && __ballot(flagged) != 0;
+        int32_t fmask = 0;  // rows of this lane whose fill_volumes term is added below
+        if (__builtin_expect(__ballot(flagged) != 0, 0)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (ve[i] > 0 && (ve[i] & kWordExactTally)) { fmask |= 1 << i; ve[i] &= ~kWordExactTally; }
+        }
+        // lanes 0..15 also hold the entry point of the chunk's first row: the exit point of the row before (another chunk's last
+        // row) or, for a record that keeps its own end points, the side list's p
+        double hx = 0.0, hy = 0.0;
+        if (j > 0) {  // (uniform; a track's first chunk starts with a record of the generic step)
+            int32_t hw = 0;
+            if (lane < 16 && cnt > r0) hw = stg.element[stage_slot(ctab[j - 1], kChunkRows - 1, lane_q)];
+            if (hw > 0) hw &= ~kWordExactTally;
+            const RT_G EdgeABC *he = a.etab + (hw > 0 ? hw - 1 : 0);
+            const double hA = he->A, hB = he->B, hC = he->C;
+            edge_exit_point(tA, tB, tC, hA, hB, hC, hx, hy);
+            if (__builtin_expect(hw < 0, 0)) { hx = stg.s_qx[-hw - 1]; hy = stg.s_qy[-hw - 1]; }
+        }
+        if (lane < 16 && ve[0] < 0) {  // the chunk's first row keeps its own entry point (every track's first record: chunk 0)
+            const int32_t idx = -ve[0] - 1;
+            hx = stg.s_px[idx]; hy = stg.s_py[idx];
+        }
+        // ---- exit points (four rows at a time: the gathers' registers)
+        bool slow = false;  // a marked record that is not its chunk's first row: its entry point is fetched where it is needed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double eA[4], eB[4], eC[4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const int i = 4 * h + i2;
+                const RT_G EdgeABC *e = a.etab + (ve[i] > 0 ? ve[i] - 1 : 0);
+                eA[i2] = e->A; eB[i2] = e->B; eC[i2] = e->C;
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const int i = 4 * h + i2;
+                double qx, qy;
+                edge_exit_point(tA, tB, tC, eA[i2], eB[i2], eC[i2], qx, qy);  // src/intersection.jl:127-138
+                if (__builtin_expect(ve[i] < 0, 0)) {  // a record of the generic step: its own q (and cell)
+                    const int32_t idx = -ve[i] - 1;
+                    qx = stg.s_qx[idx]; qy = stg.s_qy[idx];
+                    if (i == 0 && rr == 0) ve[i] = 3 * (stg.s_el[idx] - 1) + 1;  // (its p sits in slot 0: from here on an ordinary word)
+                    else slow = true;
+                }
+                X[tb + 1 + 4 * i + rr] = qx;
+                Y[tb + 1 + 4 * i + rr] = qy;
+            }
+        }
+        if (lane < 16) { X[tb] = hx; Y[tb] = hy; }
+        const bool any_slow = __ballot(slow) != 0;
+        __builtin_amdgcn_wave_barrier();
+        // ---- ℓ = ‖p − q‖ (Segment ctor, src/segment.jl:31-33) in the load mapping; p, q to the output in the store mapping
+        double dl[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = 4 * i + rr;
+            double px = X[tb + rl], py = Y[tb + rl];
+            const double qx = X[tb + rl + 1], qy = Y[tb + rl + 1];
+            if (__builtin_expect(any_slow, 0))
+                if (ve[i] < 0) { px = stg.s_px[-ve[i] - 1]; py = stg.s_py[-ve[i] - 1]; }
+            dl[i] = norm2(px - qx, py - qy);
+            acc += ve[i] != 0 ? dl[i] : 0.0;
+        }
+        if (__builtin_expect(any_flagged, 0)) {
+            // fill_volumes (src/trackgenerator.jl:382) for the records the march left out: δs[azim]·ℓ with the record's own length
+            const double wt = have ? out.delta_s[t.azim[u] - 1] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((fmask >> i) & 1) unsafeAtomicAdd((double *)&a.vacc[(int32_t)((uint32_t)(ve[i] - 1) / 3u)], wt * dl[i]);
+        }
+        if (RECORDS) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int tt = 2 * g + sub;
+                const int sb = tt * kC3Pitch + rowL;
+                const int row = r0 + rowL;
+                const int64_t o = soff[tt] + row;
+                const double px = X[sb], qx = X[sb + 1], py = Y[sb], qy = Y[sb + 1];
+                // plain stores: the partial lines at the ends of a run wait in L2 for the sibling wave's half
+                if (row < scnt[tt] && o < out.cap && !((out.dbg & 1) && px != -1.25)) { out.px[o] = px; out.py[o] = py; out.qx[o] = qx; out.qy[o] = qy; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lengths and cells through the tiles
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int32_t wd = ve[i];
+            if (__builtin_expect(any_slow, 0))
+                if (wd < 0) wd = 3 * (stg.s_el[-wd - 1] - 1) + 1;
+            const int32_t cell = (int32_t)((uint32_t)(wd > 0 ? wd - 1 : 0) / 3u) + 1;
+            X[tb + 1 + 4 * i + rr] = dl[i];
+            Yi[tb + 1 + 4 * i + rr] = cell;
+            if (ROWS && wd != 0) {
+                const int64_t sidx = stage_slot(c, 4 * i + rr, lane_q);
+                a.ell_rows[sidx] = dl[i];
+                a.cell_rows[sidx] = cell;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (RECORDS) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int tt = 2 * g + sub;
+                const int sb = tt * kC3Pitch + 1 + rowL;
+                const int row = r0 + rowL;
+                const int64_t o = soff[tt] + row;
+                const double ell = X[sb];
+                const int32_t el = Yi[sb];
+                if (row < scnt[tt] && o < out.cap && !((out.dbg & 1) && ell != -1.25)) { out.ell[o] = ell; out.element[o] = el; }
+            }
+            if (__builtin_expect(any_slow, 0)) {
+                // the entry points of marked records that are not their chunk's first row, straight from the load mapping
+                // (stores to the same addresses as above, later in program order: these stay)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (ve[i] < 0 && off + r0 + 4 * i + rr < out.cap) {
+                        const int32_t idx = -ve[i] - 1;
+                        out.px[off + r0 + 4 * i + rr] = stg.s_px[idx];
+                        out.py[off + r0 + 4 * i + rr] = stg.s_py[idx];
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
+    }
+    if (a.tally) {
+        // Σℓ of the 16 tracks over this wave's rows: the four lanes of a track, then the four waves' parts in LDS
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < 16 && acc != 0.0) atomicAdd(&s_sum[lane], acc);
         __syncthreads();
-        for (int c = threadIdx.x; c < a.n_cells; c += 256 * TEAMS) a.slabs[(int64_t)blockIdx.x * a.n_cells + c] = hist[c];
+        if (kw == 0 && lane < 16 && have) {
+            const double S = s_sum[lane];
+            const double L = t.ell[u];
+            // any-order sum against the left-to-right one: within cnt·2⁻⁵³·Σ; 96 bands hold the statistic's 64 (k_finish)
+            if (a.force_exact || sum_check_is_marginal(L, S, a.rtol, cnt, 96.0)) {
+                const int32_t e = atomicAdd((int32_t *)&a.marg[0], 1);
+                if (e < a.marg_cap) a.marg[1 + e] = (int32_t)slot;  // (marg_cap = every march slot: cannot overflow)
+            } else if (status[u] == RT_TRACK_OK && !isapprox_s(L, S, a.rtol)) {  // src/track.jl:171-175
+                status[u] = RT_TRACK_LENGTH_MISMATCH;
+                atomicAdd(&a.ctl[0], 1ull);
+                atomicMin(&a.ctl[1], (unsigned long long)(u + 1));
+            }
+        }
     }
 }
 
-// After k_materialise: (1) the tracks whose Σℓ check a sum in another order cannot decide are summed left to right — from
-// the records, or from the ℓ rows when the call wrote no records — and checked as the reference does (src/track.jl:171-175);
-// the statistic of rt_last_stats (tracks within 64 summation-order bands of the threshold) is counted here; (2) volumes =
-// Σ shares ./ n_azim_2 (src/trackgenerator.jl:376-386), the workgroups' shares added in workgroup order; (3) the block that
+// After k_materialise: the tracks whose Σℓ check a sum in another order cannot decide are summed left to right — from the
+// records, or from the ℓ rows when the call wrote no records — and checked as the reference does (src/track.jl:171-175); the
+// statistic of rt_last_stats (tracks within 64 summation-order bands of the threshold) is counted here.  The block that
 // finishes last — a ticket — copies the control block to the host and writes the call's sequence number behind it.
-// mode: bit 0 volumes, bit 1 exact sums.
 __global__ __launch_bounds__(256) void k_finish(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
                                                 const int64_t *__restrict__ offsets, const double *__restrict__ ell, int64_t cap,
                                                 DStage stg, const double *__restrict__ ell_rows, double rtol, int32_t *__restrict__ marg,
-                                                double *__restrict__ volumes, const double *__restrict__ slabs, int32_t n_slabs,
-                                                int32_t n_cells, double n_azim_2, int32_t mode, unsigned long long *__restrict__ ctl,
-                                                unsigned long long *__restrict__ host_copy, unsigned long long seq) {
+                                                double *__restrict__ volumes, double *__restrict__ vacc, int32_t n_cells, double n_azim_2,
+                                                unsigned long long *__restrict__ ctl, unsigned long long *__restrict__ host_copy,
+                                                unsigned long long seq) {
     __shared__ int last_wg;
     const bool void_attempt = stg.cursor[1] != 0 || stg.cursor[3] != 0;
-    if (!void_attempt) {
-        if (mode & 2) {
-            const int32_t nm = marg[0];
-            for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < nm; e += gridDim.x * 256) {
-                const int32_t slot = marg[1 + e];
-                if (slot < 0) continue;  // done by an earlier pass
-                const int32_t u = t.perm[slot];
-                const int32_t cnt = counts[u];
-                const int64_t off = offsets[u];
-                double S = 0.0;
-                if (ell_rows) {
-                    const RT_G int32_t *ctab = stg.ctab + (int64_t)(slot >> 6) * kMaxChunks;
-                    for (int32_t r = 0; r < cnt; ++r) S += ell_rows[stage_slot(ctab[r >> kChunkLog2], r & (kChunkRows - 1), slot & 63)];
-                } else if (ell && off + cnt <= cap) {
-                    for (int32_t r = 0; r < cnt; ++r) S += ell[off + r];
-                } else {
-                    atomicAdd(&ctl[kCtlDeferred], 1ull);  // the host compacts again with larger arrays and calls this once more
-                    continue;
-                }
-                marg[1 + e] = -1 - slot;
-                const double L = t.ell[u];
-                if (sum_check_is_marginal(L, S, rtol, cnt)) atomicAdd(&ctl[kCtlNearRtol], 1ull);
-                if (status[u] == RT_TRACK_OK && !isapprox_s(L, S, rtol)) {
-                    status[u] = RT_TRACK_LENGTH_MISMATCH;
-                    atomicAdd(&ctl[0], 1ull);
-                    atomicMin(&ctl[1], (unsigned long long)(u + 1));
-                }
-            }
+    // volumes ./= n_azim_2 (src/trackgenerator.jl:386): the march accumulated into `vacc` (k_materialise added the terms of the
+    // records the march left to it), which is read, scaled into `volumes` and left ZERO for the next call's march
+    if (volumes)
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < n_cells; c += gridDim.x * 256) {
+            volumes[c] = vacc[c] / n_azim_2;
+            vacc[c] = 0.0;
         }
-    }
-    if (!void_attempt && (mode & 1)) {
-        // 16 cells x 16 ranges of shares per workgroup: a thread adds its range of shares of one cell in order, the 16 partial
-        // sums are added in range order — the same order in every run
-        __shared__ double part[16][17];
-        const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-        const int b0 = (int)((int64_t)n_slabs * rg / 16), b1 = (int)((int64_t)n_slabs * (rg + 1) / 16);
-        for (int c0 = blockIdx.x * 16; c0 < n_cells; c0 += gridDim.x * 16) {
-            const int c = c0 + cl;
-            double v = 0.0;
-            if (c < n_cells)
-                for (int b = b0; b < b1; ++b) v += slabs[(int64_t)b * n_cells + c];
-            part[rg][cl] = v;
-            __syncthreads();
-            if (rg == 0 && c < n_cells) {
-                double tsum = 0.0;
-                for (int r = 0; r < 16; ++r) tsum += part[r][cl];
-                volumes[c] = tsum / n_azim_2;  // volumes ./= n_azim_2, src/trackgenerator.jl:386
+    if (!void_attempt) {
+        const int32_t nm = marg[0];
+        for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < nm; e += gridDim.x * 256) {
+            const int32_t slot = marg[1 + e];
+            if (slot < 0) continue;  // done by an earlier pass
+            const int32_t u = t.perm[slot];
+            const int32_t cnt = counts[u];
+            const int64_t off = offsets[u];
+            double S = 0.0;
+            if (ell_rows) {
+                const RT_G int32_t *ctab = stg.ctab + (int64_t)(slot >> 6) * kMaxChunks;
+                for (int32_t r = 0; r < cnt; ++r) S += ell_rows[stage_slot(ctab[r >> kChunkLog2], r & (kChunkRows - 1), slot & 63)];
+            } else if (ell && off + cnt <= cap) {
+                for (int32_t r = 0; r < cnt; ++r) S += ell[off + r];
+            } else {
+                atomicAdd(&ctl[kCtlDeferred], 1ull);  // the host compacts again with larger arrays and calls this once more
+                continue;
             }
-            __syncthreads();
+            marg[1 + e] = -1 - slot;
+            const double L = t.ell[u];
+            if (sum_check_is_marginal(L, S, rtol, cnt)) atomicAdd(&ctl[kCtlNearRtol], 1ull);
+            if (status[u] == RT_TRACK_OK && !isapprox_s(L, S, rtol)) {
+                status[u] = RT_TRACK_LENGTH_MISMATCH;
+                atomicAdd(&ctl[0], 1ull);
+                atomicMin(&ctl[1], (unsigned long long)(u + 1));
+            }
         }
     }
     __threadfence();
@@ -1673,6 +1680,7 @@ __global__ __launch_bounds__(256) void k_finish(DTracks t, const int32_t *__rest
     if (threadIdx.x == 0 && __hip_atomic_load(&ctl[kCtlDeferred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) marg[0] = 0;  // the list is consumed
     if (threadIdx.x == 0) ctl[kCtlFinishTicket] = 0;  // (a second pass of this call counts again)
     if (host_copy) {
+        __syncthreads();
         if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();
         __syncthreads();
@@ -2230,7 +2238,8 @@ struct rt_mesh {
                            // compaction may still be running on the stream (every entry point that touches results waits)
     int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
-    double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0;
+    double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0, tally_tau = 0.0;
+    int64_t test_tally_tau = 0;  // tests only: overrides tally_tau (in 1e-12; < 0: ∞ — every cheap record tallied by k_materialise)
     int64_t n_records_topo = 0;
     int hybrid = 0;        // 1: batches that fill the chip march only their longest waves in pieces, beside the whole-track march of the rest
                            // (measured slower at every threshold on MI355X — the full batch is within 1.6x of its throughput floor — DESIGN.md §4)
@@ -2244,8 +2253,6 @@ struct rt_mesh {
     int test_volumes_fallback = 0;  // tests only: take the split mode's volumes recomputation path unconditionally
     int test_exact_sums = 0;        // tests only: every track's Σℓ check by k_finish's left-to-right sum (two-phase march)
     int64_t side_entries_hint = 0;  // tests only: capacity of the dynamic part of the side list on a handle's first call (forces its overflow path)
-    int mat_wgs = 0;                // k_materialise: workgroups per CU (0: as many as fit)
-    int mat_teams = 0;              // ... teams of four waves per workgroup (0: automatic; 1, 2, 4)
     int sort_mode = 2;     // march order: 0 uid order, 1 longest track first, 2 uid-contiguous waves, longest wave first
     double kappa = 0.0;    // expected segments per unit track length (sizes the staging pool)
     std::string prep_note;
@@ -2289,10 +2296,9 @@ struct rt_tracks {
     DevBuf<int32_t> gelement, ctab, cowner;
     // two-phase march (k_march<TOPO> + k_materialise): the side list of records that keep their own end points, the
     // workgroups' shares of `volumes`, the list of tracks whose Σℓ check k_finish decides with a left-to-right sum
-    DevBuf<double> side_px, side_py, side_qx, side_qy, slabs;
+    DevBuf<double> side_px, side_py, side_qx, side_qy;
     DevBuf<int32_t> side_el, marg;
     int64_t side_cap = 0, side_needed_last = 0;
-    int32_t n_slabs = 0;
     bool marg_clean = false;
     DevBuf<int32_t> fst_i;   // k_first: it, T, pred per march slot
     DevBuf<double> fst_v;    // ... and its ten doubles
@@ -2477,7 +2483,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     d.walk_ok = P.walk_ok ? 1 : 0;
     d.trec = as_global((const rt::TopoRec *)m->trec.p); d.etab = as_global((const rt::EdgeABC *)m->etab.p);
     m->topo_available = P.walk_ok && P.topo_ok;
-    m->topo_tiny_max = P.topo_tiny_max; m->topo_rmax = P.topo_rmax; m->topo_end_err = P.topo_end_err;
+    m->topo_tiny_max = P.topo_tiny_max; m->topo_rmax = P.topo_rmax; m->topo_end_err = P.topo_end_err; m->tally_tau = P.tally_tau;
     m->n_records_topo = P.n_records_topo;
     m->walk_available = P.walk_ok;
     m->kappa = P.kappa;
@@ -2511,7 +2517,7 @@ int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out) {
 }
 
 // Codes -> records and / or (ℓ, cell) rows (k_materialise) for the plan of the last two-phase call.  tally: the call's first
-// pass over the codes — Σℓ, status, fill_volumes' shares (k_finish completes them).
+// pass over the codes — Σℓ and status (k_finish completes them).
 int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl) {
     using rt::as_global;
     rt_mesh *m = t->mesh;
@@ -2519,76 +2525,41 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
     if (t->n <= 0 || c.n_whole_waves <= 0) return RT_SUCCESS;
     rt::DMat a{};
     a.etab = m->d.etab; a.corder = as_global(c.corder);
-    a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.n_cells = m->n_cells; a.tally = tally ? 1 : 0;
-    a.force_exact = m->test_exact_sums; a.ctl = d_ctl;
-    const size_t hist = tally ? (size_t)m->n_cells * sizeof(double) : 0;
-    // Shape: teams of four waves (one unit each) per workgroup, sharing the workgroup's LDS copy of `volumes`; as many waves per CU
-    // as LDS allows, up to 16 (the kernel's registers allow four per SIMD), with the fewest teams that get there.
-    int teams = 1, per_cu = 0;
-    {
-        int best_waves = 0;
-        const int max_teams_cu = RT_MAT_OCC;  // (teams of four waves per CU the registers allow)
-        for (int tm : {1, 2, 3, 4}) {
-            if (tm > max_teams_cu) break;
-            const size_t stat = (size_t)tm * 4 * 2 * 16 * rt::kMatPitch * sizeof(double) + 512;  // the kernel's own tiles
-            const int pc = (int)std::min<size_t>((size_t)(max_teams_cu / tm), (size_t)(158 * 1024) / (stat + hist));
-            if (pc * tm * 4 > best_waves) { best_waves = pc * tm * 4; teams = tm; per_cu = pc; }
-        }
-        if (m->mat_teams >= 1 && m->mat_teams <= max_teams_cu) {  // (experiments)
-            teams = m->mat_teams;
-            const size_t stat = (size_t)teams * 4 * 2 * 16 * rt::kMatPitch * sizeof(double) + 512;
-            per_cu = (int)std::min<size_t>((size_t)(max_teams_cu / teams), (size_t)(158 * 1024) / (stat + hist));
-        }
-    }
-    if (m->mat_wgs > 0) per_cu = std::min(per_cu, m->mat_wgs);
-    if (per_cu < 1) { set_error("k_materialise: an LDS copy of volumes (%zu B) does not fit", hist); return RT_ERR_INVALID; }
-    const unsigned blocks = (unsigned)std::min<int64_t>((a.n_units + teams - 1) / teams, (int64_t)m->n_cus * per_cu);
+    a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.tally = tally ? 1 : 0;
+    a.force_exact = m->test_exact_sums; a.ctl = d_ctl; a.vacc = as_global(t->vacc.p);
     if (tally) {
-        RT_HIP(t->slabs.reserve((size_t)blocks * m->n_cells));
         RT_HIP(t->marg.reserve((size_t)c.n_whole_waves * 64 + 1));
         if (!t->marg_clean) { RT_HIP(hipMemsetAsync(t->marg.p, 0, sizeof(int32_t), s)); t->marg_clean = true; }
-        t->n_slabs = (int32_t)blocks;
-        a.slabs = as_global(t->slabs.p); a.marg = as_global(t->marg.p); a.marg_cap = (int32_t)std::min<int64_t>(c.n_whole_waves * 64, 0x7fffffff);
+        a.marg = as_global(t->marg.p); a.marg_cap = (int32_t)std::min<int64_t>(c.n_whole_waves * 64, 0x7fffffff);
     }
     if (rows) {
         const size_t slots = (size_t)t->pool_chunks * rt::kChunkRows * 64;
         RT_HIP(t->sw_ell.reserve(slots > 0 ? slots : 1)); RT_HIP(t->sw_cell.reserve(slots > 0 ? slots : 1));
         a.ell_rows = as_global(t->sw_ell.p); a.cell_rows = as_global(t->sw_cell.p);
     }
-    auto go = [&]<bool RECORDS, bool ROWS, int TEAMS>() -> int {
-        static size_t attr_set = 0;  // (per instantiation; raised only: hipFuncSetAttribute costs host time)
-        if (hist > attr_set) {
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_materialise<RECORDS, ROWS, TEAMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist));
-            attr_set = hist;
-        }
-        hipLaunchKernelGGL((rt::k_materialise<RECORDS, ROWS, TEAMS>), dim3(blocks), dim3(256 * TEAMS), hist, s, c.d_whole,
-                           (const int32_t *)t->counts.p, t->status.p, (const int64_t *)t->offsets.p, c.stg, out, a);
-        return RT_SUCCESS;
-    };
-    auto shape = [&]<bool RECORDS, bool ROWS>() -> int {
-        if (teams == 4) return go.template operator()<RECORDS, ROWS, 4>();
-        if (teams == 3) return go.template operator()<RECORDS, ROWS, 3>();
-        if (teams == 2) return go.template operator()<RECORDS, ROWS, 2>();
-        return go.template operator()<RECORDS, ROWS, 1>();
-    };
-    if (records && rows) return shape.template operator()<true, true>();
-    if (records) return shape.template operator()<true, false>();
-    if (rows) return shape.template operator()<false, true>();
-    set_error("k_materialise: nothing to write");
-    return RT_ERR_INVALID;
+    const unsigned blocks = (unsigned)a.n_units;
+    if (records && rows)
+        hipLaunchKernelGGL((rt::k_materialise<true, true>), dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
+                           (const int64_t *)t->offsets.p, c.stg, out, a);
+    else if (records)
+        hipLaunchKernelGGL((rt::k_materialise<true, false>), dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
+                           (const int64_t *)t->offsets.p, c.stg, out, a);
+    else if (rows)
+        hipLaunchKernelGGL((rt::k_materialise<false, true>), dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
+                           (const int64_t *)t->offsets.p, c.stg, out, a);
+    else { set_error("k_materialise: nothing to write"); return RT_ERR_INVALID; }
+    return RT_SUCCESS;
 }
 
-// k_finish behind a tallying k_materialise (mode bit 0: volumes from the shares, bit 1: exact Σℓ of the listed tracks);
-// copies the control block to the host.
-void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, int mode, bool from_rows, double n_azim_2, unsigned long long *d_ctl,
-                   unsigned long long *h_res_dev, unsigned long long seq) {
-    rt_mesh *m = t->mesh;
+// k_finish behind a tallying k_materialise: exact Σℓ of the listed tracks; copies the control block to the host.
+void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_rows, bool scale_volumes, double n_azim_2,
+                   unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq) {
     const rt_tracks::CompactPlan &c = t->cplan;
-    const unsigned blocks = (unsigned)std::min(1024, std::max(1, (m->n_cells + 15) / 16));
+    const unsigned blocks = t->mesh->test_exact_sums ? 64u : 8u;
     hipLaunchKernelGGL(rt::k_finish, dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
                        (const int64_t *)t->offsets.p, from_rows ? (const double *)nullptr : (const double *)t->sell.p, out.cap, c.stg,
-                       from_rows ? (const double *)t->sw_ell.p : (const double *)nullptr, c.rtol, t->marg.p, t->volumes.p,
-                       (const double *)t->slabs.p, t->n_slabs, m->n_cells, n_azim_2, mode, d_ctl, h_res_dev, seq);
+                       from_rows ? (const double *)t->sw_ell.p : (const double *)nullptr, c.rtol, t->marg.p,
+                       scale_volumes ? t->volumes.p : (double *)nullptr, t->vacc.p, t->mesh->n_cells, n_azim_2, d_ctl, h_res_dev, seq);
 }
 
 // Staged rows -> compact CSR records for the plan of the last single-pass call: k_compact3 over (q, ±cell) rows, or — codes —
@@ -2655,7 +2626,7 @@ void free_tracks(rt_tracks *t) {
     t->gelement.release(); t->ctab.release(); t->cowner.release(); t->fst_i.release(); t->fst_v.release();
     t->sw_src.release(); t->sw_w.release(); t->sw_xs.release(); t->sw_psi_in.release(); t->sw_psi_out.release(); t->sw_phi.release();
     t->sw_ell.release(); t->sw_cell.release();
-    t->side_px.release(); t->side_py.release(); t->side_qx.release(); t->side_qy.release(); t->side_el.release(); t->slabs.release(); t->marg.release();
+    t->side_px.release(); t->side_py.release(); t->side_qx.release(); t->side_qy.release(); t->side_el.release(); t->marg.release();
     t->vorder.release(); t->vw_wave.release(); t->vw_k.release(); t->w_base.release(); t->w_P.release();
     t->s_el.release(); t->s_eq.release(); t->p_count.release(); t->p_flags.release(); t->p_valid.release(); t->p_rel.release();
     t->s_px.release(); t->s_py.release(); t->s_qx.release(); t->s_qy.release(); t->s_ell.release(); t->p_sum.release();
@@ -2831,9 +2802,8 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "test_out_records")) { mesh->test_out_records = value; return RT_SUCCESS; }
     if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "test_exact_sums")) { mesh->test_exact_sums = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "test_tally_tau")) { mesh->test_tally_tau = value; return RT_SUCCESS; }
     if (!strcmp(name, "side_entries_hint")) { mesh->side_entries_hint = value; return RT_SUCCESS; }
-    if (!strcmp(name, "mat_wgs")) { mesh->mat_wgs = (int)value; return RT_SUCCESS; }
-    if (!strcmp(name, "mat_teams")) { mesh->mat_teams = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
         mesh->d.walk_ok = (value != 0 && mesh->walk_available) ? 1 : 0;
@@ -3036,6 +3006,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
     prm.topo_tiny_max = m->topo_tiny_max; prm.topo_rmax = m->topo_rmax; prm.topo_end_err = m->topo_end_err;
     prm.topo_force = m->topo == 2 ? 1 : 0; prm.pad_ = 0;
+    prm.tally_tau = m->test_tally_tau != 0 ? (m->test_tally_tau < 0 ? (double)INFINITY : 1e-12 * (double)m->test_tally_tau) : m->tally_tau;
 
     const int64_t n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
     const int64_t n_waves = (n + 63) / 64;
@@ -3211,7 +3182,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
                            : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * ((split ? t->n_vwaves : 0) + (split_all ? 0 : n_whole_waves)) + 64;
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
-        fused_volumes_this_call = fuse;  // (two-phase march: k_materialise + k_finish produce `volumes` inside the call)
+        fused_volumes_this_call = fuse;
         // the side list of the two-phase march: one reserved entry per march slot (a track's first record) + the records the
         // generic step makes further on — estimated from the share of records without a walk certificate (or the last call's need)
         const int64_t side_static = n_whole_waves * 64;
@@ -3295,13 +3266,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             side_first_this_call = topo ? (int32_t)side_static : 0;
             const int64_t reset_key = (int64_t)first_chunk_this_call | ((int64_t)side_first_this_call << 32);
             if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
-            // (two-phase march: neither `vacc` nor `volumes` is accumulated into — k_finish writes `volumes`)
-            const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != reset_key || !(topo || (fuse && n > 0 && vacc_was_clean));
+            const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != reset_key || !(fuse && n > 0 && vacc_was_clean);
             auto enqueue_attempt = [&]() -> int {
                 if (need_reset)
                     hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(m->n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, d_ctl,
-                                       topo ? (double *)nullptr : ((fuse && n > 0) ? t->vacc.p : t->volumes.p), m->n_cells, first_chunk_this_call,
-                                       side_first_this_call);
+                                       (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk_this_call, side_first_this_call);
                 if (int rc = rec(1)) return rc;
                 if (use_first)
                     hipLaunchKernelGGL(rt::k_first, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, m->d, t->d, prm, stg, fst);
@@ -3332,8 +3301,10 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     // experiment: eight-wave workgroups (one per CU) with all walk records in LDS (1), or from L2 as usual (2: its control)
                     const size_t lds_base = ((hist_bytes + 8 * rt::kMaxChunks * sizeof(int32_t) + 15) & ~(size_t)15);
                     const size_t lds_smem = lds_base + (size_t)3 * m->n_cells * sizeof(rt::WalkRec);
-                    if (topo)  // the decision-only march keeps no LDS copy of `volumes`: four-wave workgroups, their chunk tables only
-                        rc = march.template operator()<rt::kStage, 4, false, false, false, true>((unsigned)((n_whole_waves + 3) / 4), 4 * rt::kMaxChunks * sizeof(int32_t));
+                    if (topo && fuse_waves == 4)
+                        rc = march.template operator()<rt::kStage, 4, false, false, false, true>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
+                    else if (topo)
+                        rc = march.template operator()<rt::kStage, 6, false, false, false, true>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
                     else if (fuse && m->lds_records == 1 && !hybrid && lds_smem <= 160 * 1024)
                         rc = march.template operator()<rt::kStage, 8, false, false, true>((unsigned)((n_whole_waves + 7) / 8), lds_smem);
                     else if (fuse && m->lds_records == 2 && !hybrid && lds_smem <= 160 * 1024)
@@ -3347,13 +3318,13 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     if (hybrid) RT_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
                 }
                 if (int rc = rec(2)) return rc;
-                if (int rc = scan_counts(!topo, fuse && !topo, true)) return rc;
+                if (int rc = scan_counts(!topo, fuse && !topo, true)) return rc;  // (two-phase: k_finish scales the volumes, behind k_materialise)
                 if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
                 if (topo) {
-                    // codes -> records (or, "compact" = 0, (ℓ, cell) rows) + Σℓ / status / fill_volumes; k_finish completes them and
-                    // copies the control block to the host
+                    // codes -> records (or, "compact" = 0, (ℓ, cell) rows) + Σℓ / status; k_finish completes them and copies the control
+                    // block to the host
                     if (int rc = launch_materialise(t, out, s, do_compact, !do_compact, true, d_ctl)) return rc;
-                    launch_finish(t, out, s, 3, !do_compact, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+                    launch_finish(t, out, s, !do_compact, fuse, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
                 } else if (do_compact) {
                     launch_compaction(t, out, s);
                 }
@@ -3377,9 +3348,14 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             // option "async": back to the caller as soon as the scan's copy of the control block has arrived — total, failure
             // summary and pool cursor are final then, the compaction goes on behind the call (whole-track calls without events)
             const bool async_call = m->async_calls && !m->timing && n > 0 && !split && !hybrid;
-            if (async_call) RT_HIP(wait_seq(h_res, t->call_seq, s));
+            // two-phase calls: the control block's copy and the sequence number behind it are the LAST thing the call's last kernel
+            // writes (k_finish's last block, after every other block of it has finished) — seeing the number in pinned memory is
+            // seeing the call complete, a few microseconds before the stream reports it (hipStreamQuery); what is still to happen
+            // on the stream is that kernel's retirement, which every later operation on the stream is ordered behind anyway
+            const bool seq_done = topo && !m->timing && n > 0;
+            if (async_call || seq_done) RT_HIP(wait_seq(h_res, t->call_seq, s));
             else RT_HIP(wait_stream(s));
-            t->in_flight = async_call;
+            t->in_flight = async_call || seq_done;  // (accessors wait for the stream: immediate here)
 #ifdef RT_HOST_TIMING
             {
                 const double ht3 = ht_now();
@@ -3398,7 +3374,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 launch_compaction(t, out, s);
                 if (topo && h_res[rt::kCtlDeferred] != 0) {
                     // tracks whose exact Σℓ k_finish could not form from the truncated records: once more, from the complete ones
-                    launch_finish(t, out, s, 2, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+                    launch_finish(t, out, s, false, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
                     RT_HIP(hipStreamSynchronize(s));
                     memcpy(fi, h_res, sizeof(fi));
                 }
@@ -3416,7 +3392,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 if (int rc = launch_volumes()) return rc;
                 RT_HIP(hipStreamSynchronize(s));
             }
-            if (!cur[1] && topo && false) {  // (two-phase march: a restarted track's rows are staged again, nothing was tallied)
+            if (!cur[1] && !cur[3] && topo && fuse && h_res[rt::kCtlRestarts] != 0) {
                 // a track whose iteration bound reached the cap was marched again with exact steps: its cheap records had
                 // already been added to the fused volumes — recompute them from the records
                 if (!do_compact) {
@@ -3439,7 +3415,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 if (topo && !do_compact) t->sw_ell_valid = true;  // (k_materialise left the (ℓ, cell) rows)
                 if (n > 0) {  // this call's scan has reset the other control block and (fused) left the accumulator zero
                     t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = reset_key;
-                    t->vacc_clean = topo ? vacc_was_clean : fuse;
+                    t->vacc_clean = fuse;
                     t->ctl_idx = 1 - cb;
                 }
                 break;
@@ -3975,7 +3951,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
                    b(t->w_base) + b(t->w_P) + b(t->s_el) + b(t->s_eq) + b(t->p_count) + b(t->p_flags) + b(t->p_valid) + b(t->p_rel) + b(t->s_px) +
                    b(t->s_py) + b(t->s_qx) + b(t->s_qy) + b(t->s_ell) + b(t->p_sum) + b(t->vacc) + b(t->fst_i) + b(t->fst_v) + b(t->tau) +
                    b(t->sigma_t) + b(t->sw_src) + b(t->sw_w) + b(t->sw_xs) + b(t->sw_psi_in) + b(t->sw_psi_out) + b(t->sw_phi) + b(t->sw_ell) +
-                   b(t->sw_cell) + b(t->side_px) + b(t->side_py) + b(t->side_qx) + b(t->side_qy) + b(t->side_el) + b(t->slabs) + b(t->marg);
+                   b(t->sw_cell) + b(t->side_px) + b(t->side_py) + b(t->side_qx) + b(t->side_qy) + b(t->side_el) + b(t->marg);
     }
     return RT_SUCCESS;
 }

@@ -99,6 +99,51 @@ def test_rtol_controls_length_check(rt, orc, pincell):
     assert tg.track_status[7] == 2 and np.count_nonzero(tg.track_status) == 1
 
 
+def test_length_check_at_the_threshold_is_the_left_to_right_sum(rt, orc, traced):
+    """isapprox(track.ℓ, Σℓ; rtol) (src/track.jl:171) for tracks whose ℓ sits within a few ulp of the threshold: the two-phase
+    march adds a track's lengths in another order than the reference's left-to-right sum, decides by margin, and hands the
+    tracks inside the margin to k_finish's left-to-right sum — statuses equal the checker's, and rt_last_stats counts them."""
+    from raytracing_jl_amd import _capi
+
+    tg0 = traced(16, 1e-2)
+    om = orc.OracleMesh.from_mesh(tg0.mesh, omp=True)
+    kw = dict(cos_phi=tg0.cos_phi, sin_phi=tg0.sin_phi, tiny_step=tg0.tiny_step, n_threads=0)
+    base = om.segmentize(tg0.px, tg0.py, tg0.phi, tg0.A, tg0.B, tg0.C, tg0.ell, **kw)
+    rtol = 1e-6
+    ell = tg0.ell.copy()
+    picked = list(range(0, len(ell), 7))[:200]
+    for n, u in enumerate(picked):
+        seg = base["ell"][base["offsets"][u]:base["offsets"][u + 1]]
+        S = 0.0
+        for v in seg:  # left to right, as the reference's check (and the checker) add
+            S += float(v)
+        L = S / (1.0 - rtol)  # |L − S| = rtol·L up to rounding
+        ell[u] = np.nextafter(L, np.inf if n % 2 else -np.inf) if n % 3 else L
+        for _ in range(n % 5):
+            ell[u] = np.nextafter(ell[u], np.inf if n % 2 else -np.inf)
+    ref = om.segmentize(tg0.px, tg0.py, tg0.phi, tg0.A, tg0.B, tg0.C, ell, rtol=rtol, **kw)
+    assert 0 < np.count_nonzero(ref["status"][picked] == 2) < len(picked)  # some fail, some pass: the threshold is hit from both sides
+    for opts in (dict(split=0), dict(split=0, compact=0), dict(split=0, topo=0), dict()):
+        dm = _capi.DeviceMesh(tg0.mesh, 0)
+        for k, v in opts.items():
+            dm.set_option(k, v)
+        dt = _capi.DeviceTracks(dm, tg0.px, tg0.py, tg0.phi, tg0.cos_phi, tg0.sin_phi, tg0.A, tg0.B, tg0.C, ell, tg0.azim_idx)
+        aq = tg0.azimuthal_quadrature
+        assert dt.segmentize(tg0.tiny_step, 5, rtol, aq.delta_s, aq.n_azim_2) == ref["total"]
+        off, st = dt.fetch_offsets()
+        assert dt.stats()["tracks_near_rtol"] >= len(picked) // 2, dt.stats()
+        if opts:
+            assert np.array_equal(st, ref["status"]), opts
+            n_fail, first, first_status = dt.failed()
+            assert n_fail == np.count_nonzero(ref["status"]) and first == np.flatnonzero(ref["status"])[0] + 1 and first_status == 2
+        else:
+            # (a batch this small marches in pieces by default: Σℓ is then the sum of the pieces' sums — the statistic flags the
+            #  tracks whose status that can change, and only those differ)
+            differ = np.flatnonzero(st != ref["status"])
+            assert set(differ.tolist()) <= set(picked), differ
+        dt.close(); dm.close()
+
+
 def test_shifted_anisotropic_domain(rt, orc, pincell):
     xy = pincell.node_coordinates * np.array([1.7, 0.6]) + np.array([3.25, -2.5])
     model = rt.DiscreteModel(xy, pincell.cell_node_ids)
@@ -149,7 +194,14 @@ def test_single_track_and_empty_batch(rt, orc, traced):
                                   dict(sort_mode=0), dict(sort_mode=1), dict(fuse_volumes=0), dict(split=48), dict(split=8), dict(split=20, walk=0),
                                   dict(split=24, test_volumes_fallback=1), dict(split=24, fuse_volumes=0),
                                   dict(split=0), dict(split=0, topo=0), dict(split=0, pool_chunks_hint=8), dict(split=0, sort_mode=0),
-                                  dict(split=0, test_out_records=20000)])
+                                  dict(split=0, test_out_records=20000),
+                                  # the two-phase march (whole tracks, cheap steps: codes + k_materialise): its side list overflowing, every
+                                  # track's Σℓ check by k_finish's left-to-right sum (also with truncated records: the deferred second pass),
+                                  # every cheap record's fill_volumes term / none of them added by k_materialise, codes on a mesh-order march
+                                  dict(split=0, side_entries_hint=16), dict(split=0, test_exact_sums=1),
+                                  dict(split=0, test_exact_sums=1, test_out_records=20000), dict(split=0, test_tally_tau=-1),
+                                  dict(split=0, test_tally_tau=1), dict(split=0, test_tally_tau=20000000), dict(split=0, compact=0),
+                                  dict(split=0, compact=0, test_exact_sums=1), dict(split=0, topo=2, sort_mode=1)])
 def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
     from raytracing_jl_amd import _capi
 
@@ -168,6 +220,32 @@ def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
     for k in FIELDS:
         assert np.array_equal(s[k], ref[k]), k
     assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
+
+
+def test_two_phase_march_regime_and_memory(rt, traced, oracle_run):
+    """Whole-track batches on a mesh with cheap-step records march in two phases: k_march stages one 4-B word per record (and the
+    generic step's records in a side list), k_materialise computes the 44-B records.  The handle then holds the word pool, not
+    (q, ±cell) rows with sparse entry points: 4 instead of 36 B per staging slot."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    held = {}
+    for topo in (1, 0):
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        dm.set_option("split", 0)
+        dm.set_option("topo", topo)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        aq = tg.azimuthal_quadrature
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+        st = dt.stats()
+        assert (st["cheap_records"] > 0.9 * ref["total"]) == (topo == 1)
+        held[topo] = st["device_bytes"]
+        assert np.array_equal(dt.fetch_segments()["ell"], ref["ell"])
+        dt.close(); dm.close()
+    slots = st["chunks_allocated"] * 32 * 64
+    assert held[0] - held[1] > 24 * slots, (held, slots)  # 36 B -> 4 B per slot, minus the side list (40 B per track + ...)
+    print(f"device bytes held: two-phase {held[1]}, exact-step staging {held[0]} ({slots} staging slots)")
 
 
 def test_staging_pool_overflow_is_recovered(rt, traced, oracle_run):

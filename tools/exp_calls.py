@@ -17,6 +17,6 @@ import time
 for _ in range(4):
     dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
 t0 = time.perf_counter()
-for _ in range(100):
+for _ in range(int(os.environ.get("CALLS", "100"))):
     total = dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
-print("segments", total, "ms per step %.4f" % ((time.perf_counter() - t0) / 100 * 1e3))
+print("segments", total, "ms per step %.4f" % ((time.perf_counter() - t0) / int(os.environ.get("CALLS", "100")) * 1e3))
