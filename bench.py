@@ -43,12 +43,14 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 # Algorithmic bytes per segment of each kernel of a step.  The march's figure is
-# SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input (the march itself stages
-# only 20 B of it: q and the cell).  The compaction reads those 20 B from the staging pool, rebuilds p
-# and ℓ, and writes the 44-B record to its CSR position.
+# SURVEY.md §8(d)'s: 44 B of record written + ≈1.3 B of amortised track input.  Round 4's two-phase march (whole-track batches
+# with cheap steps) stages ONE 4-B word per record; k_materialise reads it, computes p, q, ℓ and writes the 44-B record to
+# its CSR position: 48 B/segment ("compact" below is that phase: k_materialise + k_finish).  Batches that march with exact
+# steps stage (q, ±cell) rows, 20 B, and k_compact3 moves 64 B/segment.
 BYTES_PER_SEGMENT = {"march": 45.0, "compact": 64.0, "scan": 0.0}
+BYTES_PER_SEGMENT_TWO_PHASE = {"march": 45.0, "compact": 48.0, "scan": 0.0}
 STEP_BYTES_PER_SEGMENT = 45.0  # the whole step, by the same definition (what one segmentize! must at least move)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "pmc_summary.json")
 
 WORKLOADS = {
     "c3": dict(mesh="pincell.msh", n_azim=128, delta=1e-3, name="BASELINE configs[2]: demo/pincell.msh, nφ=128, δ=1e-3"),
@@ -71,9 +73,9 @@ def pmc_traffic():
     try:
         d = json.load(open(PMC_SUMMARY))
         if d.get("lib_sha256") != lib_sha256():
-            return {}, "profiles/r03/pmc_summary.json was taken from another build of the library"
+            return {}, "profiles/r04/pmc_summary.json was taken from another build of the library"
         return ({k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in d["kernels"].items()
-                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r03/pmc_summary.json (same library, sha256 match)")
+                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r04/pmc_summary.json (same library, sha256 match)")
     except Exception as e:
         return {}, "no PMC summary: %r" % (e,)
 
@@ -86,7 +88,12 @@ def kernel_names(stats):
     cheap = stats.get("cheap_records", 0) > 0  # the TOPO instantiation (cheap steps) ran
     return {"march": "rt::k_march<2, %d, %s, %s, false, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
                                                                   "true" if cheap else "false"),
-            "compact": "rt::k_compact3<%s>" % ("true" if sp else "false"), "scan": "rt::k_scan_write"}
+            "compact": "rt::k_materialise<true, false>" if cheap else "rt::k_compact3<%s>" % ("true" if sp else "false"),
+            "scan": "rt::k_scan_write"}
+
+
+def bytes_per_segment(stats):
+    return BYTES_PER_SEGMENT_TWO_PHASE if stats.get("cheap_records", 0) > 0 else BYTES_PER_SEGMENT
 
 
 def make_tg(rt, wl):
@@ -116,6 +123,13 @@ def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=Non
     t0 = time.perf_counter()
     dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
     h2d_ms = (time.perf_counter() - t0) * 1e3
+    h2d_again_ms = None
+    if e2e:  # a second handle on the same arrays: the library keeps its page-locked staging block from the second upload of a process on
+        for _ in range(2):
+            t0 = time.perf_counter()
+            dt2 = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+            h2d_again_ms = (time.perf_counter() - t0) * 1e3
+            dt2.close()
     run_steps(rt, dt, tg, aq, warmup)
     total, el = run_steps(rt, dt, tg, aq, steps)
     dm.set_option("timing", 1)
@@ -129,7 +143,8 @@ def single_gpu_run(rt, _capi, wl, device, steps, warmup, stream_ptr=None, tg=Non
         try:
             out["e2e"] = boundary_costs(dt, total)
             out["e2e"].update({"mesh_create_ms": mesh_ms, "mesh_prep_host_ms": dm.info()["prep_ms"], "tracks_h2d_ms": h2d_ms,
-                               "segmentize_ms": out["ms_per_step"]})
+                               "tracks_h2d_again_ms": h2d_again_ms, "segmentize_ms": out["ms_per_step"]})
+            one_shot(out["e2e"])
         except Exception as e:  # pragma: no cover
             out["e2e"] = {"error": repr(e)}
     dt.close()
@@ -201,6 +216,16 @@ def stream_ordered_calls(rt, tg, aq, dmesh, dt, steps, segments_per_step):
         return {"error": repr(e)}
 
 
+def one_shot(e):
+    """One call as the reference makes it (segmentize! runs once per TrackGenerator, src/trackgenerator.jl:357-369): track arrays in,
+    the step, all eight result arrays out — on a mesh handle that exists."""
+    e["one_shot_ms"] = e["tracks_h2d_ms"] + e["segmentize_ms"] + e["fetch_pinned_all_ms"]
+    if e.get("tracks_h2d_again_ms") is not None:
+        e["one_shot_again_ms"] = e["tracks_h2d_again_ms"] + e["segmentize_ms"] + e["fetch_pinned_all_ms"]
+    e["one_shot_note"] = ("tracks_h2d_ms + segmentize_ms + fetch_pinned_all_ms; `_again`: a process's later track sets go up through a "
+                          "page-locked block the library keeps (the first one from the caller's pageable arrays)")
+
+
 def boundary_costs(dt, total):
     """What the boundary adds around one step when the caller wants host arrays (never part of `value`): all eight result
     arrays through the handle's page-locked buffers in one call (rt_fetch_pinned), and the older pair of calls beside it."""
@@ -234,13 +259,15 @@ def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
                                 "Δ = (ψ − q/Σt)(−expm1(−τ)), ψ −= Δ, φ[cell] += w·Δ; boundary fluxes handed on through "
                                 "next_track_fwd/bwd + dir_next_track_* (Vacuum: 0); f64"}
     seg = lambda: dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
-    for name, compact in (("compact", 1), ("staged", 0)):
+    # "compact": the CSR records (ℓ, cell) as a caller with the reference's layout holds them; "staged": a call that wrote no records
+    # ("compact" = 0: k_materialise leaves (ℓ, cell) rows in the march's slot order instead); "auto": the default input after an
+    # ordinary call — the rows are built from the staged words once per segmentation (`first_sweep_ms` includes that)
+    for key, compact, name in (("compact", 1, "compact"), ("staged", 0, "staged"), ("auto", 1, "auto")):
         dmesh.set_option("compact", compact)
         seg()
         r = dt.sweep(G, sig, src, None, None, input=name, fetch=False)
         ms = min(dt.sweep(G, input=name, fetch=False)["ms"] for _ in range(5))
-        # per segment, direction and pass over a slab of groups: the compact records' (ℓ, cell), or the staged (ℓ, cell) rows that the
-        # first staged pass after a segmentize leaves behind (that pass itself reads the 20-B exit-point rows: `first_sweep_ms`)
+        # per segment, direction and pass over a slab of groups: (ℓ, cell), 12 B — CSR records or rows
         row_bytes = 12.0
         nbytes = total * 2.0 * r["passes"] * row_bytes
         t0 = time.perf_counter()
@@ -258,7 +285,7 @@ def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
         dt.wait()
         b2b_ms = (time.perf_counter() - t0) / 10 * 1e3
         dmesh.set_option("async", 0)
-        out[name] = {"sweep_ms": ms, "sweeps_back_to_back_ms": b2b_ms, "first_sweep_ms": r["ms"], "passes": r["passes"], "groups_per_pass": r["groups_per_pass"], "bytes_per_segment": 2.0 * r["passes"] * row_bytes,
+        out[key] = {"input": r["input"], "sweep_ms": ms, "sweeps_back_to_back_ms": b2b_ms, "first_sweep_ms": r["ms"], "passes": r["passes"], "groups_per_pass": r["groups_per_pass"], "bytes_per_segment": 2.0 * r["passes"] * row_bytes,
                      "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "segment_group_updates_per_s": total * 2.0 * G / (ms * 1e-3),
                      "ms_per_step_segmentize_plus_sweep": step_ms}
     dmesh.set_option("compact", 0)
@@ -512,7 +539,8 @@ def _main(real_stdout):
                     ms_step = t_max / args.steps * 1e3
                     per_k = {key: kern[key] / args.steps for key in ("march", "compact")}
                     dom = max(per_k, key=per_k.get)
-                    ach = BYTES_PER_SEGMENT[dom] * local_total / (per_k[dom] * 1e-3) / 1e9 if per_k[dom] > 0 else 0.0
+                    bps_fb = bytes_per_segment(stats)
+                    ach = bps_fb[dom] * local_total / (per_k[dom] * 1e-3) / 1e9 if per_k[dom] > 0 else 0.0
                     fb = {"metric": "segments/sec (whole node)", "value": global_segments * args.steps / t_max, "unit": "segments/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -521,7 +549,7 @@ def _main(real_stdout):
                                      "tracks_global": int(tg.n_total_tracks), "segments_global": int(global_segments),
                                      "failed_tracks": failed_tracks},
                           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_segment": BYTES_PER_SEGMENT[dom],
+                                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_segment": bps_fb[dom],
                                        "segments_per_launch": int(local_total), "kernel_ms_avg": per_k[dom]},
                           "kernel_ms": {k: v / args.steps for k, v in kern.items()}, "per_rank": per_rank,
                           "allreduce_ms_exposed": allreduce_exposed_ms,
@@ -619,6 +647,16 @@ def _main(real_stdout):
         seg_ms = (time.perf_counter() - a) * 1e3
         e2e = boundary_costs(dt, local_total)
         e2e.update({"mesh_create_ms": mesh_create_ms, "mesh_prep_host_ms": info["prep_ms"], "tracks_h2d_ms": tracks_h2d_ms, "segmentize_ms": seg_ms})
+        try:
+            for _ in range(2):
+                a = time.perf_counter()
+                dt2 = _capi.DeviceTracks(dmesh, tg.px[lo:hi], tg.py[lo:hi], tg.phi[lo:hi], tg.cos_phi[lo:hi], tg.sin_phi[lo:hi], tg.A[lo:hi], tg.B[lo:hi],
+                                         tg.C[lo:hi], tg.ell[lo:hi], tg.azim_idx[lo:hi])
+                e2e["tracks_h2d_again_ms"] = (time.perf_counter() - a) * 1e3
+                dt2.close()
+        except Exception as e:  # pragma: no cover
+            e2e["tracks_h2d_again_ms"] = None
+        one_shot(e2e)
     downstream_sweep = None
     if rank == 0 and not args.no_extras and not dist_on:
         try:
@@ -656,9 +694,10 @@ def _main(real_stdout):
         names = kernel_names(stats)
         traffic, traffic_src = pmc_traffic()
         per_kernel = []
+        bps_by_phase = bytes_per_segment(stats)
         for key in ("march", "compact", "scan"):
             ms = kern[key] / args.steps
-            bps = BYTES_PER_SEGMENT[key]
+            bps = bps_by_phase[key]
             per_kernel.append({"kernel": names[key], "ms_avg": ms, "bytes_per_segment": bps,
                                "achieved_GBs": bps * local_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                                "traffic": traffic.get(names[key]) if wkey == "c3" and world == 1 else None})
@@ -690,7 +729,12 @@ def _main(real_stdout):
                 "tiny_step": tg.tiny_step, "k": 5, "rtol": rt.RTOL_DEFAULT, "failed_tracks": failed_tracks,
                 "march_plan": {0: "whole tracks", 1: "every track in pieces", 2: "hybrid: the longest waves in pieces beside the whole-track march"}[stats["split"]],
                 "regime": {"walk_enabled": info["walk_enabled"], "records_walkable": info["records_walk"], "records": info["records"],
-                           "walk_records_rank0": stats["walk_records"], "generic_records_rank0": stats["generic_records"]},
+                           "walk_records_rank0": stats["walk_records"], "generic_records_rank0": stats["generic_records"],
+                           "cheap_records_rank0": stats["cheap_records"], "two_phase": stats["cheap_records"] > 0,
+                           "cheap_refusals_rank0": stats["cheap_refusals"], "tracks_restarted_rank0": stats["tracks_restarted"],
+                           # tracks whose Σℓ check (src/track.jl:171) lies within summation-order noise of its threshold: Julia's
+                           # pairwise / @simd sum could decide them the other way — what cannot be pinned without the real package
+                           "tracks_near_rtol_rank0": stats["tracks_near_rtol"]},
                 "device_GB_held_by_rank0_handle": stats["device_bytes"] / 1e9,
                 "library_sha256": lib_sha256(),
             },
@@ -711,6 +755,9 @@ def _main(real_stdout):
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},
             "kernel_ms_note": "from a second pass of the same K steps with the library's HIP events on (option \"timing\"); "
                               "that pass took %.4f ms per step" % (elapsed_with_events / args.steps * 1e3),
+            # what a synchronous call adds around its kernels: completion seen by the host, the return through the caller, the next
+            # call's launches (the kernels of one call run back to back)
+            "host_gap_us": (ms_per_step - (kern["march"] + kern["scan"] + kern["compact"] + kern["volumes"]) / args.steps) * 1e3 if world == 1 else None,
         }
         if per_rank is not None:
             out["per_rank"] = per_rank  # load balance of the Σℓ-balanced uid ranges

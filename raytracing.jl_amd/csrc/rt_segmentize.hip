@@ -21,6 +21,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_segmentize.h"
@@ -1101,6 +1102,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         }
         counts[u] = i;
         status[u] = st;
+        if (TOPO) t.cnt_slot[slot] = i;  // (k_materialise reads its units' counts in slot order)
         {
             // per-call statistic (rt_last_stats): records the generic step produced, summed over the wave's active lanes
             // bit by bit with ballots (n_generic <= kMaxIter < 2^14)
@@ -1442,14 +1444,18 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
     const int q = (int)(unit & 3);
     const int64_t slot = w * 64 + 16 * q + tl;
     // every lane holds its load-mapping track's uid, count, offset and line (the 4 lanes of a track load the same words)
+    // (everything a unit needs first is read in march-slot order, side by side: counts, offsets, lines, the wave's first chunk id)
     int32_t cnt = 0, u = 0;
     int64_t off = 0;
     double tA = 0.0, tB = 0.0, tC = 0.0;
     const bool have = slot < t.n;
+    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
+    const int32_t c_first = ctab[kw];
     if (have) {
         u = t.perm[slot];
-        cnt = counts[u];
-        off = offsets[u];
+        cnt = t.cnt_slot[slot];
+        off = t.off_slot[slot];
+        tA = t.As[slot]; tB = t.Bs[slot]; tC = t.Cs[slot];
     }
     if (threadIdx.x < 16) { scnt[tl] = cnt; soff[tl] = off; s_sum[tl] = 0.0; }
     int32_t gmax = cnt;
@@ -1458,15 +1464,13 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
         gmax = v > gmax ? v : gmax;
     }
     gmax = __shfl(gmax, 0, 64);
-    if ((kw << kChunkLog2) < gmax && have) { tA = t.A[u]; tB = t.B[u]; tC = t.C[u]; }
     __syncthreads();
-    const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
     const int lane_q = 16 * q + tl;
     const int tb = tl * kC3Pitch;
     double acc = 0.0;  // Σℓ of this lane's rows of its load-mapping track
     for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
         const int r0 = j << kChunkLog2;
-        const int32_t c = ctab[j];
+        const int32_t c = j == kw ? c_first : ctab[j];
         // ---- the chunk's words, in the load mapping (lane = track tl, rows 4 i + rr)
         int32_t ve[8];
 #pragma unroll
@@ -1786,7 +1790,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__rest
                                                            const int64_t *__restrict__ total,
                                                            int64_t *__restrict__ offsets,
                                                            double *__restrict__ volumes, int32_t n_cells,
-                                                           double n_azim_2, double *__restrict__ vacc) {
+                                                           double n_azim_2, double *__restrict__ vacc,
+                                                           const int32_t *__restrict__ iperm, int64_t *__restrict__ off_slot) {
     // volumes ./= n_azim_2 (src/trackgenerator.jl:386) rides along when fill_volumes was fused into the march: the march
     // accumulated into `vacc`, which is read, scaled into `volumes` and left ZERO for the next call's march
     if (volumes)
@@ -1817,7 +1822,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__rest
     int64_t run = tile_offsets[blockIdx.x] + wave_off + incl - s;
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
-        if (i0 + j < n) offsets[i0 + j] = run;
+        if (i0 + j < n) {
+            offsets[i0 + j] = run;
+            if (iperm) off_slot[iperm[i0 + j]] = run;  // (the offsets in march-slot order, for k_materialise)
+        }
         run += c[j];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *total;
@@ -2262,12 +2270,26 @@ struct rt_mesh {
     double eps_min = 0.0, eps_max = 0.0, prep_ms = 0.0;
 };
 
+// A piece of a handle's input arena (one device allocation, filled by one host-to-device copy).
+template <typename T>
+struct DevView {
+    T *p = nullptr;
+    size_t cap = 0;  // (counted with the arena, not here)
+    void release() { p = nullptr; }
+};
+
 struct rt_tracks {
     rt_mesh *mesh = nullptr;
     int64_t n = 0;
-    DevBuf<double> px, py, phi, cs, sn, A, B, C, ell;
-    DevBuf<int32_t> corder;  // march waves sorted by the uid of their first track (the compaction order of large batches)
-    DevBuf<int32_t> azim, perm, perm_whole;  // perm: march order of all tracks; perm_whole: of those the hybrid plan marches whole
+    DevBuf<unsigned char> in_arena;  // px | py | phi | cos ϕ | sin ϕ | A | B | C | ℓ | A, B, C in march order | azim_idx | march order | its inverse | compaction order
+    DevView<double> px, py, phi, cs, sn, A, B, C, ell;
+    DevView<int32_t> corder;  // march waves sorted by the uid of their first track (the compaction order of large batches)
+    DevView<int32_t> azim, perm;  // perm: march order of all tracks
+    DevView<double> As, Bs, Cs;   // the track lines in march order (k_materialise)
+    DevView<int32_t> iperm;       // uid -> march slot
+    DevBuf<int32_t> cnt_slot;     // record counts / CSR offsets in march-slot order (whole-track two-phase calls)
+    DevBuf<int64_t> off_slot;
+    DevBuf<int32_t> perm_whole;  // ... of those the hybrid plan marches whole
     rt::DTracks d{};
     // results
     bool segmentized = false;
@@ -2611,6 +2633,7 @@ int ensure_rows(rt_tracks *t) {
 void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->perm_whole.release(); t->corder.release();
+    t->in_arena.release(); t->cnt_slot.release(); t->off_slot.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
     t->tile_sums.release(); t->ctl.release(); t->vacc.release();
 #ifdef RT_TIMING
@@ -2639,6 +2662,69 @@ void free_tracks(rt_tracks *t) {
 }
 
 }  // namespace
+
+// Page-locked staging blocks for the upload of a track set: kept process-wide (pinning costs milliseconds), one per concurrent
+// caller (rt_multi_create uploads its shards from several threads).
+namespace {
+struct StagingBlock { void *p = nullptr; size_t cap = 0; bool busy = false; };
+std::vector<StagingBlock> g_staging;
+std::mutex g_staging_mutex;
+long g_staging_calls = 0;
+// allocate: pin a new block when none fits (milliseconds per 10 MB: only worth it for a process that uploads track sets repeatedly)
+int staging_acquire(size_t bytes, void **out, bool *allocate_if_missing) {
+    std::lock_guard<std::mutex> lk(g_staging_mutex);
+    const bool alloc = g_staging_calls++ > 0;  // a process's first track set goes up from the caller's pageable arrays
+    if (allocate_if_missing) *allocate_if_missing = alloc;
+    for (size_t i = 0; i < g_staging.size(); ++i)
+        if (!g_staging[i].busy && g_staging[i].cap >= bytes) { g_staging[i].busy = true; *out = g_staging[i].p; return (int)i; }
+    if (!alloc) return -1;
+    for (size_t i = 0; i < g_staging.size(); ++i)
+        if (!g_staging[i].busy) {  // too small: replace it
+            if (g_staging[i].p) (void)hipHostFree(g_staging[i].p);
+            g_staging[i] = StagingBlock{};
+            const size_t cap = bytes + bytes / 8 + 4096;
+            if (hipHostMalloc(&g_staging[i].p, cap, hipHostMallocDefault) != hipSuccess) { g_staging[i].p = nullptr; return -1; }
+            g_staging[i].cap = cap; g_staging[i].busy = true; *out = g_staging[i].p;
+            return (int)i;
+        }
+    StagingBlock b;
+    const size_t cap = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&b.p, cap, hipHostMallocDefault) != hipSuccess) return -1;
+    b.cap = cap; b.busy = true;
+    g_staging.push_back(b);
+    *out = b.p;
+    return (int)g_staging.size() - 1;
+}
+void staging_release(int slot) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_staging_mutex);
+    g_staging[(size_t)slot].busy = false;
+}
+// f(i0, i1) over [0, n) on a few host threads (results must not depend on the split); what a worker throws is rethrown here
+template <typename F>
+void par_ranges(size_t n, size_t grain, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n / std::max<size_t>(grain, 1) + 1}));
+    if (nt == 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(nt);
+    size_t done = 0;
+    try {
+        for (unsigned k = 0; k + 1 < nt; ++k) {
+            const size_t i0 = n * k / nt, i1 = n * (k + 1) / nt;
+            std::exception_ptr *slot = &err[k];
+            th.emplace_back([=, &f]() { try { f(i0, i1); } catch (...) { *slot = std::current_exception(); } });
+            done = i1;
+        }
+    } catch (...) {  // no thread to be had: the caller's thread does the rest
+    }
+    try { f(done, n); } catch (...) { err[nt - 1] = std::current_exception(); }
+    for (auto &x : th) x.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+}
+}  // namespace
+
 
 // ------------------------------------------------------------------- C ABI ---------------
 extern "C" {
@@ -2832,20 +2918,36 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     // tracks of one angle cross the same cells at the same time (shared walk records, coherent
     // branches) and have nearly equal lengths; sorting individual tracks by length measured 20 %
     // slower because it scatters the lanes of a wave over the whole mesh.
+    // (one call is what the reference makes, src/trackgenerator.jl:357-369: the host's share of it — wave maxima, the fills,
+    //  the copy into the staging block — runs on a few threads; the sorts are over waves, not tracks)
     std::vector<int32_t> perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
     if (mesh->sort_mode == 1) {
+        std::iota(perm.begin(), perm.end(), 0);
         std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
     } else if (mesh->sort_mode == 2) {
         const size_t nw = (n + 63) / 64;
         std::vector<double> wmax(nw, 0.0);
-        for (size_t i = 0; i < n; ++i) wmax[i / 64] = std::max(wmax[i / 64], ell[i]);
+        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                double mx = 0.0;
+                for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[i]);
+                wmax[w] = mx;
+            }
+        });
         std::vector<int32_t> worder(nw);
         std::iota(worder.begin(), worder.end(), 0);
         std::stable_sort(worder.begin(), worder.end(), [&](int32_t a, int32_t b) { return wmax[a] > wmax[b]; });
-        size_t k2 = 0;
-        for (size_t w = 0; w < nw; ++w)
-            for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
+        // the batch's last wave of uids may be partial: the slots behind it are packed (no padding), so its position shifts them
+        std::vector<size_t> first(nw + 1, 0);
+        for (size_t w = 0; w < nw; ++w) first[w + 1] = first[w] + std::min<size_t>(64, n - (size_t)worder[w] * 64);
+        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                size_t k2 = first[w];
+                for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
+            }
+        });
+    } else {
+        std::iota(perm.begin(), perm.end(), 0);
     }
     std::vector<int32_t> h_corder;
     if (nw_all_early(n) > 4096) {  // batches of many rounds: compaction in output order (measured -8 % at 16 k waves, +1.5 % at 2 k)
@@ -2854,10 +2956,22 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         std::iota(h_corder.begin(), h_corder.end(), 0);
         std::stable_sort(h_corder.begin(), h_corder.end(), [&](int32_t a, int32_t b) { return perm[(size_t)a * 64] < perm[(size_t)b * 64]; });
     }
-    for (size_t i = 0; i < n; ++i) t->sum_ell += ell[i];
+    {
+        // Σℓ in a fixed order (blocks of 4096 tracks, added in block order) whatever the number of threads; range of azim_idx
+        const size_t nb = (n + 4095) / 4096;
+        std::vector<double> bs(nb, 0.0);
+        std::vector<int32_t> bmin(nb, 0x7fffffff), bmax(nb, (int32_t)0x80000000);
+        par_ranges(nb, 16, [&](size_t b0, size_t b1) {
+            for (size_t b = b0; b < b1; ++b) {
+                double sl = 0.0;
+                int32_t lo = 0x7fffffff, hi = (int32_t)0x80000000;
+                for (size_t i = b * 4096; i < std::min(n, b * 4096 + 4096); ++i) { sl += ell[i]; lo = std::min(lo, azim_idx[i]); hi = std::max(hi, azim_idx[i]); }
+                bs[b] = sl; bmin[b] = lo; bmax[b] = hi;
+            }
+        });
+        for (size_t b = 0; b < nb; ++b) { t->sum_ell += bs[b]; t->azim_min = std::min(t->azim_min, bmin[b]); t->azim_max = std::max(t->azim_max, bmax[b]); }
+    }
     if (n > 0) {
-        t->azim_min = *std::min_element(azim_idx, azim_idx + n);
-        t->azim_max = *std::max_element(azim_idx, azim_idx + n);
         if (t->azim_min < 1) {  // δs[azim_idx] is read on the device (fill_volumes, src/trackgenerator.jl:379-382)
             set_error("rt_tracks_create: azim_idx must be 1-based (smallest value %d)", t->azim_min);
             return nullptr;
@@ -2932,11 +3046,58 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             h_w_base.clear(); h_w_P.clear();
         }
     }
-    bool ok = upload(t->px, px, n, s) == 0 && upload(t->py, py, n, s) == 0 && upload(t->phi, phi, n, s) == 0 &&
-              upload(t->cs, cos_phi, n, s) == 0 && upload(t->sn, sin_phi, n, s) == 0 && upload(t->A, A, n, s) == 0 &&
-              upload(t->B, B, n, s) == 0 && upload(t->C, C, n, s) == 0 && upload(t->ell, ell, n, s) == 0 &&
-              upload(t->azim, azim_idx, n, s) == 0 && upload(t->perm, perm.data(), n, s) == 0 &&
-              (h_corder.empty() || upload(t->corder, h_corder.data(), h_corder.size(), s) == 0);
+    // One device allocation, one page-locked staging block (kept process-wide), one host-to-device copy: the eleven pageable
+    // uploads into eleven allocations of round 3 were 31.7 ms of a C5 call whose kernels take 3.
+    bool ok = true;
+    {
+        const size_t na = (n + 31) & ~(size_t)31;  // every array starts on a 256-B boundary
+        const size_t ncord = (h_corder.size() + 63) & ~(size_t)63;
+        const size_t bytes = 12 * na * sizeof(double) + 3 * na * sizeof(int32_t) + ncord * sizeof(int32_t) + 256;
+        void *stage = nullptr;
+        bool may_pin = false;
+        const int slot = staging_acquire(bytes, &stage, &may_pin);
+        struct Rel { int s; ~Rel() { staging_release(s); } } rel{slot};
+        ok = t->in_arena.reserve(bytes) == hipSuccess;
+        unsigned char *db = t->in_arena.p;
+        const double *src8[9] = {px, py, phi, cos_phi, sin_phi, A, B, C, ell};
+        DevView<double> *dst8[12] = {&t->px, &t->py, &t->phi, &t->cs, &t->sn, &t->A, &t->B, &t->C, &t->ell, &t->As, &t->Bs, &t->Cs};
+        if (ok) {
+            for (int a = 0; a < 12; ++a) dst8[a]->p = (double *)(db + (size_t)a * na * sizeof(double));
+            t->azim.p = (int32_t *)(db + 12 * na * sizeof(double)); t->perm.p = t->azim.p + na; t->iperm.p = t->perm.p + na;
+            t->corder.p = h_corder.empty() ? nullptr : t->iperm.p + na;
+        }
+        // the host image of the arena: the staging block, or — a process's first track set, before anything is pinned — only the
+        // derived arrays in a pageable vector (the caller's arrays then go up from where they lie)
+        std::vector<unsigned char> derived;
+        unsigned char *hb = (unsigned char *)stage;
+        const size_t derived_off = 9 * na * sizeof(double);
+        if (ok && slot < 0) derived.resize(bytes - derived_off);
+        if (ok) {
+            unsigned char *hd = slot >= 0 ? hb + derived_off : derived.data();  // the derived arrays' part of the image
+            double *h_As = (double *)hd, *h_Bs = h_As + na, *h_Cs = h_Bs + na;
+            int32_t *h_az = (int32_t *)(hd + 3 * na * sizeof(double)), *h_pm = h_az + na, *h_ip = h_pm + na, *h_co = h_ip + na;
+            par_ranges(n, 16384, [&](size_t i0, size_t i1) {
+                if (slot >= 0)
+                    for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * na * sizeof(double)) + i0, src8[a] + i0, (i1 - i0) * sizeof(double));
+                memcpy(h_az + i0, azim_idx + i0, (i1 - i0) * sizeof(int32_t));
+                memcpy(h_pm + i0, perm.data() + i0, (i1 - i0) * sizeof(int32_t));
+                for (size_t i = i0; i < i1; ++i) {  // (slot i holds track perm[i])
+                    const int32_t u = perm[i];
+                    h_As[i] = A[u]; h_Bs[i] = B[u]; h_Cs[i] = C[u];
+                    h_ip[u] = (int32_t)i;
+                }
+            });
+            if (!h_corder.empty()) memcpy(h_co, h_corder.data(), h_corder.size() * sizeof(int32_t));
+            if (slot >= 0) {
+                ok = hipMemcpyAsync(db, hb, bytes - 256, hipMemcpyHostToDevice, s) == hipSuccess;
+            } else {
+                for (int a = 0; a < 9 && ok && n > 0; ++a) ok = hipMemcpyAsync(dst8[a]->p, src8[a], n * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+                ok = ok && hipMemcpyAsync(db + derived_off, derived.data(), derived.size() - 256, hipMemcpyHostToDevice, s) == hipSuccess;
+            }
+            ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        }
+        ok = ok && t->cnt_slot.reserve(na + 64) == hipSuccess && t->off_slot.reserve(na + 64) == hipSuccess;
+    }
     if (ok && t->n_vwaves > 0) {
         const size_t np = (size_t)t->n_vwaves * 64;
         ok = upload(t->vorder, h_vorder.data(), h_vorder.size(), s) == 0 && upload(t->vw_wave, h_vw_wave.data(), h_vw_wave.size(), s) == 0 &&
@@ -2963,6 +3124,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     d.px = as_global(t->px.p); d.py = as_global(t->py.p); d.phi = as_global(t->phi.p); d.cs = as_global(t->cs.p);
     d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
     d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
+    d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.iperm = as_global(t->iperm.p);
+    d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p);
     d.n = n_tracks;
     guard.p = nullptr;
     return t;
@@ -3093,7 +3256,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
     int32_t first_chunk_this_call = 0, side_first_this_call = 0;
     // reset_other: the scan's last block also resets the OTHER control block for the next call (single-pass calls)
-    auto scan_counts = [&](bool copy_out, bool scale, bool reset_other) -> int {
+    auto scan_counts = [&](bool copy_out, bool scale, bool reset_other, bool slot_order = false) -> int {
         if (n > 0) {
             hipLaunchKernelGGL(rt::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, n_tiles, d_total, reinterpret_cast<unsigned int *>(d_ctl + 20),
@@ -3102,7 +3265,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                                ++t->call_seq);
             hipLaunchKernelGGL(rt::k_scan_write, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, t->counts.p, n,
                                t->tile_sums.p, d_total, t->offsets.p, scale ? t->volumes.p : (double *)nullptr, m->n_cells,
-                               (double)n_azim_2, t->vacc.p);
+                               (double)n_azim_2, t->vacc.p, slot_order ? (const int32_t *)t->iperm.p : (const int32_t *)nullptr, t->off_slot.p);
         } else {
             RT_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
             RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
@@ -3318,7 +3481,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                     if (hybrid) RT_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
                 }
                 if (int rc = rec(2)) return rc;
-                if (int rc = scan_counts(!topo, fuse && !topo, true)) return rc;  // (two-phase: k_finish scales the volumes, behind k_materialise)
+                if (int rc = scan_counts(!topo, fuse && !topo, true, topo)) return rc;  // (two-phase: k_finish scales the volumes, behind k_materialise)
                 if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
                 if (topo) {
                     // codes -> records (or, "compact" = 0, (ℓ, cell) rows) + Σℓ / status; k_finish completes them and copies the control
@@ -3944,7 +4107,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 19) stats[19] = t->n_restarts;
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
-        stats[7] = b(t->px) + b(t->py) + b(t->phi) + b(t->cs) + b(t->sn) + b(t->A) + b(t->B) + b(t->C) + b(t->ell) + b(t->azim) + b(t->perm) +
+        stats[7] = b(t->in_arena) + b(t->cnt_slot) + b(t->off_slot) +
                    b(t->perm_whole) + b(t->counts) + b(t->status) + b(t->element) + b(t->offsets) + b(t->tile_sums) + b(t->ctl) + b(t->spx) +
                    b(t->spy) + b(t->sqx) + b(t->sqy) + b(t->sell) + b(t->volumes) + b(t->volumes_prev) + b(t->delta_s) + b(t->gpx) + b(t->gpy) +
                    b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +
