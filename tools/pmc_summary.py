@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 --pmc passes (tools/pmc_passes.sh): per kernel, mean counter value per dispatch."""
+"""Summarise rocprofv3 --pmc passes (tools/pmc.sh): per kernel, mean counter value per dispatch."""
 import csv, glob, os, sys, collections, json
 root = sys.argv[1]
 out = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,6 +22,5 @@ if len(sys.argv) > 2:
     import hashlib
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracing.jl_amd", "csrc", "librt_segmentize.so")
     json.dump({"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
-               "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
-                         "(tools/pmc_passes.sh); mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
+               "source": "rocprofv3 --pmc passes (tools/pmc.sh, tools/prof.sh); mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
                "kernels": res}, open(sys.argv[2], "w"), indent=1)
