@@ -488,6 +488,7 @@ def _main(real_stdout):
     #                               a rank that exits alone would deadlock the others)
     stats = dt.stats()
     info = dmesh.info()
+    info_cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
     # ---- N > 1: the same K steps once more WITHOUT the volumes all-reduce — what the pipelined all-reduce still costs a step
     #      (its launch and whatever of its latency the next march does not cover) is the difference; load balance per rank
@@ -779,6 +780,21 @@ def _main(real_stdout):
         if same_workload is not None:
             out["single_gpu_same_workload"] = same_workload
             out["speedup_vs_single_gpu"] = same_workload["ms_per_step"] / ms_per_step
+        if dist_on:
+            # what a sub-linear curve is made of, in the line itself: a rank's shard is a smaller batch, and the march of a batch that
+            # no longer fills the chip lasts as long as its longest track's chain whatever the number of waves
+            waves = (int(hi - lo) + 63) // 64
+            simds = 4 * info_cus
+            out["shard_regime"] = {
+                "march_waves_rank0": waves, "simds": simds, "waves_per_simd_rank0": waves / simds,
+                "resident_waves_per_simd": 2,  # k_march<..., TOPO>: 200 VGPRs
+                "march_rounds_rank0": max(1.0, waves / (2.0 * simds)),
+                "ideal_ms_per_step": (same_workload["ms_per_step"] / world) if same_workload is not None else None,
+                "note": "strong scaling of a FIXED problem: with N ranks a shard has 1/N of the waves; below ~2 waves per SIMD every wave is "
+                        "resident from the start and the march is bound by the longest track's dependent chain (it does not shorten with N), "
+                        "while k_materialise / the scans scale with the shard — the step tends to (chain) + (records/N)/(HBM rate); "
+                        "ideal_ms_per_step = single_gpu_same_workload / N",
+            }
         if config5 is not None:
             out["config5_single_gpu"] = config5
         if downstream is not None:

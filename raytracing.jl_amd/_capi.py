@@ -39,11 +39,11 @@ class RtError(RuntimeError):
 
 def build(force: bool = False, extra: str = "") -> str:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp", "Makefile"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp", ".cpp", "Makefile"))]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "rt_segmentize.h"))
     fresh = os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)
     if force or not fresh:
-        cmd = ["make", "-C", _CSRC] + (["-B"] if force else []) + ([f"EXTRA={extra}"] if extra else [])
+        cmd = ["make", "-j4", "-C", _CSRC] + (["-B"] if force else []) + ([f"EXTRA={extra}"] if extra else [])
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
     return LIB_PATH
 

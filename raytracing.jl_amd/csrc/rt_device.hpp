@@ -171,7 +171,7 @@ RT_HD __forceinline__ bool near_bb(double x, double b, double atol) {
     return ((int)(x == b) | ((int)isfin(x) & (int)(fabs(x - b) <= tol))) != 0;
 }
 // atol == 0 (never in practice): out of line, so that its constants do not occupy scalar registers in the march
-RT_HD __noinline__ bool inboundary_general(double bx0, double by0, double bx1, double by1, double x, double y, double atol) {
+inline RT_HD __noinline__ bool inboundary_general(double bx0, double by0, double bx1, double by1, double x, double y, double atol) {
     return ((int)near_bb(x, bx1, atol) | (int)near_bb(x, bx0, atol) | (int)near_bb(y, by1, atol) | (int)near_bb(y, by0, atol)) != 0;
 }
 RT_HD __forceinline__ bool inboundary(const DMesh &m, double x, double y, double atol) {

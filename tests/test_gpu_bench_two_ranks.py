@@ -56,3 +56,29 @@ def test_bench_two_ranks_extras_watchdog():
         assert key in d, key
     assert d["n_gpus"] == 2 and d["config"]["segments_global"] == 114447177 and d["value"] > 0 and d["roofline"]["frac"] > 0
     assert "extras" in d and "allgather" not in d
+
+
+def test_bench_one_rank_rccl_group_runs_the_multi_gpu_path():
+    """`bench.py --force-dist`: the N > 1 code path on a REAL one-rank RCCL communicator (backend "nccl"), as a fresh child process —
+    the pipelined side-stream all-reduce of the volumes inside the timed region, the all-gather-v (`SegmentGather`) and the sharded
+    sweep's exchange (`--sharded-sweep`) on device tensors.  The two-rank tests above run over gloo (RCCL refuses two ranks on one
+    device); this is the one that drives the RCCL backend before the driver's first multi-GPU run does."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", "c5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--sharded-sweep", "--no-concurrent"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["segments_global"] == 114447177 and d["value"] > 0
+    # the keys of an N > 1 line
+    assert d["per_rank"]["segments"] == [114447177] and d["per_rank"]["tracks"] == [1043212]
+    assert d["allreduce_ms_exposed"] is not None and abs(d["allreduce_ms_exposed"]) < 1.0
+    assert "error" not in d["allgather"] and d["allgather"]["ms"] >= 0 and d["allgather"]["bytes_received_per_rank"] == 0.0
+    ss = d["sharded_sweep"]
+    assert "error" not in ss and ss["ms_per_sweep"] > 0 and ss["groups"] == 7, ss
+    reg = d["shard_regime"]
+    assert reg["march_waves_rank0"] == (1043212 + 63) // 64 and reg["march_rounds_rank0"] > 1
+    assert d["config"]["regime"]["two_phase"] is True

@@ -190,7 +190,7 @@ def test_single_track_and_empty_batch(rt, orc, traced):
     assert np.all(empty.fetch_volumes() == 0)
 
 
-@pytest.mark.parametrize("opts", [dict(single_pass=0), dict(single_pass=0, volumes_mode=1), dict(walk=0),
+@pytest.mark.parametrize("opts", [dict(walk=0),
                                   dict(sort_mode=0), dict(sort_mode=1), dict(fuse_volumes=0), dict(split=48), dict(split=8), dict(split=20, walk=0),
                                   dict(split=24, test_volumes_fallback=1), dict(split=24, fuse_volumes=0),
                                   dict(split=0), dict(split=0, topo=0), dict(split=0, pool_chunks_hint=8), dict(split=0, sort_mode=0),
@@ -399,34 +399,6 @@ def test_max_iter_counts_whole_tracks_even_when_marched_in_pieces(rt, orc):
     _same(tg, ref, check_volumes=False)
 
 
-@pytest.mark.parametrize("pct", [55, 80])
-def test_hybrid_plan_gives_identical_results(rt, traced, oracle_run, pct):
-    """"hybrid" = 1: on a batch that fills the chip only the longest waves are marched in pieces (split kernel, second
-    stream) beside the whole-track march of the rest.  An option kept for experiments; same records."""
-    from raytracing_jl_amd import _capi
-
-    tg = traced(128, 1e-3)
-    ref = oracle_run(tg)
-    dm = _capi.DeviceMesh(tg.mesh, 0)
-    dm.set_option("hybrid", 1)
-    dm.set_option("hybrid_pct", pct)
-    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
-    aq = tg.azimuthal_quadrature
-    for _ in range(2):
-        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
-    assert dt.stats()["split"] == 2
-    off, st = dt.fetch_offsets()
-    s = dt.fetch_segments()
-    assert np.array_equal(off, ref["offsets"]) and st.max() == 0
-    assert np.array_equal(s["element"], ref["element"])
-    for k in FIELDS:
-        assert np.array_equal(s[k], ref[k]), k
-    assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
-    # a wide k cannot use the plan: the same handle then marches every track whole
-    assert dt.segmentize(tg.tiny_step, 12, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
-    assert dt.stats()["split"] == 0 and np.array_equal(dt.fetch_segments()["element"], ref["element"])
-
-
 @pytest.mark.parametrize("opts", [dict(), dict(fuse_volumes=0), dict(split=24)])
 def test_short_output_estimate_is_recovered(rt, traced, oracle_run, opts):
     """The six output arrays are sized from an estimate of the record count; a call that produces more must grow them
@@ -504,52 +476,3 @@ def test_cheap_steps_keep_the_iteration_guard_exact(rt, orc, traced, iter_cap):
     print(f"iter_cap={iter_cap}: {stats}, failing {int(np.count_nonzero(st))}")
 
 
-@pytest.mark.parametrize("n_azim,delta,mesh", [(32, 5e-3, "pincell"), (16, 0.02, "bwr")])
-def test_first_records_by_k_first(rt, orc, traced, oracle_run, n_azim, delta, mesh):
-    """Option "first" = 1 (off by default: measured slower): every track's first record by k_first — eight lanes
-    per track ahead of the march — must leave the same records, counts, status and volumes as the march's own first step,
-    including the tracks that end right behind their first record (their xp lies in the END band)."""
-    from raytracing_jl_amd import _capi
-
-    model = None if mesh == "pincell" else rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
-    tg = traced(n_azim, delta, model=model) if model is not None else traced(n_azim, delta)
-    ref = oracle_run(tg)
-    aq = tg.azimuthal_quadrature
-    for topo in (0, 1):
-        dm = _capi.DeviceMesh(tg.mesh, 0)
-        dm.set_option("split", 0); dm.set_option("first", 1); dm.set_option("topo", topo)
-        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
-        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
-        off, st = dt.fetch_offsets()
-        s = dt.fetch_segments()
-        assert np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and np.array_equal(s["element"], ref["element"])
-        for k in FIELDS:
-            assert np.array_equal(s[k], ref[k]), k
-        assert np.allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10, atol=0)
-        dt.close(); dm.close()
-
-
-def test_compaction_in_memory_order_kernel(rt, traced, oracle_run):
-    """Option "compact_kernel" = 4: k_compact4 writes the records of a whole-track batch in memory order (built for batches whose
-    records run to gigabytes; measured no faster, so it only runs on request) — same records, bit for bit, incl. tracks
-    longer than one 128-row round and the re-compaction after an undersized output estimate."""
-    from raytracing_jl_amd import _capi
-
-    bwr = rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
-    for n_azim, delta, model, extra in ((16, 2e-2, bwr, {}), (8, 2e-2, None, {"test_out_records": 1000})):
-        tg = traced(n_azim, delta, model=model) if model is not None else traced(n_azim, delta)
-        ref = oracle_run(tg)
-        dm = _capi.DeviceMesh(tg.mesh, 0)
-        dm.set_option("split", 0); dm.set_option("compact_kernel", 4)
-        for k, v in extra.items():
-            dm.set_option(k, v)
-        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
-        aq = tg.azimuthal_quadrature
-        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
-        assert model is None or np.diff(ref["offsets"]).max() > 128  # (BWR-like: some tracks span more than one 128-row round)
-        off, st = dt.fetch_offsets()
-        s = dt.fetch_segments()
-        assert np.array_equal(off, ref["offsets"]) and np.array_equal(s["element"], ref["element"])
-        for k in FIELDS:
-            assert np.array_equal(s[k], ref[k]), k
-        dt.close(); dm.close()

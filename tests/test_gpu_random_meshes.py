@@ -58,7 +58,7 @@ def test_random_delaunay_mesh_matches_oracle(rt, orc, seed, n_interior, kw):
     rt.trace(tg)
     ref = _oracle(orc, tg)
     ref_vol = ref["volumes"]
-    for opts in (dict(), dict(split=24), dict(walk=0), dict(single_pass=0)):
+    for opts in (dict(), dict(split=24), dict(walk=0), dict(split=0)):
         total, off, st, seg, vol = _run(rt, tg, opts)
         assert total == ref["total"], opts
         assert np.array_equal(st, ref["status"]), ("per-track status differs", opts)
