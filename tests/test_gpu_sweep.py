@@ -96,6 +96,33 @@ def test_sweep_matches_sequential_sweep_over_oracle_records(rt, orc, mesh, n_azi
         dt.close(); dm.close()
 
 
+def test_sweep_at_config4_size(rt, orc):
+    """BASELINE configs[3] (BWR-like mesh, nφ=64, δ=2e-3: 130,472 tracks, 14.3 M segments): the full batch — 2,039 march waves, the
+    BWR-like mesh's two groups of tallies per pass in LDS — swept twice on the device, against the sequential sweep over ALL of
+    the oracle's records (no sampling: the tallies of a cell need every track that crosses it)."""
+    model = rt.GmshDiscreteModel(rt.data_path("bwr_like.msh"))
+    tg = rt.TrackGenerator(model, 64, 2e-3, bcs=_bcs(rt, "reflective"))
+    rt.trace(tg)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                        tiny_step=tg.tiny_step, n_threads=0)
+    G = 3
+    sigma_t, source, weight, psi_in = _problem(rt, tg, G, 21)
+    phi1, out1 = sweep_ref.sweep_fast(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, weight, psi_in)
+    nxt1 = sweep_ref.link(out1, *_links(tg))
+    phi2, out2 = sweep_ref.sweep_fast(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, weight, nxt1)
+    for compact, inp in ((1, "auto"), (0, "staged"), (1, "compact")):
+        dm, dt = _device(rt, tg, compact)
+        assert dt.total == ref["total"]
+        r = dt.sweep(G, sigma_t, source, weight, psi_in, input=inp)
+        e = [_close(r["phi"], phi1, "phi"), _close(r["psi_out"], out1, "psi_out"), _close(r["psi_next"], nxt1, "psi_next")]
+        r2 = dt.sweep(G)
+        e += [_close(r2["phi"], phi2, "phi, 2nd sweep"), _close(r2["psi_out"], out2, "psi_out, 2nd sweep")]
+        print(f"config 4, G={G}, compact={compact}, input {inp} -> {r['input']}: {r['passes']} passes of {r['groups_per_pass']} groups, {r['ms']:.3f} ms, "
+              f"max rel err {max(e):.1e}")
+        dt.close(); dm.close()
+
+
 def test_sweep_default_weight_and_group_slabs(rt, orc, traced, oracle_run):
     """Default weights are fill_volumes' δs[azim_idx]; 1 to 4 groups per pass (and global atomics) give the same tallies."""
     tg = traced(16, 1e-2)

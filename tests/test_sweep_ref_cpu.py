@@ -56,3 +56,18 @@ def test_attenuation_factor_is_accurate_to_an_ulp():
     assert np.all(got >= 0) and np.all(got <= 1)
     assert np.all(np.abs(got - ref) <= 4.5e-16 * ref)  # 2 ulp of headroom over numpy's own rounding
     assert got[tau == 0.0][0] == 0.0 and got[-1] == 1.0
+
+
+def test_fast_sweep_equals_the_plain_one(rt, traced, oracle_run):
+    """sweep_fast (bincount tallies, the active tracks as a prefix of the tracks sorted by length) is what the C4-sized GPU test
+    uses: the same numbers as `sweep` up to the order of the tallies' additions."""
+    tg = traced(16, 1e-2)
+    ref = oracle_run(tg)
+    nc, n, G = tg.mesh.num_cells, tg.n_total_tracks, 3
+    rng = np.random.default_rng(5)
+    sigma_t = rng.uniform(0.05, 3.0, (nc, G)); source = rng.uniform(0.0, 2.0, (nc, G))
+    w = rng.uniform(0.5, 1.5, n); psi_in = rng.uniform(0.0, 1.5, (2, n, G))
+    phi, out = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, w, psi_in)
+    phi2, out2 = sweep_ref.sweep_fast(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, w, psi_in)
+    assert np.array_equal(out, out2)
+    assert np.abs(phi - phi2).max() <= 1e-13 * np.abs(phi).max()
