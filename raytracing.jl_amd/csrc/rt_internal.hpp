@@ -139,7 +139,6 @@ constexpr int kCtlWords = 64;
 constexpr int kCtlRefusal = 32;   // 32..40: cheap-step refusals by certificate term (order of topo_certified)
 constexpr int kCtlRestarts = 41;  // tracks marched again with exact steps after cheap steps (their fused volumes were counted twice)
 constexpr int kCtlNearRtol = 42;  // tracks whose Σℓ check (src/track.jl:171) sits within summation-order noise of its threshold
-constexpr int kCtlFinishTicket = 43;  // k_finish: its "last block" ticket
 constexpr int kCtlDeferred = 27;      // k_finish: tracks whose exact Σℓ it could not form (their records lie beyond the arrays' capacity)
 // generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
 // C3 — a lane that escalates waits for the rest of its wave — 8..32 equal)

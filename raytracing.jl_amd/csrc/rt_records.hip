@@ -364,28 +364,30 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
     }
 }
 
-// After k_materialise: the tracks whose Σℓ check a sum in another order cannot decide are summed left to right — from the
-// records, or from the ℓ rows when the call wrote no records — and checked as the reference does (src/track.jl:171-175); the
-// statistic of rt_last_stats (tracks within 64 summation-order bands of the threshold) is counted here.  The block that
-// finishes last — a ticket — copies the control block to the host and writes the call's sequence number behind it.
-__global__ __launch_bounds__(256) void k_finish(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
-                                                const int64_t *__restrict__ offsets, const double *__restrict__ ell, int64_t cap,
-                                                DStage stg, const double *__restrict__ ell_rows, double rtol, int32_t *__restrict__ marg,
-                                                double *__restrict__ volumes, double *__restrict__ vacc, int32_t n_cells, double n_azim_2,
-                                                unsigned long long *__restrict__ ctl, unsigned long long *__restrict__ host_copy,
-                                                unsigned long long seq) {
-    __shared__ int last_wg;
+// After k_materialise, ONE workgroup: volumes ./= n_azim_2; the tracks whose Σℓ check a sum in another order cannot decide are
+// summed left to right — from the records, or from the ℓ rows when the call wrote no records — and checked as the reference
+// does (src/track.jl:171-175), the statistic of rt_last_stats (tracks within 64 summation-order bands of the threshold) is
+// counted; then the control block is copied to the host and the call's sequence number written behind it (what a two-phase
+// call's host waits for).  (A single workgroup: no ticket between blocks — the list is empty in practice and the volumes are a
+// few thousand values.)
+constexpr int kFinishThreads = 1024;
+__global__ __launch_bounds__(kFinishThreads) void k_finish(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
+                                                           const int64_t *__restrict__ offsets, const double *__restrict__ ell, int64_t cap,
+                                                           DStage stg, const double *__restrict__ ell_rows, double rtol, int32_t *__restrict__ marg,
+                                                           double *__restrict__ volumes, double *__restrict__ vacc, int32_t n_cells, double n_azim_2,
+                                                           unsigned long long *__restrict__ ctl, unsigned long long *__restrict__ host_copy,
+                                                           unsigned long long seq) {
     const bool void_attempt = stg.cursor[1] != 0 || stg.cursor[3] != 0;
     // volumes ./= n_azim_2 (src/trackgenerator.jl:386): the march accumulated into `vacc` (k_materialise added the terms of the
     // records the march left to it), which is read, scaled into `volumes` and left ZERO for the next call's march
     if (volumes)
-        for (int c = blockIdx.x * 256 + threadIdx.x; c < n_cells; c += gridDim.x * 256) {
+        for (int c = threadIdx.x; c < n_cells; c += kFinishThreads) {
             volumes[c] = vacc[c] / n_azim_2;
             vacc[c] = 0.0;
         }
     if (!void_attempt) {
         const int32_t nm = marg[0];
-        for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < nm; e += gridDim.x * 256) {
+        for (int32_t e = threadIdx.x; e < nm; e += kFinishThreads) {
             const int32_t slot = marg[1 + e];
             if (slot < 0) continue;  // done by an earlier pass
             const int32_t u = t.perm[slot];
@@ -413,14 +415,8 @@ __global__ __launch_bounds__(256) void k_finish(DTracks t, const int32_t *__rest
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) last_wg = atomicAdd((unsigned int *)&ctl[kCtlFinishTicket], 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last_wg) return;
-    __threadfence();
     if (threadIdx.x == 0 && __hip_atomic_load(&ctl[kCtlDeferred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) marg[0] = 0;  // the list is consumed
-    if (threadIdx.x == 0) ctl[kCtlFinishTicket] = 0;  // (a second pass of this call counts again)
     if (host_copy) {
-        __syncthreads();
         if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();
         __syncthreads();
@@ -701,8 +697,7 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
 void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_rows, bool scale_volumes, double n_azim_2,
                    unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq) {
     const rt_tracks::CompactPlan &c = t->cplan;
-    const unsigned blocks = t->mesh->test_exact_sums ? 64u : 8u;
-    hipLaunchKernelGGL(rt::k_finish, dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
+    hipLaunchKernelGGL(rt::k_finish, dim3(1), dim3(rt::kFinishThreads), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
                        (const int64_t *)t->offsets.p, from_rows ? (const double *)nullptr : (const double *)t->sell.p, out.cap, c.stg,
                        from_rows ? (const double *)t->sw_ell.p : (const double *)nullptr, c.rtol, t->marg.p,
                        scale_volumes ? t->volumes.p : (double *)nullptr, t->vacc.p, t->mesh->n_cells, n_azim_2, d_ctl, h_res_dev, seq);
