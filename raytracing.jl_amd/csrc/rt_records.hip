@@ -380,10 +380,20 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(DTracks t, const int3
     const bool void_attempt = stg.cursor[1] != 0 || stg.cursor[3] != 0;
     // volumes ./= n_azim_2 (src/trackgenerator.jl:386): the march accumulated into `vacc` (k_materialise added the terms of the
     // records the march left to it), which is read, scaled into `volumes` and left ZERO for the next call's march
+    // (eight independent loads per thread and round: `vacc` was written by atomics from every XCD, each load is a trip to memory)
     if (volumes)
-        for (int c = threadIdx.x; c < n_cells; c += kFinishThreads) {
-            volumes[c] = vacc[c] / n_azim_2;
-            vacc[c] = 0.0;
+        for (int c0 = threadIdx.x; c0 < n_cells; c0 += 8 * kFinishThreads) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k * kFinishThreads;
+                v[k] = c < n_cells ? vacc[c] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k * kFinishThreads;
+                if (c < n_cells) { volumes[c] = v[k] / n_azim_2; vacc[c] = 0.0; }
+            }
         }
     if (!void_attempt) {
         const int32_t nm = marg[0];
@@ -413,13 +423,13 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(DTracks t, const int3
             }
         }
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();  // (the counters above are device-scope atomics; what this kernel wrote to device memory is flushed at its end)
+    if (threadIdx.x >= 64) return;  // (one wave copies: a system-scope release per wave is a cache write-back per wave)
     if (threadIdx.x == 0 && __hip_atomic_load(&ctl[kCtlDeferred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) marg[0] = 0;  // the list is consumed
     if (host_copy) {
-        if (threadIdx.x < kCtlWords) host_copy[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-        __syncthreads();
+        static_assert(kCtlWords <= 64, "one wave copies the control block");
+        host_copy[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the lanes' stores and lane 0's release store are one wave's instructions, in order; the release waits for them)
         if (threadIdx.x == 0) __hip_atomic_store(&host_copy[kCtlWords], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
