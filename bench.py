@@ -86,8 +86,8 @@ def kernel_names(stats):
     w = stats["march_waves"]
     sp = stats["split"] == 1
     cheap = stats.get("cheap_records", 0) > 0  # the TOPO instantiation (cheap steps) ran
-    return {"march": "rt::k_march<2, %d, %s, %s, false, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
-                                                                  "true" if cheap else "false"),
+    return {"march": "rt::k_march<2, %d, %s, %s, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
+                                                           "true" if cheap else "false"),
             "compact": "rt::k_materialise<true, false>" if cheap else "rt::k_compact3<%s>" % ("true" if sp else "false"),
             "scan": "rt::k_scan_write"}
 
