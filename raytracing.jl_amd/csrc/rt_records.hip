@@ -153,33 +153,33 @@ __global__ __launch_bounds__(256) void k_compact3(DTracks t, const int32_t *__re
 // same edge: they share cache lines; in the store mapping every lane would fetch a line of its own).
 // RECORDS: write the 44-B records.  ROWS: leave (ℓ, cell) of every staged row, slot-indexed like the rows, for rt_sweep.
 #ifndef RT_MAT_OCC
-#define RT_MAT_OCC 3  // waves per SIMD the kernel is compiled for
+#define RT_MAT_OCC 4  // waves per SIMD the kernel is compiled for (131 VGPRs unforced: six spilled values, four workgroups per CU; measured -1 … -2 % per step against 3)
 #endif
+// LDS: one tile per wave, 16 tracks x (1 + 32) slots of 16 B.  A slot first holds a row's exit point (x, y) — slot 0 of a
+// track: the row before the chunk, i.e. the first row's entry point —, written in the load mapping and read back in the store
+// mapping (one ds_read_b128 / ds_write_b128 per point: the first version kept x and y in two tiles of doubles, twice the LDS
+// instructions, and was LDS-issue-bound beside its arithmetic), then the row's (ℓ, cell).  Pitch 33 slots: the 16 lanes of a
+// row of the load mapping fall on different banks.
+constexpr int kMatPitch = kChunkRows + 1;
+typedef double __attribute__((ext_vector_type(2))) rt_d2;
 template <bool RECORDS, bool ROWS>
 __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, const int32_t *__restrict__ counts, int32_t *__restrict__ status,
-                                                     const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
+                                                                const int64_t *__restrict__ offsets, DStage stg, DOut out, DMat a) {
     static_assert(kChunkRows == 32, "k_materialise moves 32-row chunks");
-    __shared__ double tiles_x[4][16 * kC3Pitch];  // per wave: the chunk's exit points (slot 0 of a track: the row before, i.e. the
-    __shared__ double tiles_y[4][16 * kC3Pitch];  // first row's entry point), then its lengths (x tile) and cells (y tile)
-    __shared__ double s_sum[16];                  // Σℓ of the unit's tracks
-    __shared__ int64_t s_off[16];
-    __shared__ int32_t s_cnt[16];
+    __shared__ rt_d2 tiles[4][16 * kMatPitch];
+    __shared__ double s_sum[16];   // Σℓ of the unit's tracks
+    __shared__ rt_d2 s_track[16];  // per track: CSR offset and record count (as bit patterns)
     if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
     const int kw = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr + 4, ...
     const int rowL = lane & 31, sub = lane >> 5;  // store mapping: row rowL of tracks sub, sub + 2, ...
-    typedef __attribute__((address_space(3))) volatile double lds_f64;
-    typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
-    typedef __attribute__((address_space(3))) volatile int64_t lds_i64;
-    lds_f64 *X = (lds_f64 *)tiles_x[kw], *Y = (lds_f64 *)tiles_y[kw];
-    lds_i32 *Yi = (lds_i32 *)tiles_y[kw];
-    lds_i32 *scnt = (lds_i32 *)s_cnt;
-    lds_i64 *soff = (lds_i64 *)s_off;
+    typedef __attribute__((address_space(3))) volatile rt_d2 lds_d2;
+    lds_d2 *T = (lds_d2 *)tiles[kw];
+    lds_d2 *strk = (lds_d2 *)s_track;
     const int64_t unit = blockIdx.x;
     const int64_t w = a.corder ? a.corder[unit >> 2] : (unit >> 2);
     const int q = (int)(unit & 3);
     const int64_t slot = w * 64 + 16 * q + tl;
-    // every lane holds its load-mapping track's uid, count, offset and line (the 4 lanes of a track load the same words)
     // (everything a unit needs first is read in march-slot order, side by side: counts, offsets, lines, the wave's first chunk id)
     int32_t cnt = 0, u = 0;
     int64_t off = 0;
@@ -193,7 +193,12 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
         off = t.off_slot[slot];
         tA = t.As[slot]; tB = t.Bs[slot]; tC = t.Cs[slot];
     }
-    if (threadIdx.x < 16) { scnt[tl] = cnt; soff[tl] = off; s_sum[tl] = 0.0; }
+    if (threadIdx.x < 16) {
+        rt_d2 v;
+        v.x = __builtin_bit_cast(double, off); v.y = __builtin_bit_cast(double, (int64_t)cnt);
+        strk[tl] = v;
+        s_sum[tl] = 0.0;
+    }
     int32_t gmax = cnt;
     for (int o = 8; o > 0; o >>= 1) {
         const int32_t v = __shfl_xor(gmax, o, 64);
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
     gmax = __shfl(gmax, 0, 64);
     __syncthreads();
     const int lane_q = 16 * q + tl;
-    const int tb = tl * kC3Pitch;
+    const int tb = tl * kMatPitch;
     double acc = 0.0;  // Σℓ of this lane's rows of its load-mapping track
     for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
         const int r0 = j << kChunkLog2;
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
                 const int i = 4 * h + i2;
+                rt_d2 qv;
                 double qx, qy;
                 edge_exit_point(tA, tB, tC, eA[i2], eB[i2], eC[i2], qx, qy);  // src/intersection.jl:127-138
                 if (__builtin_expect(ve[i] < 0, 0)) {  // a record of the generic step: its own q (and cell)
@@ -262,11 +268,11 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
                     if (i == 0 && rr == 0) ve[i] = 3 * (stg.s_el[idx] - 1) + 1;  // (its p sits in slot 0: from here on an ordinary word)
                     else slow = true;
                 }
-                X[tb + 1 + 4 * i + rr] = qx;
-                Y[tb + 1 + 4 * i + rr] = qy;
+                qv.x = qx; qv.y = qy;
+                T[tb + 1 + 4 * i + rr] = qv;
             }
         }
-        if (lane < 16) { X[tb] = hx; Y[tb] = hy; }
+        if (lane < 16) { rt_d2 hv; hv.x = hx; hv.y = hy; T[tb] = hv; }
         const bool any_slow = __ballot(slow) != 0;
         __builtin_amdgcn_wave_barrier();
         // ---- ℓ = ‖p − q‖ (Segment ctor, src/segment.jl:31-33) in the load mapping; p, q to the output in the store mapping
@@ -274,11 +280,11 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int rl = 4 * i + rr;
-            double px = X[tb + rl], py = Y[tb + rl];
-            const double qx = X[tb + rl + 1], qy = Y[tb + rl + 1];
+            rt_d2 pv = T[tb + rl];
+            const rt_d2 qv = T[tb + rl + 1];
             if (__builtin_expect(any_slow, 0))
-                if (ve[i] < 0) { px = stg.s_px[-ve[i] - 1]; py = stg.s_py[-ve[i] - 1]; }
-            dl[i] = norm2(px - qx, py - qy);
+                if (ve[i] < 0) { pv.x = stg.s_px[-ve[i] - 1]; pv.y = stg.s_py[-ve[i] - 1]; }
+            dl[i] = norm2(pv.x - qv.x, pv.y - qv.y);
             acc += ve[i] != 0 ? dl[i] : 0.0;
         }
         if (__builtin_expect(any_flagged, 0)) {
@@ -292,24 +298,27 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int tt = 2 * g + sub;
-                const int sb = tt * kC3Pitch + rowL;
+                const rt_d2 trk = strk[tt];
                 const int row = r0 + rowL;
-                const int64_t o = soff[tt] + row;
-                const double px = X[sb], qx = X[sb + 1], py = Y[sb], qy = Y[sb + 1];
+                const int64_t o = __builtin_bit_cast(int64_t, (double)trk.x) + row;
+                const rt_d2 pv = T[tt * kMatPitch + rowL], qv = T[tt * kMatPitch + rowL + 1];
                 // plain stores: the partial lines at the ends of a run wait in L2 for the sibling wave's half
-                if (row < scnt[tt] && o < out.cap && !((out.dbg & 1) && px != -1.25)) { out.px[o] = px; out.py[o] = py; out.qx[o] = qx; out.qy[o] = qy; }
+                if (row < (int32_t)__builtin_bit_cast(int64_t, (double)trk.y) && o < out.cap && !((out.dbg & 1) && pv.x != -1.25)) {
+                    out.px[o] = pv.x; out.py[o] = pv.y; out.qx[o] = qv.x; out.qy[o] = qv.y;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- lengths and cells through the tiles
+        // ---- lengths and cells through the tile
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int32_t wd = ve[i];
             if (__builtin_expect(any_slow, 0))
                 if (wd < 0) wd = 3 * (stg.s_el[-wd - 1] - 1) + 1;
             const int32_t cell = (int32_t)((uint32_t)(wd > 0 ? wd - 1 : 0) / 3u) + 1;
-            X[tb + 1 + 4 * i + rr] = dl[i];
-            Yi[tb + 1 + 4 * i + rr] = cell;
+            rt_d2 lv;
+            lv.x = dl[i]; lv.y = __builtin_bit_cast(double, (int64_t)cell);
+            T[tb + 1 + 4 * i + rr] = lv;
             if (ROWS && wd != 0) {
                 const int64_t sidx = stage_slot(c, 4 * i + rr, lane_q);
                 a.ell_rows[sidx] = dl[i];
@@ -321,12 +330,13 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int tt = 2 * g + sub;
-                const int sb = tt * kC3Pitch + 1 + rowL;
+                const rt_d2 trk = strk[tt];
                 const int row = r0 + rowL;
-                const int64_t o = soff[tt] + row;
-                const double ell = X[sb];
-                const int32_t el = Yi[sb];
-                if (row < scnt[tt] && o < out.cap && !((out.dbg & 1) && ell != -1.25)) { out.ell[o] = ell; out.element[o] = el; }
+                const int64_t o = __builtin_bit_cast(int64_t, (double)trk.x) + row;
+                const rt_d2 lv = T[tt * kMatPitch + 1 + rowL];
+                if (row < (int32_t)__builtin_bit_cast(int64_t, (double)trk.y) && o < out.cap && !((out.dbg & 1) && lv.x != -1.25)) {
+                    out.ell[o] = lv.x; out.element[o] = (int32_t)__builtin_bit_cast(int64_t, (double)lv.y);
+                }
             }
             if (__builtin_expect(any_slow, 0)) {
                 // the entry points of marked records that are not their chunk's first row, straight from the load mapping
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
                     }
             }
         }
-        __builtin_amdgcn_wave_barrier();  // the tiles are rewritten if this wave has a further chunk
+        __builtin_amdgcn_wave_barrier();  // the tile is rewritten if this wave has a further chunk
     }
     if (a.tally) {
         // Σℓ of the 16 tracks over this wave's rows: the four lanes of a track, then the four waves' parts in LDS
