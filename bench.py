@@ -728,14 +728,16 @@ def _main(real_stdout):
                 "tracks_rank0": int(hi - lo), "segments_rank0": int(local_total),
                 "sharding": "contiguous uid ranges balanced by Σℓ; all-reduce(sum) of volumes inside the step" if world > 1 else "none",
                 "tiny_step": tg.tiny_step, "k": 5, "rtol": rt.RTOL_DEFAULT, "failed_tracks": failed_tracks,
-                "march_plan": {0: "whole tracks", 1: "every track in pieces", 2: "hybrid: the longest waves in pieces beside the whole-track march"}[stats["split"]],
+                "march_plan": {0: "whole tracks", 1: "every track in pieces"}[stats["split"]],
                 "regime": {"walk_enabled": info["walk_enabled"], "records_walkable": info["records_walk"], "records": info["records"],
                            "walk_records_rank0": stats["walk_records"], "generic_records_rank0": stats["generic_records"],
                            "cheap_records_rank0": stats["cheap_records"], "two_phase": stats["cheap_records"] > 0,
                            "cheap_refusals_rank0": stats["cheap_refusals"], "tracks_restarted_rank0": stats["tracks_restarted"],
                            # tracks whose Σℓ check (src/track.jl:171) lies within summation-order noise of its threshold: Julia's
                            # pairwise / @simd sum could decide them the other way — what cannot be pinned without the real package
-                           "tracks_near_rtol_rank0": stats["tracks_near_rtol"]},
+                           "tracks_near_rtol_rank0": stats["tracks_near_rtol"],
+                           # cheap records whose fill_volumes term the second kernel added from the record's own length
+                           "records_tallied_from_lengths_rank0": stats["records_tallied_from_lengths"]},
                 "device_GB_held_by_rank0_handle": stats["device_bytes"] / 1e9,
                 "library_sha256": lib_sha256(),
             },

@@ -271,7 +271,9 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
  * point), 16 D·c1 < dtf (bound on tiny steps), 17 |s_v| < lc·lcf (chord length / order guard) — DESIGN.md §2; stats[18] tracks
  * whose Σℓ check (src/track.jl:171) lies within summation-order noise (64 ulp·n) of its rtol threshold: their status could
  * differ under Julia's pairwise / @simd `sum`; stats[19] tracks marched again with exact steps because the cheap steps'
- * iteration bound reached the iteration cap.
+ * iteration bound reached the iteration cap; stats[20] cheap records whose fill_volumes term was added from the record's own
+ * length by the second kernel of the two-phase march (a short chord or a shallow crossing: the chord from the vertices' distances
+ * would not be within 4e-11 of it — DESIGN.md §2).
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 

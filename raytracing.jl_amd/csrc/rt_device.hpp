@@ -124,6 +124,7 @@ struct DTracks {
     const RT_G int32_t *iperm;
     RT_G int32_t *cnt_slot;
     RT_G int64_t *off_slot;
+    RT_G double *w_slot;    // δs of the track's azimuthal angle, march-slot order (k_march leaves it for k_materialise's fill_volumes terms)
 };
 
 struct DParams {
@@ -135,8 +136,9 @@ struct DParams {
     double topo_tiny_max, topo_rmax, topo_end_err;  // cheap steps (topo_track); unused elsewhere
     int32_t topo_force;  // 1: option "topo" = 2 — a wave that is refused often does NOT hand back to exact steps
     int32_t pad_;
-    double tally_tau;    // cheap records whose exit edge's end points are closer than this across the track line are tallied
-                         // (fill_volumes) by k_materialise from the record's exact length (rt_mesh_prep.hpp); ∞: all of them
+    double tally_c1, tally_c2;  // fill_volumes of a cheap record from the vertices' distances (k_march) only if chord >= c1 and
+                                // chord · (smaller |s_p − s_q| of its two crossings) >= c2; else k_materialise adds the term
+                                // from the record's own length (rt_mesh_prep.hpp); c1 = ∞: all of them
 };
 
 // ---------------------------------------------------------------- Base.isapprox ----------

@@ -138,6 +138,7 @@ enum MarchMode { kCount = 0, kFill = 1, kStage = 2 };
 constexpr int kCtlWords = 64;
 constexpr int kCtlRefusal = 32;   // 32..40: cheap-step refusals by certificate term (order of topo_certified)
 constexpr int kCtlRestarts = 41;  // tracks marched again with exact steps after cheap steps (their fused volumes were counted twice)
+constexpr int kCtlExactTally = 43;  // cheap records whose fill_volumes term k_materialise adds from the record's own length
 constexpr int kCtlNearRtol = 42;  // tracks whose Σℓ check (src/track.jl:171) sits within summation-order noise of its threshold
 constexpr int kCtlDeferred = 27;      // k_finish: tracks whose exact Σℓ it could not form (their records lie beyond the arrays' capacity)
 // generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
@@ -261,8 +262,8 @@ struct rt_mesh {
                            // compaction may still be running on the stream (every entry point that touches results waits)
     int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
-    double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0, tally_tau = 0.0;
-    int64_t test_tally_tau = 0;  // tests only: overrides tally_tau (in 1e-12; < 0: ∞ — every cheap record tallied by k_materialise)
+    double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0, tally_a = 0.0, tally_b = 0.0;
+    int64_t test_tally_tau = 0;  // tests, A/B: the relative error allowed to a cheap record's chord in fill_volumes, in 1e-12 (0: 8e-11; < 0: none — every cheap record tallied by k_materialise)
     int64_t n_records_topo = 0;
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits
     int compact = 1;       // 0: rt_segmentize stops after march + scan (offsets, status, volumes); the 44-B records are produced on
@@ -300,6 +301,7 @@ struct rt_tracks {
     DevView<int32_t> iperm;       // uid -> march slot
     DevBuf<int32_t> cnt_slot;     // record counts / CSR offsets in march-slot order (whole-track two-phase calls)
     DevBuf<int64_t> off_slot;
+    DevBuf<double> w_slot;
     rt::DTracks d{};
     // results
     bool segmentized = false;
@@ -374,7 +376,7 @@ struct rt_tracks {
     bool sw_links = false, sw_has_w = false, sw_has_xs = false, sw_done = false;
     int32_t sw_groups = 0, sw_last_input = 0, sw_last_gp = 0, sw_last_passes = 0;
     int64_t refusals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // cheap-step refusals of the last call by certificate term
-    int64_t n_near_rtol = 0, n_restarts = 0;
+    int64_t n_near_rtol = 0, n_restarts = 0, n_exact_tally = 0;
     int64_t n_failed = 0, first_failed_uid = 0;
     int32_t first_failed_status = 0;
 };

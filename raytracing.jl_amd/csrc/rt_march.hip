@@ -270,12 +270,14 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     double tta = 0.0, ttb = 0.0, ttp = 0.0;
     const double nab = (TOPO && FUSE) ? sqrt(tA * tA + tB * tB) : 1.0;
     const double wq = (TOPO && FUSE) ? w / nab : 0.0;
-    const double tau_s = (TOPO && FUSE) ? prm.tally_tau * nab : 0.0;  // (s is scaled by ‖(A, B)‖ as t is)
-    bool pin = false;  // the lane's last exit point came from a shallow crossing: the next chord starts there
+    // what the approximate chord may be used for (rt_mesh_prep.hpp, tally_c1 / tally_c2; s and t are scaled by ‖(A, B)‖)
+    const double tc1 = (TOPO && FUSE) ? prm.tally_c1 * nab : 0.0, tc2 = (TOPO && FUSE) ? prm.tally_c2 * (nab * nab) : 0.0;
+    double dprev = 0.0;  // |s_p − s_q| of the crossing the lane's last exit point came from (∞: an exact step's point)
+    int32_t n_exact_tally = 0;  // cheap records of this lane whose fill_volumes term is left to k_materialise
     auto topo_tally_enter = [&]() {
         tta = __builtin_fma(tB, wk.ax, -(tA * wk.ay)); ttb = __builtin_fma(tB, wk.bx, -(tA * wk.by));
         ttp = __builtin_fma(tB, lqx, -(tA * lqy));
-        pin = false;  // (an exact step's exit point)
+        dprev = INFINITY;  // (an exact step's exit point)
     };
     int32_t n_cheap_it = 0, n_cheap_ref = 0;  // wave-uniform: cheap iterations of this wave, and those in which a lane was refused
     int32_t last_word = 0;  // staging word of the lane's last record
@@ -404,11 +406,12 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                         rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
                         rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
                         const double tx = (sp * tq - sq * tp) * rc;
-                        // (a chord one of whose ends is a shallow crossing is left to k_materialise: rt_mesh_prep.hpp, tally_tau)
-                        const bool shallow = !(fabs(den) >= tau_s);
-                        inexact = pin || shallow;
-                        atomicAdd(&hist[g.cell], (commit && !inexact) ? wq * fabs(tx - ttp) : 0.0);  // (LDS-private; a lane that decided nothing adds 0)
-                        if (commit) { ttp = tx; tta = tp; ttb = tq; pin = shallow; }
+                        // (a chord that is short, or one of whose ends is a shallow crossing, is left to k_materialise: its relative
+                        //  error bound, rt_mesh_prep.hpp, is 2e-11·(c1/chord + c2/(chord·min D_x)) — per record, hence for every sum)
+                        const double ch = fabs(tx - ttp), dmin = fmin(fabs(den), dprev);
+                        inexact = !(ch >= tc1 && ch * dmin >= tc2);
+                        atomicAdd(&hist[g.cell], (commit && !inexact) ? wq * ch : 0.0);  // (LDS-private; a lane that decided nothing adds 0)
+                        if (commit) { ttp = tx; tta = tp; ttb = tq; dprev = fabs(den); n_exact_tally += inexact ? 1 : 0; }
                     }
                     if (commit) {
                         ++i;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 asm volatile("" ::: "memory");
                 // its records have already been added to the fused volumes: the host recomputes them from the records
                 atomicAdd(march_ctl() + kCtlRestarts, 1ull);
-                tt.on = false; fl = 0; n_generic = 0;
+                tt.on = false; fl = 0; n_generic = 0; n_exact_tally = 0;
                 i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
                 xpx = t.px[u] + sx; xpy = t.py[u] + sy;
                 continue;
@@ -740,13 +743,18 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         }
         counts[u] = i;
         status[u] = st;
-        if (TOPO) t.cnt_slot[slot] = i;  // (k_materialise reads its units' counts in slot order)
+        if (TOPO) { t.cnt_slot[slot] = i; if (FUSE) t.w_slot[slot] = out.delta_s[t.azim[u] - 1]; }  // (k_materialise reads its units' counts and weights in slot order)
         {
             // per-call statistic (rt_last_stats): records the generic step produced, summed over the wave's active lanes
             // bit by bit with ballots (n_generic <= kMaxIter < 2^14)
             unsigned long long ng = 0;
             for (int b = 0; b < 14; ++b) ng += (unsigned long long)__popcll(__ballot((n_generic >> b) & 1)) << b;
             if (lane == __ffsll((long long)__ballot(1)) - 1 && ng) atomicAdd(&fail_info[15], ng);
+            if (TOPO && FUSE) {
+                unsigned long long ne = 0;
+                for (int b = 0; b < 14; ++b) ne += (unsigned long long)__popcll(__ballot((n_exact_tally >> b) & 1)) << b;
+                if (lane == __ffsll((long long)__ballot(1)) - 1 && ne) atomicAdd(march_ctl() + kCtlExactTally, ne);
+            }
         }
         if (st != RT_TRACK_OK) {
             atomicAdd(&fail_info[0], 1ull);

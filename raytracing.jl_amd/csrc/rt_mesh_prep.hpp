@@ -115,8 +115,8 @@ struct Prep {
     double topo_tiny_max = 0.0;     // the cheap step's certificates hold for tiny_step <= this
     double topo_rmax = 0.0;         // order guard: a track needs |s_v| >= lc * max(1, topo_rmax / |cos ϕ|)
     double topo_end_err = 0.0;      // |computed exit coordinate - border| bound on border edges
-    double tally_tau = INFINITY;    // fill_volumes of cheap records from the vertices' distances (k_march): exact enough where the exit
-                                    // edge's end points lie at least this far apart across the track line (see prepare)
+    double tally_a = INFINITY, tally_b = INFINITY;  // fill_volumes of cheap records from the vertices' distances (k_march): the chord is
+                                    // within a + b / (end points' distance across the track line) of the record's length (see prepare)
     int64_t n_records_topo = 0;
     // node grid
     int gnx = 1, gny = 1;
@@ -345,24 +345,22 @@ inline Prep prepare(const double *x, const double *y, int32_t n_nodes, const int
         // fill_volumes (src/trackgenerator.jl:376-386) sums δs·ℓ per cell and is compared at 1e-10, not bit for bit.  For a cheap
         // record the march adds the chord between the two edge crossings, each interpolated from the signed distances s and the
         // positions t along the line of the edge's end points: t = (s_p·t_q − s_q·t_p)/(s_p − s_q).  With R the largest
-        // coordinate norm, the inputs carry |δs| <= 3uR, |δt| <= 2uR, the expression 3uR, and ∂t/∂s <= l_max/D_x (D_x = |s_p −
-        // s_q|, the end points' distance across the line): a chord differs from the record's ‖p − q‖ by at most
-        // 2uR·(7 + 6·l_max/D_x) — the reference's own points carry the same kind of error.  Relative to a cell's volume the sum
-        // of such differences is at most that over the cell's mean chord, π·area/perimeter (Cauchy).  Budget: 2e-11 for the
-        // part that does not depend on the crossing (16uR / smallest mean chord — a mesh that exceeds it gets tally_tau = ∞:
-        // every cheap record is then tallied exactly, by k_materialise), 2e-11 for shallow crossings: records with D_x below
-        // tally_tau are tallied exactly as well.
-        double chord_min = INFINITY;
-        for (int32_t c = 0; c < n_cells; ++c) {
-            const CellRecHost &R = P.rec[c];
-            if (R.cls != 0) continue;  // (cheap records neither enter nor leave fragile / degenerate cells)
-            double per = 0;
-            for (int k = 0; k < 3; ++k) per += std::hypot(R.vx[k] - R.vx[(k + 1) % 3], R.vy[k] - R.vy[(k + 1) % 3]);
-            if (per > 0) chord_min = std::min(chord_min, 3.141592653589793 * 0.5 * R.area2 / per);
-        }
+        // coordinate norm and D_x = |s_p − s_q| (the end points' distance across the line):
+        //  * the inputs carry |δs| <= 3uR, |δt| <= 2uR, the expression 3uR, and ∂t/∂s <= l_max/D_x: 2uR·(7 + 6·l_max/D_x) for the
+        //    chord's two ends;
+        //  * the REFERENCE's own point is the track line intersected with the edge's general_form (src/intersection.jl:11-18), whose
+        //    C = x_i·y_o − x_o·y_i carries u·R² of rounding against ‖(A, B)‖ = |edge|: the line it represents lies up to
+        //    uR²/|edge| + uR beside the edge through the vertices, i.e. (uR² + uR·l_max)/D_x along the track (1/sin of the crossing
+        //    angle = |edge|/D_x), and Cramer's rule adds ≈2uR·|edge|/D_x — two ends: 2uR·(R + 3·l_max)/D_x.  (Without this term the
+        //    first version's bound was exceeded far from the origin: 5.1e-11 on a lattice 40 units out, profiles/r04/.)
+        // A chord is therefore within a + b/D_x of the record's ‖p − q‖, a = 16uR, b = 2uR·(10·l_max + 1.25·R), D_x the smaller of
+        // its two crossings'.  The march uses the chord only where that is a fraction ε of THE CHORD ITSELF (rt_segmentize: ε =
+        // 8e-11 of north_star's 1e-10, an eighth for a, the rest for b); every other cheap record is marked and k_materialise adds
+        // δs·ℓ from the record's own length.  A bound per term is a bound for every cell's sum, however few or short the chords a
+        // cell happens to get.  Far from the origin everything is tallied from the lengths — slower, never wrong.
         const double Rfar = std::hypot(cmax_x, cmax_y);
-        const double floor_rel = chord_min > 0 && std::isfinite(chord_min) ? 16.0 * kUlp * Rfar / chord_min : INFINITY;
-        P.tally_tau = floor_rel <= 2e-11 ? 16.0 * kUlp * Rfar * l_max / (2e-11 * chord_min) : INFINITY;
+        P.tally_a = 16.0 * kUlp * Rfar;
+        P.tally_b = 2.0 * kUlp * Rfar * (10.0 * l_max + 1.25 * Rfar);
     }
     if (wild.size() > 4096) { P.walk_ok = false; P.note = "too many degenerate cells for the walk certificates"; }
     {

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
     __shared__ rt_d2 tiles[4][16 * kMatPitch];
     __shared__ double s_sum[16];   // Σℓ of the unit's tracks
     __shared__ rt_d2 s_track[16];  // per track: CSR offset and record count (as bit patterns)
+    __shared__ double s_w[16];     // per track: δs of its azimuthal angle (fill_volumes terms of marked records)
     if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
     const int kw = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = lane & 15, rr = lane >> 4;     // load mapping: track tl, rows rr, rr + 4, ...
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
         tA = t.As[slot]; tB = t.Bs[slot]; tC = t.Cs[slot];
     }
     if (threadIdx.x < 16) {
+        s_w[tl] = (have && a.tally) ? t.w_slot[slot] : 0.0;
         rt_d2 v;
         v.x = __builtin_bit_cast(double, off); v.y = __builtin_bit_cast(double, (int64_t)cnt);
         strk[tl] = v;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
         }
         if (__builtin_expect(any_flagged, 0)) {
             // fill_volumes (src/trackgenerator.jl:382) for the records the march left out: δs[azim]·ℓ with the record's own length
-            const double wt = have ? out.delta_s[t.azim[u] - 1] : 0.0;
+            const double wt = s_w[tl];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if ((fmask >> i) & 1) unsafeAtomicAdd((double *)&a.vacc[(int32_t)((uint32_t)(ve[i] - 1) / 3u)], wt * dl[i]);

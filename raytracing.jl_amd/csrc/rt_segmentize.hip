@@ -150,7 +150,7 @@ int build_mesh(rt_mesh *m, const double *x, const double *y, int32_t n_nodes, co
     d.walk_ok = P.walk_ok ? 1 : 0;
     d.trec = as_global((const rt::TopoRec *)m->trec.p); d.etab = as_global((const rt::EdgeABC *)m->etab.p);
     m->topo_available = P.walk_ok && P.topo_ok;
-    m->topo_tiny_max = P.topo_tiny_max; m->topo_rmax = P.topo_rmax; m->topo_end_err = P.topo_end_err; m->tally_tau = P.tally_tau;
+    m->topo_tiny_max = P.topo_tiny_max; m->topo_rmax = P.topo_rmax; m->topo_end_err = P.topo_end_err; m->tally_a = P.tally_a; m->tally_b = P.tally_b;
     m->n_records_topo = P.n_records_topo;
     m->walk_available = P.walk_ok;
     m->kappa = P.kappa;
@@ -174,7 +174,7 @@ void pin_release_to_cache(rt_tracks *t);  // defined with rt_fetch_segments_pinn
 void free_tracks(rt_tracks *t) {
     t->px.release(); t->py.release(); t->phi.release(); t->cs.release(); t->sn.release();
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->corder.release();
-    t->in_arena.release(); t->cnt_slot.release(); t->off_slot.release();
+    t->in_arena.release(); t->cnt_slot.release(); t->off_slot.release(); t->w_slot.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
     t->tile_sums.release(); t->ctl.release(); t->vacc.release();
 #ifdef RT_TIMING
@@ -601,7 +601,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             }
             ok = ok && hipStreamSynchronize(s) == hipSuccess;
         }
-        ok = ok && t->cnt_slot.reserve(na + 64) == hipSuccess && t->off_slot.reserve(na + 64) == hipSuccess;
+        ok = ok && t->cnt_slot.reserve(na + 64) == hipSuccess && t->off_slot.reserve(na + 64) == hipSuccess && t->w_slot.reserve(na + 64) == hipSuccess;
     }
     if (ok && t->n_vwaves > 0) {
         const size_t np = (size_t)t->n_vwaves * 64;
@@ -626,7 +626,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
     d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
     d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.iperm = as_global(t->iperm.p);
-    d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p);
+    d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p); d.w_slot = as_global(t->w_slot.p);
     d.n = n_tracks;
     guard.p = nullptr;
     return t;
@@ -670,7 +670,13 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
     prm.topo_tiny_max = m->topo_tiny_max; prm.topo_rmax = m->topo_rmax; prm.topo_end_err = m->topo_end_err;
     prm.topo_force = m->topo == 2 ? 1 : 0; prm.pad_ = 0;
-    prm.tally_tau = m->test_tally_tau != 0 ? (m->test_tally_tau < 0 ? (double)INFINITY : 1e-12 * (double)m->test_tally_tau) : m->tally_tau;
+    {
+        // the chord of a cheap record is used for fill_volumes where its error bound a + b/D_x (rt_mesh_prep.hpp) is at most ε of the
+        // chord: ε/8 for a, 7ε/8 for b.  "test_tally_tau" (tests, A/B): ε in 1e-12; < 0: every cheap record is tallied from its length
+        const double eps = m->test_tally_tau > 0 ? 1e-12 * (double)m->test_tally_tau : 8e-11;
+        prm.tally_c1 = m->test_tally_tau < 0 ? (double)INFINITY : m->tally_a / (0.125 * eps);
+        prm.tally_c2 = m->test_tally_tau < 0 ? (double)INFINITY : m->tally_b / (0.875 * eps);
+    }
 
     const int64_t n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
     const int64_t n_waves = (n + 63) / 64;
@@ -1106,6 +1112,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     t->n_exact_walk_records = topo ? (int64_t)fi[14] : 0;
     for (int b = 0; b < 9; ++b) t->refusals[b] = m->single_pass ? (int64_t)h_res[rt::kCtlRefusal + b] : 0;
     t->n_near_rtol = (int64_t)h_res[rt::kCtlNearRtol];
+    t->n_exact_tally = (int64_t)h_res[rt::kCtlExactTally];
     t->n_restarts = m->single_pass ? (int64_t)h_res[rt::kCtlRestarts] : 0;
     t->n_failed = (int64_t)fi[0];
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
@@ -1319,9 +1326,10 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     for (int b = 0; b < 9 && 9 + b < n; ++b) stats[9 + b] = t->refusals[b];
     if (n > 18) stats[18] = t->n_near_rtol;
     if (n > 19) stats[19] = t->n_restarts;
+    if (n > 20) stats[20] = t->last_topo ? t->n_exact_tally : 0;
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
-        stats[7] = b(t->in_arena) + b(t->cnt_slot) + b(t->off_slot) +
+        stats[7] = b(t->in_arena) + b(t->cnt_slot) + b(t->off_slot) + b(t->w_slot) +
                    b(t->counts) + b(t->status) + b(t->element) + b(t->offsets) + b(t->tile_sums) + b(t->ctl) + b(t->spx) +
                    b(t->spy) + b(t->sqx) + b(t->sqy) + b(t->sell) + b(t->volumes) + b(t->volumes_prev) + b(t->delta_s) + b(t->gpx) + b(t->gpy) +
                    b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +

@@ -200,7 +200,7 @@ def test_single_track_and_empty_batch(rt, orc, traced):
                                   # every cheap record's fill_volumes term / none of them added by k_materialise, codes on a mesh-order march
                                   dict(split=0, side_entries_hint=16), dict(split=0, test_exact_sums=1),
                                   dict(split=0, test_exact_sums=1, test_out_records=20000), dict(split=0, test_tally_tau=-1),
-                                  dict(split=0, test_tally_tau=1), dict(split=0, test_tally_tau=20000000), dict(split=0, compact=0),
+                                  dict(split=0, test_tally_tau=1), dict(split=0, test_tally_tau=20), dict(split=0, compact=0),
                                   dict(split=0, compact=0, test_exact_sums=1), dict(split=0, topo=2, sort_mode=1)])
 def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
     from raytracing_jl_amd import _capi
