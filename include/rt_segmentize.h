@@ -143,15 +143,16 @@ int64_t rt_segmentize(rt_tracks *tracks, double tiny_step, int32_t k, double rto
 /* Number of tracks with status != RT_TRACK_OK after the last rt_segmentize, and the 1-based
  * uid of the first one (0 if none). */
 int32_t rt_failed_tracks(rt_tracks *tracks, int64_t *n_failed, int64_t *first_uid, int32_t *first_status);
-/* Stream-ordered calls — rt_set_option(mesh, "async", 1): rt_segmentize returns as soon as the host knows the total, the failure
- * summary and that the offsets' scan has been issued; the compaction of the records (38 % of a step at the headline
- * configuration) may still be running on the mesh's stream, and the next rt_segmentize queues behind it, so consecutive calls
- * leave no host turnaround between their kernels.  Every entry point that reads results (rt_fetch_*, rt_device_pointers,
- * rt_fill_tau, rt_sweep*, rt_last_timing, rt_tracks_destroy) first waits; a consumer with its own stream orders against
- * rt_mesh_get_stream or calls rt_wait.  rt_sweep behaves the same way under the option: its kernels are queued and it returns
- * (ms = 0), so that consecutive sweeps — with the source updated through rt_sweep_xs_pointer on the same stream — run without a
- * host turnaround.  Default 0: segmentize! semantics, everything is complete at return.  Calls that march
- * track pieces, or with the "timing" option on, always complete before they return. */
+/* Completion.  A whole-track call with cheap steps (the default regime) ends with a one-workgroup kernel that copies the call's
+ * control block (total, failure summary, cursors, statistics) to page-locked host memory and stores the call's sequence number behind
+ * it; rt_segmentize returns when the host sees that number — everything is complete then (segmentize! semantics), a few microseconds
+ * before the stream itself reports idle.  Stream-ordered calls — rt_set_option(mesh, "async", 1): for calls that march with exact
+ * steps only, rt_segmentize returns as soon as the host knows the total and the failure summary (the scan's copy), while the
+ * compaction may still be running on the mesh's stream; rt_sweep under the option queues its kernels and returns (ms = 0), so that
+ * consecutive sweeps — with the source updated through rt_sweep_xs_pointer on the same stream — run without a host turnaround.
+ * Every entry point that reads results (rt_fetch_*, rt_device_pointers, rt_fill_tau, rt_sweep*, rt_last_timing,
+ * rt_tracks_destroy) first waits; a consumer with its own stream orders against rt_mesh_get_stream or calls rt_wait.  Default 0.
+ * Calls that march track pieces, or with the "timing" option on, always complete before they return. */
 int32_t rt_wait(rt_tracks *tracks);
 
 /* Copy results into caller-allocated host buffers (any pointer may be NULL to skip it). */
@@ -226,11 +227,13 @@ int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
  *   track_weight        [n_tracks] w[u]; NULL: the previous call's, or δs[azim_idx[u]] — the weight fill_volumes gives a
  *                       segment (src/trackgenerator.jl:379-382) — if none was ever given
  *   psi_in              [2][n_tracks][G] incoming boundary flux; NULL: what the previous sweep handed on (0 at first)
- *   input               1: the compact CSR records (ℓ and element, 12 B per segment and direction); 2: the march's staging
- *                       rows directly (q and cell, 20 B; p = previous q and ℓ = ‖p − q‖ rebuilt with the Segment
- *                       constructor's expression, bit-identical) — what makes rt_set_option(mesh, "compact", 0) a complete
- *                       step: march + offsets scan + sweep, no compaction; 0: the staging rows when the last call left
- *                       them (whole-track single-pass calls do), else the compact records
+ *   input               1: the compact CSR records (ℓ and element, 12 B per segment and direction, uncoalesced); 2: rows in the
+ *                       march's staging layout, coalesced — (ℓ, cell) rows, 12 B, which a two-phase call with "compact" 0 writes
+ *                       instead of the records and which the first sweep after any other two-phase call makes from the staged
+ *                       words (once per segmentation); after a call with exact steps only: its (q, cell) rows, 20 B, ℓ = ‖p − q‖
+ *                       rebuilt with the Segment constructor's expression, bit-identical — what makes
+ *                       rt_set_option(mesh, "compact", 0) a complete step: march + offsets scan + sweep; 0 (recommended): rows
+ *                       whenever the last call left them (whole-track calls do), else the compact records
  *   ms                  (may be NULL) HIP-event duration of the sweep's kernels
  * rt_sweep_fetch copies out (any may be NULL) phi[n_cells * G], psi_out[2][n_tracks][G] (the flux every traversal ended with)
  * and psi_next[2][n_tracks][G] (the boundary flux of the next sweep).  rt_sweep_info: the device pointers of those three
@@ -366,13 +369,17 @@ void rt_msh_free(rt_msh *msh);
  *   "async"    1: stream-ordered calls, see rt_wait (default 0)
  *   "sweep_ell" 0: every pass of rt_sweep over the staged rows derives ℓ from the exit points; default 1: the first pass after an
  *                 rt_segmentize keeps ℓ per row (8 B per staging slot) and every later pass and sweep reads (ℓ, cell) rows
- *   "compact"  0: rt_segmentize stops after march + offsets scan — offsets, status and volumes are final, the 44-B records
- *                 stay in the march's staging rows (20 B/segment) and are only produced when somebody asks for them
- *                 (rt_fetch_segments*, rt_device_pointers, rt_fill_tau); rt_sweep reads the staged rows directly (default 1)
+ *   "compact"  0: rt_segmentize does not write the 44-B records — offsets, status and volumes are final, the records stay staged
+ *                 (4-B words of the two-phase march, or 20-B rows) and are only produced when somebody asks for them
+ *                 (rt_fetch_segments*, rt_device_pointers, rt_fill_tau); rt_sweep reads rows in the staging layout (default 1)
  *   "topo"     0: exact walk steps only, 1: cheap steps where >= 90 % of the walkable records carry a cheap certificate
  *                 (default), 2: forced — wherever a record carries one, and waves never hand back to exact steps
  *   "walk"     0: literal step only (find_element + intersections every iteration)
- *   "iter_cap" guard on the reference's unbounded `continue` paths (default 4,000,000 iterations per track) */
+ *   "iter_cap" guard on the reference's unbounded `continue` paths (default 4,000,000 iterations per track)
+ *   "split"    (read by rt_tracks_create) 0: never march track pieces; L > 0: pieces of about L records; default −1: pieces for
+ *                 batches that do not fill the chip (< 1,536 march waves)
+ * Development and test knobs ("march_waves", "pool_chunks_hint", "side_entries_hint", "test_*", "sweep_*", "sort_mode") are
+ * listed in DESIGN.md / tools/README.md; "single_pass" and "volumes_mode" exist only in a library built with -DRT_EXPERIMENTAL. */
 int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value);
 
 #ifdef __cplusplus

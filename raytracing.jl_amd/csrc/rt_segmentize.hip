@@ -889,7 +889,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             }
             // Everything one attempt puts on the stream(s), as one function.  (Capturing it once into a HIP graph and replaying it
             // was tried: the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on
-            // events that were only ever recorded inside a graph — DESIGN.md §4.)
+            // events that were only ever recorded inside a graph — EXPERIMENTS.md §A.)
             // fused fill_volumes accumulates into `vacc` (zero between calls: k_scan_write leaves it so); otherwise the separate
             // pass adds into `volumes`, zeroed here.  The reset kernel runs only when the control block or the accumulator is
             // not known to be clean: a handle's first call, a re-run after a pool overflow, a changed number of reserved chunks.
