@@ -410,6 +410,8 @@ void launch_scan(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long lon
 int launch_volumes_pass(hipStream_t s, rt_tracks *t, const int32_t *overflow, int64_t cap);  // fill_volumes over the compact records
 void launch_scale_volumes(hipStream_t s, double *volumes, int32_t n_cells, double n_azim_2);
 void launch_fill_tau(hipStream_t s, rt_tracks *t, int32_t n_groups);
+void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, double *As,
+                        double *Bs, double *Cs, int32_t *iperm);
 // rt_march.hip
 int launch_march(int mode, int waves, bool split, bool widek, bool topo, unsigned blocks, size_t smem, hipStream_t s, const rt::DMesh &m,
                  const rt::DTracks &t, const rt::DParams &prm, int32_t *counts, int32_t *status, const int64_t *offsets, const rt::DOut &out,

@@ -10,6 +10,10 @@
 // There is no CPU fallback in this library: without a GPU every compute entry point fails.
 #include "rt_internal.hpp"
 
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
+
 namespace rthost {
 thread_local std::string g_last_error;
 
@@ -238,26 +242,77 @@ void staging_release(int slot) {
     std::lock_guard<std::mutex> lk(g_staging_mutex);
     g_staging[(size_t)slot].busy = false;
 }
+// A few host threads that stay: starting a thread costs ≈30 µs and rt_tracks_create makes four passes over the track arrays — with
+// threads per pass that was a third of the call at the headline configuration.  One job at a time; a caller that finds the team
+// busy (rt_multi_create uploads its shards from several threads) does its work alone.
+class WorkerTeam {
+  public:
+    ~WorkerTeam() {
+        if (pid_ != getpid()) return;  // (a forked child never had the threads)
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : *th_) t.join();
+    }
+    // f(k) for k in [0, parts): part 0 on the caller's thread; `parts` comes back as the number that run (the team may not get all
+    // its threads) before the first one starts; false if the team is busy (nothing was run)
+    template <typename F>
+    bool run(unsigned &parts, F &f, std::vector<std::exception_ptr> &err) {
+        std::unique_lock<std::mutex> job(job_, std::try_to_lock);
+        if (!job.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (pid_ != getpid()) { th_ = new std::vector<std::thread>; pid_ = getpid(); }  // after a fork: the parent's threads are not here
+            while (th_->size() + 1 < parts) {
+                const unsigned id = (unsigned)th_->size() + 1;
+                try { th_->emplace_back([this, id] { loop(id); }); } catch (...) { break; }
+            }
+            parts = std::min<unsigned>(parts, (unsigned)th_->size() + 1);
+            call_ = [&f, &err](unsigned k) { try { f(k); } catch (...) { err[k] = std::current_exception(); } };
+            parts_ = parts; pending_ = parts - 1; ++gen_;
+        }
+        cv_.notify_all();
+        call_(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        return true;
+    }
+  private:
+    void loop(unsigned id) {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            if (id >= parts_) continue;
+            lk.unlock();
+            call_(id);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex m_, job_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> *th_ = new std::vector<std::thread>;
+    pid_t pid_ = getpid();
+    std::function<void(unsigned)> call_;
+    unsigned parts_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+WorkerTeam g_team;
+
 // f(i0, i1) over [0, n) on a few host threads (results must not depend on the split); what a worker throws is rethrown here
 template <typename F>
 void par_ranges(size_t n, size_t grain, F f) {
     unsigned nt = std::thread::hardware_concurrency();
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n / std::max<size_t>(grain, 1) + 1}));
     if (nt == 1) { f((size_t)0, n); return; }
-    std::vector<std::thread> th;
     std::vector<std::exception_ptr> err(nt);
-    size_t done = 0;
-    try {
-        for (unsigned k = 0; k + 1 < nt; ++k) {
-            const size_t i0 = n * k / nt, i1 = n * (k + 1) / nt;
-            std::exception_ptr *slot = &err[k];
-            th.emplace_back([=, &f]() { try { f(i0, i1); } catch (...) { *slot = std::current_exception(); } });
-            done = i1;
-        }
-    } catch (...) {  // no thread to be had: the caller's thread does the rest
-    }
-    try { f(done, n); } catch (...) { err[nt - 1] = std::current_exception(); }
-    for (auto &x : th) x.join();
+    unsigned parts = nt;  // (the team may run fewer: part k is [n·k/parts, n·(k+1)/parts) of however many do)
+    auto body = [&](unsigned k) { f(n * k / parts, n * (k + 1) / parts); };
+    const bool ran = g_team.run(parts, body, err);
+    if (!ran) { f((size_t)0, n); return; }
     for (auto &e : err)
         if (e) std::rethrow_exception(e);
 }
@@ -457,6 +512,10 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     t->n = n_tracks;
     hipStream_t s = mesh->stream;
     const size_t n = (size_t)n_tracks;
+    // RT_CREATE_TIMING=1: where the call's host time goes, to stderr (development)
+    const bool ctime = getenv("RT_CREATE_TIMING") != nullptr;
+    auto cnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double cstamp[6] = {cnow(), 0, 0, 0, 0, 0};
     // march order (default 2): waves of 64 CONSECUTIVE uids, longest wave first.  Neighbouring
     // tracks of one angle cross the same cells at the same time (shared walk records, coherent
     // branches) and have nearly equal lengths; sorting individual tracks by length measured 20 %
@@ -477,9 +536,12 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                 wmax[w] = mx;
             }
         });
+        // (keys and indices side by side: the comparator of a sort over indices alone jumps through wmax)
+        std::vector<std::pair<double, int32_t>> wkey(nw);
+        for (size_t w = 0; w < nw; ++w) wkey[w] = {wmax[w], (int32_t)w};
+        std::stable_sort(wkey.begin(), wkey.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
         std::vector<int32_t> worder(nw);
-        std::iota(worder.begin(), worder.end(), 0);
-        std::stable_sort(worder.begin(), worder.end(), [&](int32_t a, int32_t b) { return wmax[a] > wmax[b]; });
+        for (size_t w = 0; w < nw; ++w) worder[w] = wkey[w].second;
         // the batch's last wave of uids may be partial: the slots behind it are packed (no padding), so its position shifts them
         std::vector<size_t> first(nw + 1, 0);
         for (size_t w = 0; w < nw; ++w) first[w + 1] = first[w] + std::min<size_t>(64, n - (size_t)worder[w] * 64);
@@ -495,9 +557,25 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     std::vector<int32_t> h_corder;
     if (nw_all_early(n) > 4096) {  // batches of many rounds: compaction in output order (measured -8 % at 16 k waves, +1.5 % at 2 k)
         const size_t nw = (n + 63) / 64;
-        h_corder.resize(nw);
-        std::iota(h_corder.begin(), h_corder.end(), 0);
-        std::stable_sort(h_corder.begin(), h_corder.end(), [&](int32_t a, int32_t b) { return perm[(size_t)a * 64] < perm[(size_t)b * 64]; });
+        // march waves (64 slots each) in the order of the uid of their first track.  Every march wave starts in another wave of
+        // uids (the slots behind a partial last uid-wave are packed, so a march wave may straddle two of them — its first slot
+        // still lies in one no other march wave starts in): a counting sort over uid-waves
+        std::vector<int32_t> at(nw, -1);
+        for (size_t a = 0; a < nw; ++a) {
+            int32_t &slot_of = at[(size_t)perm[a * 64] >> 6];
+            if (slot_of >= 0) { at.clear(); break; }  // (not expected: fall back to the sort)
+            slot_of = (int32_t)a;
+        }
+        if (!at.empty()) {
+            h_corder.reserve(nw);
+            for (size_t w = 0; w < nw; ++w)
+                if (at[w] >= 0) h_corder.push_back(at[w]);
+        }
+        if (h_corder.size() != nw) {
+            h_corder.resize(nw);
+            std::iota(h_corder.begin(), h_corder.end(), 0);
+            std::stable_sort(h_corder.begin(), h_corder.end(), [&](int32_t a, int32_t b) { return perm[(size_t)a * 64] < perm[(size_t)b * 64]; });
+        }
     }
     {
         // Σℓ in a fixed order (blocks of 4096 tracks, added in block order) whatever the number of threads; range of azim_idx
@@ -554,52 +632,57 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     // One device allocation, one page-locked staging block (kept process-wide), one host-to-device copy: the eleven pageable
     // uploads into eleven allocations of round 3 were 31.7 ms of a C5 call whose kernels take 3.
     bool ok = true;
+    cstamp[1] = cnow();
     {
         const size_t na = (n + 31) & ~(size_t)31;  // every array starts on a 256-B boundary
         const size_t ncord = (h_corder.size() + 63) & ~(size_t)63;
-        const size_t bytes = 12 * na * sizeof(double) + 3 * na * sizeof(int32_t) + ncord * sizeof(int32_t) + 256;
+        // the arena: what goes up — nine double arrays, azim_idx, the march order, the materialise order — and behind it what a small
+        // kernel derives on the device (the lines' coefficients in march-slot order, the inverse of the march order: 28 B per track
+        // that need not cross PCIe)
+        const size_t up_bytes = 9 * na * sizeof(double) + 2 * na * sizeof(int32_t) + ncord * sizeof(int32_t);
+        const size_t bytes = up_bytes + 3 * na * sizeof(double) + na * sizeof(int32_t) + 256;
         void *stage = nullptr;
         bool may_pin = false;
-        const int slot = staging_acquire(bytes, &stage, &may_pin);
+        const int slot = staging_acquire(up_bytes + 256, &stage, &may_pin);
         struct Rel { int s; ~Rel() { staging_release(s); } } rel{slot};
         ok = t->in_arena.reserve(bytes) == hipSuccess;
         unsigned char *db = t->in_arena.p;
         const double *src8[9] = {px, py, phi, cos_phi, sin_phi, A, B, C, ell};
-        DevView<double> *dst8[12] = {&t->px, &t->py, &t->phi, &t->cs, &t->sn, &t->A, &t->B, &t->C, &t->ell, &t->As, &t->Bs, &t->Cs};
+        DevView<double> *dst8[9] = {&t->px, &t->py, &t->phi, &t->cs, &t->sn, &t->A, &t->B, &t->C, &t->ell};
+        const size_t ints_off = 9 * na * sizeof(double);
         if (ok) {
-            for (int a = 0; a < 12; ++a) dst8[a]->p = (double *)(db + (size_t)a * na * sizeof(double));
-            t->azim.p = (int32_t *)(db + 12 * na * sizeof(double)); t->perm.p = t->azim.p + na; t->iperm.p = t->perm.p + na;
-            t->corder.p = h_corder.empty() ? nullptr : t->iperm.p + na;
+            for (int a = 0; a < 9; ++a) dst8[a]->p = (double *)(db + (size_t)a * na * sizeof(double));
+            t->azim.p = (int32_t *)(db + ints_off); t->perm.p = t->azim.p + na;
+            t->corder.p = h_corder.empty() ? nullptr : t->perm.p + na;
+            t->As.p = (double *)(db + up_bytes); t->Bs.p = t->As.p + na; t->Cs.p = t->Bs.p + na;
+            t->iperm.p = (int32_t *)(t->Cs.p + na);
         }
-        // the host image of the arena: the staging block, or — a process's first track set, before anything is pinned — only the
-        // derived arrays in a pageable vector (the caller's arrays then go up from where they lie)
-        std::vector<unsigned char> derived;
+        // the host image of the uploaded part: the staging block, or — a process's first track set, before anything is pinned — only
+        // the integer arrays in a pageable vector (the caller's arrays then go up from where they lie)
+        std::vector<unsigned char> ints;
+        cstamp[2] = cnow();
         unsigned char *hb = (unsigned char *)stage;
-        const size_t derived_off = 9 * na * sizeof(double);
-        if (ok && slot < 0) derived.resize(bytes - derived_off);
+        if (ok && slot < 0) ints.resize(up_bytes - ints_off + 256);
         if (ok) {
-            unsigned char *hd = slot >= 0 ? hb + derived_off : derived.data();  // the derived arrays' part of the image
-            double *h_As = (double *)hd, *h_Bs = h_As + na, *h_Cs = h_Bs + na;
-            int32_t *h_az = (int32_t *)(hd + 3 * na * sizeof(double)), *h_pm = h_az + na, *h_ip = h_pm + na, *h_co = h_ip + na;
+            unsigned char *hd = slot >= 0 ? hb + ints_off : ints.data();
+            int32_t *h_az = (int32_t *)hd, *h_pm = h_az + na, *h_co = h_pm + na;
             par_ranges(n, 16384, [&](size_t i0, size_t i1) {
                 if (slot >= 0)
                     for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * na * sizeof(double)) + i0, src8[a] + i0, (i1 - i0) * sizeof(double));
                 memcpy(h_az + i0, azim_idx + i0, (i1 - i0) * sizeof(int32_t));
                 memcpy(h_pm + i0, perm.data() + i0, (i1 - i0) * sizeof(int32_t));
-                for (size_t i = i0; i < i1; ++i) {  // (slot i holds track perm[i])
-                    const int32_t u = perm[i];
-                    h_As[i] = A[u]; h_Bs[i] = B[u]; h_Cs[i] = C[u];
-                    h_ip[u] = (int32_t)i;
-                }
             });
             if (!h_corder.empty()) memcpy(h_co, h_corder.data(), h_corder.size() * sizeof(int32_t));
+            cstamp[3] = cnow();
             if (slot >= 0) {
-                ok = hipMemcpyAsync(db, hb, bytes - 256, hipMemcpyHostToDevice, s) == hipSuccess;
+                ok = hipMemcpyAsync(db, hb, up_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
             } else {
                 for (int a = 0; a < 9 && ok && n > 0; ++a) ok = hipMemcpyAsync(dst8[a]->p, src8[a], n * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
-                ok = ok && hipMemcpyAsync(db + derived_off, derived.data(), derived.size() - 256, hipMemcpyHostToDevice, s) == hipSuccess;
+                ok = ok && hipMemcpyAsync(db + ints_off, ints.data(), up_bytes - ints_off, hipMemcpyHostToDevice, s) == hipSuccess;
             }
-            ok = ok && hipStreamSynchronize(s) == hipSuccess;
+            if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->As.p, t->Bs.p, t->Cs.p, t->iperm.p);
+            ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            cstamp[4] = cnow();
         }
         ok = ok && t->cnt_slot.reserve(na + 64) == hipSuccess && t->off_slot.reserve(na + 64) == hipSuccess && t->w_slot.reserve(na + 64) == hipSuccess;
     }
@@ -629,6 +712,9 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p); d.w_slot = as_global(t->w_slot.p);
     d.n = n_tracks;
     guard.p = nullptr;
+    if (ctime)
+        fprintf(stderr, "[rt_tracks_create] %lld tracks: order + plan %.3f ms, arena + staging %.3f, host image %.3f, copy + sync %.3f, rest %.3f\n", (long long)n_tracks,
+                cstamp[1] - cstamp[0], cstamp[2] - cstamp[1], cstamp[3] - cstamp[2], cstamp[4] - cstamp[3], cnow() - cstamp[4]);
     return t;
 }
 
