@@ -812,7 +812,13 @@ struct TopoTrack {   // per-track constants
 struct TopoState {
     int32_t pred;    // record of the predicted cell (3·T' + entry edge), -1: none
     int32_t last;    // 3·T + exit edge of the last emitted record
-    double sa, sb;   // signed distances of the end points (a, b) of T's exit edge, in T's edge orientation
+    // signed distances from the track line of the end points of T's exit edge (= T''s entry edge), kept BY SIDE: sp of the end point
+    // on the positive side, sn of the other one (the line crosses the edge: sp > 0 >= sn).  The predicted cell's third vertex
+    // replaces the end point on its own side — the line leaves through the edge of the two that are then on opposite sides — so a
+    // step moves one value instead of choosing four (round 4: the selects by edge orientation were a fifth of the loop's vector
+    // instructions); which of the two is the edge's first end point in T's orientation is one bit.
+    double sp, sn;
+    bool apos;       // the edge's first end point (a) is the one on the positive side
 };
 enum TopoResult { kTopoFull = 0, kTopoEmit = 1, kTopoEnd = 2 };
 
@@ -832,7 +838,9 @@ RT_HD __forceinline__ void edge_exit_point(double tA, double tB, double tC, doub
 // topo_geo — which edge the line leaves T' through and what comes behind it; topo_certified — the certificates;
 // topo_commit — advance the state.  topo_step is the three in a row (tests/host_march.hip).
 struct TopoGeo {
-    double s0, s1, s2;  // signed distances of v0, v1 (entry edge, in T''s orientation) and v2 from the track line
+    double s2;          // signed distance of v2 (the vertex opposite the entry edge) from the track line
+    bool p2;            // v2 lies on the positive side
+    bool pv1;           // v1 (the entry edge's second vertex in T''s orientation) lies on the positive side
     bool exit1;         // the line leaves through rotated edge 1 = (v1, v2), else edge 2 = (v2, v0)
     uint32_t nx;        // successor field behind the exit edge: record + 1, 0, kTopoEndV / kTopoEndH
     int32_t code;       // 3·T' + exit edge (in T''s own edge numbering)
@@ -840,10 +848,10 @@ struct TopoGeo {
 };
 RT_HD __forceinline__ TopoGeo topo_geo(const TopoState &ts, uint64_t hdr, double x2, double y2, double tA, double tB, double tC) {
     TopoGeo g;
-    const bool same = rec_same(hdr);
-    g.s0 = same ? ts.sa : ts.sb; g.s1 = same ? ts.sb : ts.sa;
     g.s2 = __builtin_fma(tA, x2, __builtin_fma(tB, y2, tC));
-    g.exit1 = (g.s1 > 0) != (g.s2 > 0);
+    g.p2 = g.s2 > 0;
+    g.pv1 = rec_same(hdr) != ts.apos;  // (v0, v1) = (a, b) if the record's entry edge runs as T's exit edge does, else (b, a)
+    g.exit1 = g.pv1 != g.p2;           // v1 and v2 on opposite sides
     g.nx = g.exit1 ? (uint32_t)(hdr & ((1u << kWalkIdBits) - 1)) : (uint32_t)((hdr >> kWalkIdBits) & ((1u << kWalkIdBits) - 1));
     const int32_t pr = ts.pred >= 0 ? ts.pred : 0;
     const int32_t Tn = (int32_t)((uint32_t)pr / 3u), e = pr - 3 * Tn;
@@ -858,12 +866,12 @@ RT_HD __forceinline__ int32_t topo_next(const TopoGeo &g) { return (g.nx - 1u) <
 // `kub`: upper bound of the reference's iterations for this record — 1 + at most √eps·dtf / (tiny·D) + 2 tiny steps (<= kTopoKcap)
 RT_HD __forceinline__ bool topo_certified(const TopoTrack &tt, const TopoState &ts, const TopoGeo &g, uint64_t hdr, uint32_t c01,
                                           uint32_t c23, int kk, int32_t &kub) {
-    const double a0 = fabs(g.s0), a1 = fabs(g.s1), a2 = fabs(g.s2);
-    const double D = a0 + a1, m = a0 < a1 ? a0 : a1;
-    const double sv = g.exit1 ? a1 : a0, Dx = a2 + sv;
+    const double ap = fabs(ts.sp), an = fabs(ts.sn), a2 = fabs(g.s2);
+    const double D = ap + an, m = ap < an ? ap : an;
+    const double sv = g.p2 ? an : ap, Dx = a2 + sv;  // (the end point that stays: the one across the line from v2)
     const double g1 = bf16_lo(c01), k2 = bf16_hi(c01), dtf = bf16_lo(c23), lc = bf16_hi(c23);
     // (evaluated without short-circuits: a branch here would also pull the record's second load behind the first compare)
-    const int ok = (int)(ts.pred >= 0) & (int)(rec_extras(hdr) <= kk) & (int)(a2 >= tt.dv) & (int)((g.s0 > 0) != (g.s1 > 0)) &
+    const int ok = (int)(ts.pred >= 0) & (int)(rec_extras(hdr) <= kk) & (int)(a2 >= tt.dv) & (int)((ts.sp > 0) != (ts.sn > 0)) &
                    (int)(m >= __builtin_fma(rec_eps(hdr), D, g1)) & (int)(D >= k2) & (int)(Dx >= k2) & (int)(D * tt.c1 >= dtf) &
                    (int)(sv >= lc * tt.lcf);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -880,21 +888,28 @@ RT_HD __forceinline__ bool topo_certified(const TopoTrack &tt, const TopoState &
 // 5 D < k2, 6 Dx < k2, 7 D·c1 < dtf, 8 |s_v| < lc·lcf.  Statistics only (cold path of k_march, tests).
 RT_HD __forceinline__ uint32_t topo_refusal_terms(const TopoTrack &tt, const TopoState &ts, const TopoGeo &g, uint64_t hdr, uint32_t c01,
                                                   uint32_t c23, int kk) {
-    const double a0 = fabs(g.s0), a1 = fabs(g.s1), a2 = fabs(g.s2);
-    const double D = a0 + a1, m = a0 < a1 ? a0 : a1;
-    const double sv = g.exit1 ? a1 : a0, Dx = a2 + sv;
+    const double ap = fabs(ts.sp), an = fabs(ts.sn), a2 = fabs(g.s2);
+    const double D = ap + an, m = ap < an ? ap : an;
+    const double sv = g.p2 ? an : ap, Dx = a2 + sv;
     const double g1 = bf16_lo(c01), k2 = bf16_hi(c01), dtf = bf16_lo(c23), lc = bf16_hi(c23);
     return (uint32_t)!(ts.pred >= 0) | (uint32_t)!(rec_extras(hdr) <= kk) << 1 | (uint32_t)!(a2 >= tt.dv) << 2 |
-           (uint32_t)!((g.s0 > 0) != (g.s1 > 0)) << 3 | (uint32_t)!(m >= __builtin_fma(rec_eps(hdr), D, g1)) << 4 |
+           (uint32_t)!((ts.sp > 0) != (ts.sn > 0)) << 3 | (uint32_t)!(m >= __builtin_fma(rec_eps(hdr), D, g1)) << 4 |
            (uint32_t)!(D >= k2) << 5 | (uint32_t)!(Dx >= k2) << 6 | (uint32_t)!(D * tt.c1 >= dtf) << 7 |
            (uint32_t)!(sv >= lc * tt.lcf) << 8;
 }
 // kTopoEmit: on to the successor (pred = -1 when there is none with a certificate: exact steps from `last`);
 // kTopoEnd: the exit edge lies on the border and the track ends for sure after this record
+// The exit edge's end points by side: v2 replaces the end point on its own side.  (The edge's first end point in T''s orientation is
+// v1 if the line leaves through (v1, v2) and v2 otherwise — v2 then lies where v1 does — so the orientation bit is `pv1` either
+// way.)  k_march calls this for every lane, committed or not: a lane that does not commit leaves the cheap loop and comes back
+// through topo_enter.
+RT_HD __forceinline__ void topo_advance(TopoState &ts, const TopoGeo &g) {
+    ts.sp = g.p2 ? g.s2 : ts.sp;
+    ts.sn = g.p2 ? ts.sn : g.s2;
+    ts.apos = g.pv1;
+}
 RT_HD __forceinline__ int topo_commit(const TopoTrack &tt, TopoState &ts, const TopoGeo &g) {
     ts.last = g.code;
-    ts.sa = g.exit1 ? g.s1 : g.s2;
-    ts.sb = g.exit1 ? g.s2 : g.s0;
     ts.pred = topo_next(g);
     return ((g.nx == kTopoEndV && tt.end_v) || (g.nx == kTopoEndH && tt.end_h)) ? kTopoEnd : kTopoEmit;
 }
@@ -905,6 +920,7 @@ RT_HD __forceinline__ int topo_step(const TopoTrack &tt, TopoState &ts, uint64_t
     const TopoGeo g = topo_geo(ts, hdr, x2, y2, tA, tB, tC);
     if (!topo_certified(tt, ts, g, hdr, c01, c23, kk, kub)) return kTopoFull;
     code = g.code;
+    topo_advance(ts, g);
     return topo_commit(tt, ts, g);
 }
 
@@ -913,7 +929,7 @@ RT_HD __forceinline__ bool topo_enter(const DMesh &m, const TopoTrack &tt, const
     if (!(tt.on && wk.pred >= 0)) return false;
     const double sa = __builtin_fma(tA, wk.ax, __builtin_fma(tB, wk.ay, tC)), sb = __builtin_fma(tA, wk.bx, __builtin_fma(tB, wk.by, tC));
     if (!(fabs(sa) >= tt.dv && fabs(sb) >= tt.dv && ((sa > 0) != (sb > 0)))) return false;
-    ts.pred = wk.pred; ts.sa = sa; ts.sb = sb;
+    ts.pred = wk.pred; ts.apos = sa > 0; ts.sp = ts.apos ? sa : sb; ts.sn = ts.apos ? sb : sa;
     ts.last = m.adjr[wk.pred];  // the record reached back across T''s entry edge: 3·T + exit edge
     return true;
 }

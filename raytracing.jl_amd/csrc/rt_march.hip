@@ -257,17 +257,20 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     load_next(mh, -1, nr);
     // per-lane state of the cheap step
     TopoTrack tt = topo_track(TOPO && m.walk_ok, m.d_vertex, prm.topo_tiny_max, prm.topo_rmax, prm.topo_end_err, prm.tiny_step, t.cs[u], t.sn[u]);
+    // (wave-uniform constants of the cheap loop in vector registers: the scalar file is the short one — 73 scalar values of the
+    //  kernel live in vector lanes, and every use of one inside the loop is a v_readlane)
+    if (TOPO) asm volatile("" : "+v"(tt.dv), "+v"(tt.c1), "+v"(tt.c2));
     TopoState ts;
-    ts.pred = -1; ts.last = 0; ts.sa = ts.sb = 0.0;
+    ts.pred = -1; ts.last = 0; ts.sp = ts.sn = 0.0; ts.apos = false;
     // kFlCheap: the lane takes cheap steps; kFlUsed: it has taken some (`it` is then an upper bound of the reference's
     // iterations); kFlMat: the exact step's state has to be rebuilt from `ts.last`; kFlWait: nothing to do until the wave
     // has no cheap lane left (an uncertified last step, a finished track); kFlDone / kFlRestart: see below
     constexpr uint32_t kFlCheap = 1, kFlUsed = 2, kFlMat = 4, kFlWait = 8, kFlDone = 16, kFlRestart = 32;
     uint32_t fl = 0;
     // positions along the track line, t(x, y) = B·x − A·y ((B, −A) is the line's direction; general_form normalises the whole
-    // (A, B, C), src/intersection.jl:11-18, so t is scaled by ‖(A, B)‖), of the end points of the lane's entry edge (as ts.sa /
-    // ts.sb) and of its last exit point: the chord a cheap record adds to fill_volumes is |Δt| / ‖(A, B)‖ — the scale rides in wq
-    double tta = 0.0, ttb = 0.0, ttp = 0.0;
+    // (A, B, C), src/intersection.jl:11-18, so t is scaled by ‖(A, B)‖), of the end points of the lane's entry edge (by side, as
+    // ts.sp / ts.sn) and of its last exit point: the chord a cheap record adds to fill_volumes is |Δt| / ‖(A, B)‖ — the scale rides in wq
+    double ttP = 0.0, ttN = 0.0, ttp = 0.0;
     const double nab = (TOPO && FUSE) ? sqrt(tA * tA + tB * tB) : 1.0;
     const double wq = (TOPO && FUSE) ? w / nab : 0.0;
     // what the approximate chord may be used for (rt_mesh_prep.hpp, tally_c1 / tally_c2; s and t are scaled by ‖(A, B)‖)
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     double dprev = 0.0;  // |s_p − s_q| of the crossing the lane's last exit point came from (∞: an exact step's point)
     int32_t n_exact_tally = 0;  // cheap records of this lane whose fill_volumes term is left to k_materialise
     auto topo_tally_enter = [&]() {
-        tta = __builtin_fma(tB, wk.ax, -(tA * wk.ay)); ttb = __builtin_fma(tB, wk.bx, -(tA * wk.by));
+        const double ta = __builtin_fma(tB, wk.ax, -(tA * wk.ay)), tb = __builtin_fma(tB, wk.bx, -(tA * wk.by));
+        ttP = ts.apos ? ta : tb; ttN = ts.apos ? tb : ta;
         ttp = __builtin_fma(tB, lqx, -(tA * lqy));
         dprev = INFINITY;  // (an exact step's exit point)
     };
@@ -392,26 +396,26 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     ++n_cheap_it;
                     n_cheap_ref += __ballot(cheap && !ok) != 0 ? 1 : 0;
                     const bool commit = cheap && ok && !over;
+                    const double sp0 = ts.sp, sn0 = ts.sn;  // (the refusal statistic's cold branch evaluates the terms on the entry edge again)
+                    topo_advance(ts, g);  // (every lane: the state of one that does not commit is dead)
                     bool inexact = false;
                     if (FUSE) {
-                        // fill_volumes (src/trackgenerator.jl:382) for this record: the line meets the exit edge (p, q) — end points on
-                        // opposite sides, |s_p − s_q| >= the record's k2 — at t = (s_p·t_q − s_q·t_p) / (s_p − s_q)
-                        const bool same = rec_same(c_hdr);
-                        const double t0 = same ? tta : ttb, t1 = same ? ttb : tta;
+                        // fill_volumes (src/trackgenerator.jl:382) for this record: the line meets the exit edge — its end points P, N on
+                        // either side, s_P − s_N >= the record's k2 — at t = (s_P·t_N − s_N·t_P) / (s_P − s_N)
                         const double t2 = __builtin_fma(tB, c_x2, -(tA * c_y2));
-                        const double sp = g.exit1 ? g.s1 : g.s2, sq = g.exit1 ? g.s2 : g.s0;
-                        const double tp = g.exit1 ? t1 : t2, tq = g.exit1 ? t2 : t0;
-                        const double den = sp - sq;
+                        ttP = g.p2 ? t2 : ttP; ttN = g.p2 ? ttN : t2;
+                        const double den = ts.sp - ts.sn;
                         double rc = __builtin_amdgcn_rcp(den);
                         rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
                         rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
-                        const double tx = (sp * tq - sq * tp) * rc;
+                        const double tx = (ts.sp * ttN - ts.sn * ttP) * rc;
                         // (a chord that is short, or one of whose ends is a shallow crossing, is left to k_materialise: its relative
                         //  error bound, rt_mesh_prep.hpp, is 2e-11·(c1/chord + c2/(chord·min D_x)) — per record, hence for every sum)
                         const double ch = fabs(tx - ttp), dmin = fmin(fabs(den), dprev);
                         inexact = !(ch >= tc1 && ch * dmin >= tc2);
                         atomicAdd(&hist[g.cell], (commit && !inexact) ? wq * ch : 0.0);  // (LDS-private; a lane that decided nothing adds 0)
-                        if (commit) { ttp = tx; tta = tp; ttb = tq; dprev = fabs(den); n_exact_tally += inexact ? 1 : 0; }
+                        ttp = tx; dprev = fabs(den);  // (of a lane that does not commit: dead until topo_tally_enter)
+                        n_exact_tally += (commit && inexact) ? 1 : 0;
                     }
                     if (commit) {
                         ++i;
@@ -425,7 +429,9 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                         fl = (fl & ~kFlCheap) | (ok ? kFlRestart : kFlMat);  // refused: the exact step decides this record
                         // per-call statistic (rt_last_stats): which certificate term refused — a cold branch (every refusal
                         // costs its wave an exact step anyway); one atomic per term and wave
-                        const uint32_t bad = ok ? 0u : topo_refusal_terms(tt, ts, g, c_hdr, c_c01, c_c23, kk);
+                        TopoState ts0 = ts;
+                        ts0.sp = sp0; ts0.sn = sn0;
+                        const uint32_t bad = ok ? 0u : topo_refusal_terms(tt, ts0, g, c_hdr, c_c01, c_c23, kk);
                         unsigned long long *ctl = march_ctl();
                         const int first = __ffsll((long long)__ballot(1)) - 1;
                         for (int b = 0; b < 9; ++b) {

@@ -75,7 +75,7 @@ void march_track(const rt::DMesh &m, const rt::DGeo &g, double px0, double py0, 
     using namespace rt;
     const size_t out_base = out.size();
     TopoTrack tt = tt0;
-    TopoState ts{-1, -1, 0.0, 0.0};
+    TopoState ts{-1, -1, 0.0, 0.0, false};
     bool cheap = false, used_cheap = false;
 restart:
     const double sx = tiny * cs, sy = tiny * sn;  // advance_step, src/point.jl:43
