@@ -98,6 +98,7 @@ struct DOut {
 constexpr int kChunkLog2 = RT_CHUNK_LOG2;
 constexpr int kChunkRows = 1 << kChunkLog2;
 constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
+constexpr int kStaticRegions = 12;  // chunk indices with a reserved region (see DStage): 384 records per track
 
 constexpr int32_t kWordExactTally = 1 << 30;  // staged word of a cheap record whose fill_volumes term k_materialise adds (see DStage)
 struct DStage {
@@ -108,7 +109,13 @@ struct DStage {
     RT_G int32_t *cowner;   // [pool_chunks] wave * kMaxChunks + j of the chunk's owner
     RT_G int32_t *cursor;   // [0] chunks handed out, [1] overflow flag
     int32_t pool_chunks;
-    int32_t static0;        // 1: chunk w is reserved as the first chunk of march wave w (whole-track march; cursor starts at n_waves)
+    // Whole-track marches: chunk j of march wave w is chunk reg_base[j] + w for w < reg_cap[j] — reserved by the host from the
+    // waves' estimated record counts (the waves are ordered longest first, so the waves that need a j-th chunk are a prefix), the
+    // cursor starts behind the regions.  No atomic and — for k_materialise — no table lookup in front of a wave's first loads:
+    // the chunk id follows from (w, j) and 2 x kStaticRegions kernel arguments.  Chunks beyond the estimate come from the
+    // cursor as before; ctab / cowner are written for every chunk either way (k_compact3, rt_sweep read them).
+    int32_t n_regions;      // regions in use (0: every chunk from the cursor)
+    int32_t reg_cap[kStaticRegions], reg_base[kStaticRegions];
     // k_march<TOPO> stages ONE word per record in `element`: 3·cell + exit edge + 1 (the record is a function of the track's
     // line, that edge and the previous record: k_materialise computes it), or -(index + 1) of an entry of the side list below
     // for a record that keeps its own end points (the generic step's: every track's first one, refusals).  Bit 30 of a positive
@@ -337,6 +344,7 @@ struct rt_tracks {
     int64_t pool_chunks = 0, chunks_needed_last = 0, total_last = 0;
     // split mode (pieces of tracks)
     int32_t n_vwaves = 0;
+    int32_t reg_cap[rt::kStaticRegions] = {};  // reserved staging chunks per chunk index (DStage), from the waves' expected record counts
     DevBuf<int32_t> vorder, vw_wave, vw_k, w_base, w_P, s_el, s_eq, p_count, p_flags, p_valid, p_rel;
     DevBuf<double> s_px, s_py, s_qx, s_qy, s_ell, p_sum;
     double sum_ell = 0.0;

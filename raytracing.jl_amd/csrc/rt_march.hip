@@ -317,9 +317,9 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 if (lane == L) {
                     const RT_K DStage *sk = march_stage_args();
                     RT_G int32_t *cursor = sk->cursor;
-                    // a wave's first chunk is chunk `wave_id` when the host reserved one per wave (the cursor then starts
-                    // behind them): every wave allocates at the same moment, on its first record — 2,039 atomics on one word
-                    if (!SPLIT && jL == 0 && sk->static0) c = (int32_t)wave_id;
+                    // a chunk the host reserved (DStage: regions by chunk index; the cursor starts behind them) needs no atomic —
+                    // every wave wants its first chunk at the same moment, on its first record: 2,039 atomics on one word
+                    if (!SPLIT && jL < sk->n_regions && wave_id < sk->reg_cap[jL]) c = sk->reg_base[jL] + (int32_t)wave_id;
                     else c = atomicAdd((int32_t *)&cursor[0], 1);
                     if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
                     else {

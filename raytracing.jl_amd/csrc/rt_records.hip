@@ -187,7 +187,14 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
     double tA = 0.0, tB = 0.0, tC = 0.0;
     const bool have = slot < t.n;
     const RT_G int32_t *ctab = stg.ctab + w * kMaxChunks;
-    const int32_t c_first = ctab[kw];
+    // chunk j of this march wave: reserved chunks follow from (w, j) and kernel arguments — the wave's words can be fetched with its
+    // very first loads; only chunks beyond the host's estimate are looked up (a load the words would have to wait for)
+    auto chunk_id = [&](const int j) -> int32_t {
+        const int js = __builtin_amdgcn_readfirstlane(j);
+        if (js < stg.n_regions && w < stg.reg_cap[js]) return stg.reg_base[js] + (int32_t)w;
+        return ctab[js];
+    };
+    const int32_t c_first = chunk_id(kw);
     if (have) {
         u = t.perm[slot];
         cnt = t.cnt_slot[slot];
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
     double acc = 0.0;  // Σℓ of this lane's rows of its load-mapping track
     for (int j = kw; (j << kChunkLog2) < gmax; j += 4) {
         const int r0 = j << kChunkLog2;
-        const int32_t c = j == kw ? c_first : ctab[j];
+        const int32_t c = j == kw ? c_first : chunk_id(j);
         // ---- the chunk's words, in the load mapping (lane = track tl, rows 4 i + rr)
         int32_t ve[8];
 #pragma unroll
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256, RT_MAT_OCC) void k_materialise(DTracks t, cons
         double hx = 0.0, hy = 0.0;
         if (j > 0) {  // (uniform; a track's first chunk starts with a record of the generic step)
             int32_t hw = 0;
-            if (lane < 16 && cnt > r0) hw = stg.element[stage_slot(ctab[j - 1], kChunkRows - 1, lane_q)];
+            if (lane < 16 && cnt > r0) hw = stg.element[stage_slot(chunk_id(j - 1), kChunkRows - 1, lane_q)];
             if (hw > 0) hw &= ~kWordExactTally;
             const RT_G EdgeABC *he = a.etab + (hw > 0 ? hw - 1 : 0);
             const double hA = he->A, hB = he->B, hC = he->C;

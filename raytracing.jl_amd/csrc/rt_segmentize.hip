@@ -554,6 +554,26 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     } else {
         std::iota(perm.begin(), perm.end(), 0);
     }
+    {
+        // Reserved staging chunks (DStage): march wave w (64 slots of the march order) is expected to need
+        // ceil((1.15·κ·ℓ_max + 12) / 32) chunks — κ·ℓ is the Cauchy–Crofton mean, a wave through a denser part of the mesh takes
+        // its further chunks from the cursor — and region j serves the leading waves that need a j-th chunk
+        const size_t nw = (n + 63) / 64;
+        std::vector<int32_t> need(nw, 1);
+        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                double mx = 0.0;
+                for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[perm[i]]);
+                const double est = 1.15 * mesh->kappa * mx + 12.0;
+                need[w] = (int32_t)std::min<double>((double)rt::kStaticRegions, std::max(1.0, std::ceil(est / (double)rt::kChunkRows)));
+            }
+        });
+        for (int j = 0; j < rt::kStaticRegions; ++j) {
+            size_t c = 0;
+            while (c < nw && need[c] > j) ++c;
+            t->reg_cap[j] = (int32_t)c;
+        }
+    }
     std::vector<int32_t> h_corder;
     if (nw_all_early(n) > 4096) {  // batches of many rounds: compaction in output order (measured -8 % at 16 k waves, +1.5 % at 2 k)
         const size_t nw = (n + 63) / 64;
@@ -911,6 +931,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         int64_t want = t->chunks_needed_last > 0
                            ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
                            : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * ((split ? t->n_vwaves : 0) + (split_all ? 0 : n_whole_waves)) + 64;
+        if (!split) {  // (the reserved regions of the whole-track march and some room behind them)
+            int64_t res = 0;
+            for (int j = 0; j < rt::kStaticRegions; ++j) res += t->reg_cap[j];
+            want = std::max(want, res + res / 8 + 64);
+        }
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
         fused_volumes_this_call = fuse;
         // the side list of the two-phase march: one reserved entry per march slot (a track's first record) + the records the
@@ -954,7 +979,18 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
             stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
             stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
-            stg.static0 = (!split && n_whole_waves < stg.pool_chunks) ? 1 : 0;
+            // reserved chunks of the whole-track march (DStage): region j holds chunk j of the first reg_cap[j] march waves
+            int64_t reserved = 0;
+            stg.n_regions = 0;
+            if (!split) {
+                for (int j = 0; j < rt::kStaticRegions && t->reg_cap[j] > 0; ++j) {
+                    if (reserved + t->reg_cap[j] >= stg.pool_chunks) break;
+                    stg.reg_cap[j] = t->reg_cap[j]; stg.reg_base[j] = (int32_t)reserved;
+                    reserved += t->reg_cap[j];
+                    stg.n_regions = j + 1;
+                }
+            }
+            for (int j = stg.n_regions; j < rt::kStaticRegions; ++j) stg.reg_cap[j] = stg.reg_base[j] = 0;
             if (topo) {
                 stg.s_px = as_global(t->side_px.p); stg.s_py = as_global(t->side_py.p); stg.s_qx = as_global(t->side_qx.p);
                 stg.s_qy = as_global(t->side_qy.p); stg.s_el = as_global(t->side_el.p);
@@ -979,7 +1015,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             // fused fill_volumes accumulates into `vacc` (zero between calls: k_scan_write leaves it so); otherwise the separate
             // pass adds into `volumes`, zeroed here.  The reset kernel runs only when the control block or the accumulator is
             // not known to be clean: a handle's first call, a re-run after a pool overflow, a changed number of reserved chunks.
-            first_chunk_this_call = stg.static0 ? (int32_t)n_whole_waves : 0;
+            first_chunk_this_call = (int32_t)reserved;
             side_first_this_call = topo ? (int32_t)side_static : 0;
             const int64_t reset_key = (int64_t)first_chunk_this_call | ((int64_t)side_first_this_call << 32);
             if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
