@@ -270,6 +270,7 @@ struct rt_mesh {
     int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
     double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0, tally_a = 0.0, tally_b = 0.0;
+    int64_t test_reserved_pct = -1;  // tests only: the staging chunks reserved per wave as a percentage of the estimate (< 0: all of it)
     int64_t test_tally_tau = 0;  // tests, A/B: the relative error allowed to a cheap record's chord in fill_volumes, in 1e-12 (0: 8e-11; < 0: none — every cheap record tallied by k_materialise)
     int64_t n_records_topo = 0;
     int fuse_volumes = 1;  // 1: fill_volumes inside the single-pass march (LDS-private) when the mesh fits

@@ -487,6 +487,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "test_exact_sums")) { mesh->test_exact_sums = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "test_tally_tau")) { mesh->test_tally_tau = value; return RT_SUCCESS; }
+    if (!strcmp(name, "test_reserved_pct")) { mesh->test_reserved_pct = value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "side_entries_hint")) { mesh->side_entries_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "walk")) {  // 0: generic step only (literal emulation), 1: certified walk step + generic fallback
@@ -564,7 +565,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             for (size_t w = w0; w < w1; ++w) {
                 double mx = 0.0;
                 for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[perm[i]]);
-                const double est = 1.15 * mesh->kappa * mx + 12.0;
+                const double est = (1.15 * mesh->kappa * mx + 12.0) * (mesh->test_reserved_pct >= 0 ? 0.01 * (double)mesh->test_reserved_pct : 1.0);
                 need[w] = (int32_t)std::min<double>((double)rt::kStaticRegions, std::max(1.0, std::ceil(est / (double)rt::kChunkRows)));
             }
         });

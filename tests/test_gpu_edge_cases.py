@@ -240,6 +240,12 @@ def test_two_phase_march_regime_and_memory(rt, traced, oracle_run):
         assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
         st = dt.stats()
         assert (st["cheap_records"] > 0.9 * ref["total"]) == (topo == 1)
+        # fill_volumes of cheap records: the chord from the vertices' distances where its error bound allows, the record's own
+        # length (k_materialise) for the short chords and shallow crossings — some, not most
+        if topo == 1:
+            assert 0 < st["records_tallied_from_lengths"] < 0.25 * st["cheap_records"], st
+        else:
+            assert st["records_tallied_from_lengths"] == 0
         held[topo] = st["device_bytes"]
         assert np.array_equal(dt.fetch_segments()["ell"], ref["ell"])
         dt.close(); dm.close()
@@ -260,6 +266,29 @@ def test_staging_pool_overflow_is_recovered(rt, traced, oracle_run):
     aq = tg.azimuthal_quadrature
     assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
     assert np.array_equal(dt.fetch_segments()["element"], ref["element"])
+
+
+@pytest.mark.parametrize("pct", [0, 35, 100, 300])
+def test_reserved_and_cursor_chunks_mix(rt, traced, oracle_run, pct):
+    """The staging pool reserves chunks per chunk index from the waves' expected record counts and hands out the rest from its
+    cursor.  With the reservation scaled down (0: only every wave's first chunk; 35 %: most waves need chunks from
+    the cursor behind their reserved ones) or up, the records are the same."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    aq = tg.azimuthal_quadrature
+    for topo in (1, 0):
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        dm.set_option("split", 0); dm.set_option("topo", topo); dm.set_option("test_reserved_pct", pct)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        for _ in range(2):  # (the second call sizes the pool from the first one's need)
+            assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"]
+            seg = dt.fetch_segments()
+            for k in ("px", "py", "qx", "qy", "ell", "element"):
+                assert np.array_equal(seg[k], ref[k]), (pct, topo, k)
+            np.testing.assert_allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10)
+        dt.close(); dm.close()
 
 
 def test_enqueue_hook_runs_once_per_call_beside_the_kernels(rt, traced, oracle_run):
