@@ -205,36 +205,54 @@ void free_tracks(rt_tracks *t) {
 
 }  // namespace
 
-// Page-locked staging blocks for the upload of a track set: kept process-wide (pinning costs milliseconds), one per concurrent
-// caller (rt_multi_create uploads its shards from several threads).
+// Page-locked staging blocks for the upload of a track set: kept process-wide, one per concurrent caller (rt_multi_create uploads
+// its shards from several threads), of ONE fixed size.  A track set larger than half a block goes up in ranges through the block's
+// two halves — the host writes one half while the other is in flight — so that no call pays for page-locking its whole input (0.08 ms
+// per MB: 11 ms for a BWR assembly's 90 MB, the whole of round 3's upload again) and the page-locked memory a process holds is bounded.
 namespace {
-struct StagingBlock { void *p = nullptr; size_t cap = 0; bool busy = false; };
+constexpr size_t kStageBytes = 32u << 20;
+struct StagingBlock { void *p = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy = false; };
 std::vector<StagingBlock> g_staging;
 std::mutex g_staging_mutex;
-long g_staging_calls = 0;
-// allocate: pin a new block when none fits (milliseconds per 10 MB: only worth it for a process that uploads track sets repeatedly)
-int staging_acquire(size_t bytes, void **out, bool *allocate_if_missing) {
+bool staging_new_block(StagingBlock &b) {
+    if (hipHostMalloc(&b.p, kStageBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return false; }
+    for (auto &e : b.ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(b.p); b.p = nullptr; return false; }
+    return true;
+}
+// The process's first block is page-locked (≈1.4 ms) by a thread that rt_mesh_create starts — a mesh always precedes its track sets,
+// and its own preprocessing and upload take longer than that — so that the first rt_tracks_create does not wait for it.
+struct StagingPrefetch {
+    std::thread th;
+    std::once_flag once;
+    void start(int device) {
+        std::call_once(once, [&] {
+            try {
+                th = std::thread([device] {
+                    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+                    StagingBlock b;
+                    if (!staging_new_block(b)) return;
+                    memset(b.p, 0, kStageBytes);  // (the host's first touch of its pages, here rather than in the first upload)
+                    std::lock_guard<std::mutex> lk(g_staging_mutex);
+                    g_staging.push_back(b);
+                });
+            } catch (...) {
+            }
+        });
+    }
+    void wait() { if (th.joinable()) th.join(); }
+    ~StagingPrefetch() { wait(); }
+} g_staging_prefetch;
+int staging_acquire(StagingBlock *out) {
+    g_staging_prefetch.wait();
     std::lock_guard<std::mutex> lk(g_staging_mutex);
-    const bool alloc = g_staging_calls++ > 0;  // a process's first track set goes up from the caller's pageable arrays
-    if (allocate_if_missing) *allocate_if_missing = alloc;
     for (size_t i = 0; i < g_staging.size(); ++i)
-        if (!g_staging[i].busy && g_staging[i].cap >= bytes) { g_staging[i].busy = true; *out = g_staging[i].p; return (int)i; }
-    if (!alloc) return -1;
-    for (size_t i = 0; i < g_staging.size(); ++i)
-        if (!g_staging[i].busy) {  // too small: replace it
-            if (g_staging[i].p) (void)hipHostFree(g_staging[i].p);
-            g_staging[i] = StagingBlock{};
-            const size_t cap = bytes + bytes / 8 + 4096;
-            if (hipHostMalloc(&g_staging[i].p, cap, hipHostMallocDefault) != hipSuccess) { g_staging[i].p = nullptr; return -1; }
-            g_staging[i].cap = cap; g_staging[i].busy = true; *out = g_staging[i].p;
-            return (int)i;
-        }
+        if (!g_staging[i].busy) { g_staging[i].busy = true; *out = g_staging[i]; return (int)i; }
     StagingBlock b;
-    const size_t cap = bytes + bytes / 8 + 4096;
-    if (hipHostMalloc(&b.p, cap, hipHostMallocDefault) != hipSuccess) return -1;
-    b.cap = cap; b.busy = true;
+    if (!staging_new_block(b)) return -1;
+    b.busy = true;
     g_staging.push_back(b);
-    *out = b.p;
+    *out = b;
     return (int)g_staging.size() - 1;
 }
 void staging_release(int slot) {
@@ -401,6 +419,7 @@ static rt_mesh *mesh_create_impl(int32_t device, const double *x, const double *
         return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    g_staging_prefetch.start(device);  // (the page-locked block of this process's track uploads, beside the preprocessing below)
     rt_mesh *m = new rt_mesh();
     struct Guard { rt_mesh *p; ~Guard() { if (p) free_mesh(p); } } guard{m};  // released on success
     m->device = device;
@@ -662,9 +681,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         // that need not cross PCIe)
         const size_t up_bytes = 9 * na * sizeof(double) + 2 * na * sizeof(int32_t) + ncord * sizeof(int32_t);
         const size_t bytes = up_bytes + 3 * na * sizeof(double) + na * sizeof(int32_t) + 256;
-        void *stage = nullptr;
-        bool may_pin = false;
-        const int slot = staging_acquire(up_bytes + 256, &stage, &may_pin);
+        StagingBlock stage;
+        const int slot = staging_acquire(&stage);
         struct Rel { int s; ~Rel() { staging_release(s); } } rel{slot};
         ok = t->in_arena.reserve(bytes) == hipSuccess;
         unsigned char *db = t->in_arena.p;
@@ -678,28 +696,53 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             t->As.p = (double *)(db + up_bytes); t->Bs.p = t->As.p + na; t->Cs.p = t->Bs.p + na;
             t->iperm.p = (int32_t *)(t->Cs.p + na);
         }
-        // the host image of the uploaded part: the staging block, or — a process's first track set, before anything is pinned — only
-        // the integer arrays in a pageable vector (the caller's arrays then go up from where they lie)
-        std::vector<unsigned char> ints;
         cstamp[2] = cnow();
-        unsigned char *hb = (unsigned char *)stage;
-        if (ok && slot < 0) ints.resize(up_bytes - ints_off + 256);
-        if (ok) {
-            unsigned char *hd = slot >= 0 ? hb + ints_off : ints.data();
-            int32_t *h_az = (int32_t *)hd, *h_pm = h_az + na, *h_co = h_pm + na;
-            par_ranges(n, 16384, [&](size_t i0, size_t i1) {
-                if (slot >= 0)
+        if (ok && n > 0) {
+            if (slot >= 0 && up_bytes <= kStageBytes / 2) {
+                // everything fits in half a block: the image of the uploaded part as it lies in the arena, ONE copy
+                unsigned char *hb = (unsigned char *)stage.p;
+                int32_t *h_az = (int32_t *)(hb + ints_off), *h_pm = h_az + na, *h_co = h_pm + na;
+                par_ranges(n, 16384, [&](size_t i0, size_t i1) {
                     for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * na * sizeof(double)) + i0, src8[a] + i0, (i1 - i0) * sizeof(double));
-                memcpy(h_az + i0, azim_idx + i0, (i1 - i0) * sizeof(int32_t));
-                memcpy(h_pm + i0, perm.data() + i0, (i1 - i0) * sizeof(int32_t));
-            });
-            if (!h_corder.empty()) memcpy(h_co, h_corder.data(), h_corder.size() * sizeof(int32_t));
-            cstamp[3] = cnow();
-            if (slot >= 0) {
+                    memcpy(h_az + i0, azim_idx + i0, (i1 - i0) * sizeof(int32_t));
+                    memcpy(h_pm + i0, perm.data() + i0, (i1 - i0) * sizeof(int32_t));
+                });
+                if (!h_corder.empty()) memcpy(h_co, h_corder.data(), h_corder.size() * sizeof(int32_t));
+                cstamp[3] = cnow();
                 ok = hipMemcpyAsync(db, hb, up_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+            } else if (slot >= 0) {
+                // ranges of tracks through the block's two halves: eleven slices per range, written by the host threads while the
+                // previous range's copies are in flight
+                const size_t half = kStageBytes / 2, per_track = 9 * sizeof(double) + 2 * sizeof(int32_t);
+                const size_t rcap = (half / per_track) & ~(size_t)63;
+                int k = 0;
+                for (size_t i0 = 0; i0 < n && ok; i0 += rcap, ++k) {
+                    const size_t i1 = std::min(n, i0 + rcap), m = i1 - i0;
+                    unsigned char *hb = (unsigned char *)stage.p + (size_t)(k & 1) * half;
+                    if (k >= 2) ok = hipEventSynchronize(stage.ev[k & 1]) == hipSuccess;  // the half's previous range has left it
+                    int32_t *h_az = (int32_t *)(hb + 9 * rcap * sizeof(double)), *h_pm = h_az + rcap;
+                    par_ranges(m, 16384, [&](size_t j0, size_t j1) {
+                        for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * rcap * sizeof(double)) + j0, src8[a] + i0 + j0, (j1 - j0) * sizeof(double));
+                        memcpy(h_az + j0, azim_idx + i0 + j0, (j1 - j0) * sizeof(int32_t));
+                        memcpy(h_pm + j0, perm.data() + i0 + j0, (j1 - j0) * sizeof(int32_t));
+                    });
+                    for (int a = 0; a < 9 && ok; ++a)
+                        ok = hipMemcpyAsync(dst8[a]->p + i0, hb + (size_t)a * rcap * sizeof(double), m * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+                    ok = ok && hipMemcpyAsync(t->azim.p + i0, h_az, m * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess &&
+                         hipMemcpyAsync(t->perm.p + i0, h_pm, m * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess &&
+                         hipEventRecord(stage.ev[k & 1], s) == hipSuccess;
+                }
+                cstamp[3] = cnow();
+                if (ok && !h_corder.empty())
+                    ok = hipMemcpyAsync(t->corder.p, h_corder.data(), h_corder.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess;
             } else {
-                for (int a = 0; a < 9 && ok && n > 0; ++a) ok = hipMemcpyAsync(dst8[a]->p, src8[a], n * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
-                ok = ok && hipMemcpyAsync(db + ints_off, ints.data(), up_bytes - ints_off, hipMemcpyHostToDevice, s) == hipSuccess;
+                // no page-locked block to be had: from where the arrays lie
+                cstamp[3] = cnow();
+                for (int a = 0; a < 9 && ok; ++a) ok = hipMemcpyAsync(dst8[a]->p, src8[a], n * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+                ok = ok && hipMemcpyAsync(t->azim.p, azim_idx, n * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess &&
+                     hipMemcpyAsync(t->perm.p, perm.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess;
+                if (ok && !h_corder.empty())
+                    ok = hipMemcpyAsync(t->corder.p, h_corder.data(), h_corder.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess;
             }
             if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->As.p, t->Bs.p, t->Cs.p, t->iperm.p);
             ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
