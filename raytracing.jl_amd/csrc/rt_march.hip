@@ -4,6 +4,13 @@
 
 namespace rt {
 
+// (development, -DRT_STOP_AFTER=N: every track stops after N records — a timing probe of the march's start; results are void)
+#ifdef RT_STOP_AFTER
+constexpr int kIterLimit = RT_STOP_AFTER;
+#else
+constexpr int kIterLimit = kMaxIter;
+#endif
+
 template <bool WIDEK>
 __global__ __launch_bounds__(64) void k_seed(DMesh m, DTracks t, DParams prm, DSplit sp) {
     const int32_t cv = blockIdx.x;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     bool creep_escalate = false;
     int creep_run = 0;  // generic tiny steps in a row
     for (;;) {
-    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kMaxIter && !creep_escalate) {  // :119
+    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kIterLimit && !creep_escalate) {  // :119
         if (TOPO) {
             // ---- cheap steps: a wave-uniform inner loop that runs while some lane is in cheap mode and no lane is due
             //      for an exact step (lanes whose track has ended, or that wait with an uncertified last step, idle here)
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                         fl |= kFlUsed;
                         if (r == kTopoEnd) fl = (fl & ~kFlCheap) | kFlDone | kFlWait;  // on the border, within tiny_step: :130-132
                         else if (ts.pred < 0) fl = (fl & ~kFlCheap) | kFlMat | kFlWait;
-                        else if (i >= kMaxIter) fl = (fl & ~kFlCheap) | kFlWait;
+                        else if (i >= kIterLimit) fl = (fl & ~kFlCheap) | kFlWait;
                     } else if (cheap) {
                         fl = (fl & ~kFlCheap) | (ok ? kFlRestart : kFlMat);  // refused: the exact step decides this record
                         // per-call statistic (rt_last_stats): which certificate term refused — a cold branch (every refusal
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 }
             }
             const bool any_cheap = __ballot((fl & kFlCheap) != 0) != 0;
-            if ((fl & kFlDone) || i >= kMaxIter) break;
+            if ((fl & kFlDone) || i >= kIterLimit) break;
             if ((fl & kFlCheap) || ((fl & kFlWait) && any_cheap)) continue;  // (an uncertified last step waits until no lane is cheap)
             if (__builtin_expect((fl & kFlRestart) || ((fl & kFlUsed) && it >= cap), 0)) {
                 // the bound reached the iteration cap: this track is marched again from its start with exact steps only
