@@ -98,6 +98,7 @@ struct DOut {
 constexpr int kChunkLog2 = RT_CHUNK_LOG2;
 constexpr int kChunkRows = 1 << kChunkLog2;
 constexpr int kMaxChunks = kMaxIter / kChunkRows + 1;  // per wave
+constexpr int kTileAccStride = 32;  // DStage::tile_acc: one tile sum per 128-B line (experiment)
 constexpr int kStaticRegions = 12;  // chunk indices with a reserved region (see DStage): 384 records per track
 
 constexpr int32_t kWordExactTally = 1 << 30;  // staged word of a cheap record whose fill_volumes term k_materialise adds (see DStage)
@@ -114,6 +115,9 @@ struct DStage {
     // cursor starts behind the regions.  No atomic and — for k_materialise — no table lookup in front of a wave's first loads:
     // the chunk id follows from (w, j) and 2 x kStaticRegions kernel arguments.  Chunks beyond the estimate come from the
     // cursor as before; ctab / cowner are written for every chunk either way (k_compact3, rt_sweep read them).
+    // k_march<TOPO> adds every wave's record count to the sum of its tile of kScanTile uids here (null: no): the offsets' scan is
+    // then ONE kernel whose blocks each add up the tile sums in front of their own (k_scan_fused), not two
+    RT_G int32_t *tile_acc;
     int32_t n_regions;      // regions in use (0: every chunk from the cursor)
     int32_t reg_cap[kStaticRegions], reg_base[kStaticRegions];
     // k_march<TOPO> stages ONE word per record in `element`: 3·cell + exit edge + 1 (the record is a function of the track's
@@ -270,6 +274,7 @@ struct rt_mesh {
     int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
     double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0, tally_a = 0.0, tally_b = 0.0;
+    bool fused_scan = true;  // two-phase calls: the march leaves the scan's tile sums, one scan kernel (0: the two-launch scan; A/B)
     int64_t test_reserved_pct = -1;  // tests only: the staging chunks reserved per wave as a percentage of the estimate (< 0: all of it)
     int64_t test_tally_tau = 0;  // tests, A/B: the relative error allowed to a cheap record's chord in fill_volumes, in 1e-12 (0: 8e-11; < 0: none — every cheap record tallied by k_materialise)
     int64_t n_records_topo = 0;
@@ -316,6 +321,8 @@ struct rt_tracks {
     int64_t total = 0;
     DevBuf<int32_t> counts, status, element;
     DevBuf<int64_t> offsets, tile_sums;
+    DevBuf<int32_t> tile_acc;        // two halves of n_tiles record counts per tile, one per control block (see DStage)
+    int64_t tile_acc_tiles = 0;
     // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag,
     // 20 ticket of the scan's "last block" step, 21 tracks that reached MAX_ITER segments in split mode
     DevBuf<unsigned long long> ctl;  // two blocks of kCtlWords: calls alternate, each call's scan resets the other block
@@ -413,6 +420,8 @@ int ensure_compacted(rt_tracks *t);
 int ensure_rows(rt_tracks *t);
 void launch_prologue(hipStream_t s, unsigned long long *ctl, double *volumes, int32_t n_cells, int32_t first_chunk, int32_t side_first);
 // the exclusive scan of the counts (two kernels); see k_scan_tile_sums / k_scan_write for the optional pointers
+void launch_scan_fused(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, const int32_t *tile_acc, int32_t *tile_acc_next,
+                       unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next);
 void launch_scan(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, unsigned long long *host_copy,
                  unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next, unsigned long long seq,
                  double *scale_volumes, double n_azim_2, bool slot_order);

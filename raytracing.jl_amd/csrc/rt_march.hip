@@ -758,15 +758,39 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         status[u] = st;
         if (TOPO) { t.cnt_slot[slot] = i; if (FUSE) t.w_slot[slot] = out.delta_s[t.azim[u] - 1]; }  // (k_materialise reads its units' counts and weights in slot order)
         {
-            // per-call statistic (rt_last_stats): records the generic step produced, summed over the wave's active lanes
-            // bit by bit with ballots (n_generic <= kMaxIter < 2^14)
-            unsigned long long ng = 0;
-            for (int b = 0; b < 14; ++b) ng += (unsigned long long)__popcll(__ballot((n_generic >> b) & 1)) << b;
-            if (lane == __ffsll((long long)__ballot(1)) - 1 && ng) atomicAdd(&fail_info[15], ng);
-            if (TOPO && FUSE) {
-                unsigned long long ne = 0;
-                for (int b = 0; b < 14; ++b) ne += (unsigned long long)__popcll(__ballot((n_exact_tally >> b) & 1)) << b;
-                if (lane == __ffsll((long long)__ballot(1)) - 1 && ne) atomicAdd(march_ctl() + kCtlExactTally, ne);
+            // What the wave leaves for the call: its records into the sum of its tile of uids (two-phase calls: the scan then needs no
+            // pass over the counts to form the tile sums), and the per-call statistics (rt_last_stats) — records the generic step
+            // produced, cheap records whose fill_volumes term is k_materialise's — summed over the wave's lanes bit by bit with ballots
+            // (values <= kMaxIter < 2^14; some lanes of the batch's last wave are not here).  All three go to the TILE's own 128-B
+            // line (DStage::tile_acc): device-scope atomics of many waves on one line are served one after the other, ≈80 ns each —
+            // 2,039 waves on the four lines of a dense array of tile sums cost the C3 march 40 µs, two statistics on the control block's
+            // line 3 µs.
+            auto wave_sum = [&](const int32_t v) -> unsigned long long {
+                unsigned long long r = 0;
+                for (int b = 0; b < 14; ++b) r += (unsigned long long)__popcll(__ballot((v >> b) & 1)) << b;
+                return r;
+            };
+            const bool first = lane == __ffsll((long long)__ballot(1)) - 1;
+            const unsigned long long ng = wave_sum(n_generic), ne = (TOPO && FUSE) ? wave_sum(n_exact_tally) : 0ull;
+            RT_G int32_t *acc = TOPO ? march_stage_args()->tile_acc : nullptr;
+            if (acc) {
+                static_assert(kScanTile == 1024, "tile of the offsets' scan");
+                const int32_t tile = (int32_t)(u >> 10);
+                const int32_t t0 = __builtin_amdgcn_readfirstlane(tile);
+                RT_G int32_t *line = acc + (size_t)t0 * kTileAccStride;
+                // (a wave's lanes are 64 consecutive uids — one tile — except where the batch's partial last wave of uids was packed
+                //  into the march order)
+                if (__ballot(tile != t0) == 0) {
+                    const unsigned long long ws = wave_sum(i);
+                    if (first) atomicAdd((int32_t *)line, (int32_t)ws);
+                } else {
+                    atomicAdd((int32_t *)(acc + (size_t)tile * kTileAccStride), (int32_t)i);
+                }
+                if (first && ng) atomicAdd((int32_t *)(line + 1), (int32_t)ng);
+                if (first && ne) atomicAdd((int32_t *)(line + 2), (int32_t)ne);
+            } else {
+                if (first && ng) atomicAdd(&fail_info[15], ng);
+                if (first && ne) atomicAdd(march_ctl() + kCtlExactTally, ne);
             }
         }
         if (st != RT_TRACK_OK) {

@@ -589,6 +589,72 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_write(const int32_t *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *total;
 }
 
+// The offsets' scan of a two-phase call in ONE launch: k_march<TOPO> has already added every wave's record count to the sum of
+// its tile of kScanTile uids (DStage::tile_acc), so a block needs no other block's result — it adds up the tile sums in front of
+// its own tile (n_tiles values: 128 at the headline configuration, 1,019 for a BWR assembly), scans its own 1,024 counts and writes
+// its offsets (uid order, and — through iperm — march-slot order for k_materialise).  The last tile's block writes the total and
+// resets the OTHER control block; every block clears its entry of the OTHER tile-sum buffer: calls alternate between two, so that
+// a call in the steady state starts with its march.  (A look-back scan over published tile sums was measured too: its chain of
+// waits made it slower than the two launches it replaced, profiles/r04/exp_by_side_state_and_single_scan.log.)
+__global__ __launch_bounds__(kScanBlock) void k_scan_fused(const int32_t *__restrict__ counts, int64_t n, const int32_t *__restrict__ tile_acc,
+                                                           int32_t *__restrict__ tile_acc_next, int64_t n_tiles, int64_t *__restrict__ total,
+                                                           int64_t *__restrict__ offsets, const int32_t *__restrict__ iperm,
+                                                           int64_t *__restrict__ off_slot, unsigned long long *__restrict__ ctl,
+                                                           unsigned long long *__restrict__ ctl_next, int32_t first_chunk_next,
+                                                           int32_t side_first_next) {
+    __shared__ int64_t wsum[kScanBlock / 64];
+    __shared__ int64_t bsum[kScanBlock / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x;
+    // the tiles in front of this one
+    int64_t pre = 0;
+    for (int64_t i = threadIdx.x; i < b; i += kScanBlock) pre += tile_acc[i * kTileAccStride];
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if (lane == 0) bsum[wv] = pre;
+    const int64_t i0 = (b * kScanBlock + threadIdx.x) * kScanPer;
+    int64_t c[kScanPer];
+    int64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        c[j] = (i0 + j < n) ? counts[i0 + j] : 0;
+        s += c[j];
+    }
+    int64_t incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int64_t wave_off = 0, tile = 0, base = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+        if (w < wv) wave_off += wsum[w];
+        tile += wsum[w];
+        base += bsum[w];
+    }
+    int64_t run = base + wave_off + incl - s;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        if (i0 + j < n) {
+            offsets[i0 + j] = run;
+            if (iperm) off_slot[iperm[i0 + j]] = run;
+        }
+        run += c[j];
+    }
+    if (threadIdx.x < 3 && tile_acc_next) tile_acc_next[b * kTileAccStride + threadIdx.x] = 0;
+    if (b != n_tiles - 1) return;
+    if (threadIdx.x == 0) { offsets[n] = base + tile; *total = base + tile; }
+    {   // the waves' statistics (k_march left them on their tiles' lines): records by the generic step, cheap records tallied from
+        // their lengths -> the control block's words, where the host reads them
+        unsigned long long ng = 0, ne = 0;
+        for (int64_t i = threadIdx.x; i < n_tiles; i += kScanBlock) { ng += (unsigned)tile_acc[i * kTileAccStride + 1]; ne += (unsigned)tile_acc[i * kTileAccStride + 2]; }
+        for (int off = 32; off > 0; off >>= 1) { ng += __shfl_xor(ng, off, 64); ne += __shfl_xor(ne, off, 64); }
+        if (lane == 0 && ng) atomicAdd(&ctl[15], ng);
+        if (lane == 0 && ne) atomicAdd(&ctl[kCtlExactTally], ne);
+    }
+    if (ctl_next && threadIdx.x < kCtlWords) ctl_next[threadIdx.x] = ctl_reset_word(threadIdx.x, first_chunk_next, side_first_next);
+}
+
 // fill_volumes (src/trackgenerator.jl:371-386) as its own pass over the compact records: each
 // workgroup owns a contiguous range of tracks (hence a contiguous range of segments, read
 // coalesced), accumulates δs[azim]·ℓ into an LDS-private copy of `volumes` with LDS atomics and
@@ -791,6 +857,13 @@ int ensure_rows(rt_tracks *t) {
 void launch_prologue(hipStream_t s, unsigned long long *ctl, double *volumes, int32_t n_cells, int32_t first_chunk, int32_t side_first) {
     hipLaunchKernelGGL(rt::k_prologue, dim3((unsigned)((std::max(n_cells, rt::kCtlWords) + 255) / 256)), dim3(256), 0, s, ctl, volumes, n_cells,
                        first_chunk, side_first);
+}
+
+void launch_scan_fused(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, const int32_t *tile_acc, int32_t *tile_acc_next,
+                       unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next) {
+    hipLaunchKernelGGL(rt::k_scan_fused, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, (const int32_t *)t->counts.p, t->n, tile_acc,
+                       tile_acc_next, n_tiles, reinterpret_cast<int64_t *>(d_ctl + 16), t->offsets.p, (const int32_t *)t->iperm.p, t->off_slot.p,
+                       d_ctl, ctl_next, first_chunk_next, side_first_next);
 }
 
 void launch_scan(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, unsigned long long *host_copy,

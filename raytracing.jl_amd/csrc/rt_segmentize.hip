@@ -180,7 +180,7 @@ void free_tracks(rt_tracks *t) {
     t->A.release(); t->B.release(); t->C.release(); t->ell.release(); t->azim.release(); t->perm.release(); t->corder.release();
     t->in_arena.release(); t->cnt_slot.release(); t->off_slot.release(); t->w_slot.release();
     t->counts.release(); t->status.release(); t->element.release(); t->offsets.release();
-    t->tile_sums.release(); t->ctl.release(); t->vacc.release();
+    t->tile_sums.release(); t->tile_acc.release(); t->ctl.release(); t->vacc.release();
 #ifdef RT_TIMING
     t->dbg.release();
 #endif
@@ -506,6 +506,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "test_volumes_fallback")) { mesh->test_volumes_fallback = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "test_exact_sums")) { mesh->test_exact_sums = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "test_tally_tau")) { mesh->test_tally_tau = value; return RT_SUCCESS; }
+    if (!strcmp(name, "fused_scan")) { mesh->fused_scan = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "test_reserved_pct")) { mesh->test_reserved_pct = value; return RT_SUCCESS; }  // read by rt_tracks_create
     if (!strcmp(name, "side_entries_hint")) { mesh->side_entries_hint = value; return RT_SUCCESS; }
     if (!strcmp(name, "sort_mode")) { mesh->sort_mode = (int)value; return RT_SUCCESS; }  // read by rt_tracks_create
@@ -834,6 +835,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     RT_HIP(t->status.reserve(n + 1));
     RT_HIP(t->offsets.reserve(n + 1));
     RT_HIP(t->tile_sums.reserve(n_tiles + 1));
+    if (t->tile_acc_tiles != n_tiles + 1 || !t->tile_acc.p) {  // (two zeroed halves: k_march<TOPO> adds to one, the scan clears the other)
+        RT_HIP(t->tile_acc.reserve(2 * (size_t)(n_tiles + 1) * rt::kTileAccStride));
+        RT_HIP(hipMemsetAsync(t->tile_acc.p, 0, 2 * (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
+        t->tile_acc_tiles = n_tiles + 1;
+    }
     RT_HIP(t->ctl.reserve(2 * rt::kCtlWords));
     RT_HIP(t->vacc.reserve(m->n_cells));
     if (!t->h_ctl) {
@@ -910,9 +916,14 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     // copy_out: k_scan_tile_sums' last block also writes the control block to the pinned host copy; scale: k_scan_write also
     // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
     int32_t first_chunk_this_call = 0, side_first_this_call = 0;
+    int32_t *tile_acc_cur = nullptr, *tile_acc_other = nullptr;  // (set for two-phase calls)
     // reset_other: the scan's last block also resets the OTHER control block for the next call (single-pass calls)
     auto scan_counts = [&](bool copy_out, bool scale, bool reset_other, bool slot_order = false) -> int {
-        if (n > 0) {
+        if (n > 0 && slot_order && tile_acc_cur) {  // (two-phase calls: the march has left the tile sums)
+            ++t->call_seq;
+            launch_scan_fused(s, t, n_tiles, d_ctl, tile_acc_cur, reset_other ? tile_acc_other : (int32_t *)nullptr,
+                              reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call);
+        } else if (n > 0) {
             launch_scan(s, t, n_tiles, d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
                         reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call, ++t->call_seq,
                         scale ? t->volumes.p : (double *)nullptr, (double)n_azim_2, slot_order);
@@ -1035,6 +1046,12 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
                 }
             }
             for (int j = stg.n_regions; j < rt::kStaticRegions; ++j) stg.reg_cap[j] = stg.reg_base[j] = 0;
+            stg.tile_acc = nullptr;
+            if (topo && m->fused_scan) {
+                tile_acc_cur = t->tile_acc.p + (size_t)cb * (size_t)(n_tiles + 1) * rt::kTileAccStride;
+                tile_acc_other = t->tile_acc.p + (size_t)(1 - cb) * (size_t)(n_tiles + 1) * rt::kTileAccStride;
+                stg.tile_acc = as_global(tile_acc_cur);
+            }
             if (topo) {
                 stg.s_px = as_global(t->side_px.p); stg.s_py = as_global(t->side_py.p); stg.s_qx = as_global(t->side_qx.p);
                 stg.s_qy = as_global(t->side_qy.p); stg.s_el = as_global(t->side_el.p);
@@ -1065,8 +1082,10 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
             const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != reset_key || !(fuse && n > 0 && vacc_was_clean);
             auto enqueue_attempt = [&]() -> int {
-                if (need_reset)
+                if (need_reset) {
                     launch_prologue(s, d_ctl, (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk_this_call, side_first_this_call);
+                    if (tile_acc_cur) RT_HIP(hipMemsetAsync(tile_acc_cur, 0, (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
+                }
                 if (int rc = rec(1)) return rc;
                 if (n > 0 && split) {
                     hipStream_t ps = s;  // the stream the pieces march on
@@ -1496,7 +1515,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
         stats[7] = b(t->in_arena) + b(t->cnt_slot) + b(t->off_slot) + b(t->w_slot) +
-                   b(t->counts) + b(t->status) + b(t->element) + b(t->offsets) + b(t->tile_sums) + b(t->ctl) + b(t->spx) +
+                   b(t->counts) + b(t->status) + b(t->element) + b(t->offsets) + b(t->tile_sums) + b(t->tile_acc) + b(t->ctl) + b(t->spx) +
                    b(t->spy) + b(t->sqx) + b(t->sqy) + b(t->sell) + b(t->volumes) + b(t->volumes_prev) + b(t->delta_s) + b(t->gpx) + b(t->gpy) +
                    b(t->gqx) + b(t->gqy) + b(t->gelement) + b(t->ctab) + b(t->cowner) + b(t->vorder) + b(t->vw_wave) + b(t->vw_k) +
                    b(t->w_base) + b(t->w_P) + b(t->s_el) + b(t->s_eq) + b(t->p_count) + b(t->p_flags) + b(t->p_valid) + b(t->p_rel) + b(t->s_px) +
