@@ -89,7 +89,7 @@ def kernel_names(stats):
     return {"march": "rt::k_march<2, %d, %s, %s, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
                                                            "true" if cheap else "false"),
             "compact": "rt::k_materialise<true, false>" if cheap else "rt::k_compact3<%s>" % ("true" if sp else "false"),
-            "scan": "rt::k_scan_write"}
+            "scan": "rt::k_scan_fused" if cheap else "rt::k_scan_write"}
 
 
 def bytes_per_segment(stats):
@@ -789,7 +789,7 @@ def _main(real_stdout):
             simds = 4 * info_cus
             out["shard_regime"] = {
                 "march_waves_rank0": waves, "simds": simds, "waves_per_simd_rank0": waves / simds,
-                "resident_waves_per_simd": 2,  # k_march<..., TOPO>: 200 VGPRs
+                "resident_waves_per_simd": 2,  # k_march<..., TOPO>: 221 VGPRs
                 "march_rounds_rank0": max(1.0, waves / (2.0 * simds)),
                 "ideal_ms_per_step": (same_workload["ms_per_step"] / world) if same_workload is not None else None,
                 "note": "strong scaling of a FIXED problem: with N ranks a shard has 1/N of the waves; below ~2 waves per SIMD every wave is "
