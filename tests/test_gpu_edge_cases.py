@@ -201,7 +201,10 @@ def test_single_track_and_empty_batch(rt, orc, traced):
                                   dict(split=0, side_entries_hint=16), dict(split=0, test_exact_sums=1),
                                   dict(split=0, test_exact_sums=1, test_out_records=20000), dict(split=0, test_tally_tau=-1),
                                   dict(split=0, test_tally_tau=1), dict(split=0, test_tally_tau=20), dict(split=0, compact=0),
-                                  dict(split=0, compact=0, test_exact_sums=1), dict(split=0, topo=2, sort_mode=1)])
+                                  dict(split=0, compact=0, test_exact_sums=1), dict(split=0, topo=2, sort_mode=1),
+                                  # the two-launch scan under the two-phase march (default: the march leaves the tile sums, one scan kernel);
+                                  # the fused scan with a pool that overflows first (the tile sums of the void attempt are cleared)
+                                  dict(split=0, fused_scan=0), dict(split=0, fused_scan=1, pool_chunks_hint=8), dict(split=0, sort_mode=0, fused_scan=1)])
 def test_internal_modes_give_identical_results(rt, traced, oracle_run, opts):
     from raytracing_jl_amd import _capi
 
