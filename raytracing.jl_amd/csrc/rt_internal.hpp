@@ -323,6 +323,7 @@ struct rt_tracks {
     DevBuf<int64_t> offsets, tile_sums;
     DevBuf<int32_t> tile_acc;        // two halves of n_tiles record counts per tile, one per control block (see DStage)
     int64_t tile_acc_tiles = 0;
+    bool tile_acc_clean[2] = {false, false};  // the half is zero (set by the scan that cleared it)
     // one control block: words 0..15 failure summary / stats, 16 total segments, 18..19 pool cursor + overflow flag,
     // 20 ticket of the scan's "last block" step, 21 tracks that reached MAX_ITER segments in split mode
     DevBuf<unsigned long long> ctl;  // two blocks of kCtlWords: calls alternate, each call's scan resets the other block

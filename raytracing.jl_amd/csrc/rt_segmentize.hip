@@ -839,6 +839,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         RT_HIP(t->tile_acc.reserve(2 * (size_t)(n_tiles + 1) * rt::kTileAccStride));
         RT_HIP(hipMemsetAsync(t->tile_acc.p, 0, 2 * (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
         t->tile_acc_tiles = n_tiles + 1;
+        t->tile_acc_clean[0] = t->tile_acc_clean[1] = true;
     }
     RT_HIP(t->ctl.reserve(2 * rt::kCtlWords));
     RT_HIP(t->vacc.reserve(m->n_cells));
@@ -923,6 +924,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             ++t->call_seq;
             launch_scan_fused(s, t, n_tiles, d_ctl, tile_acc_cur, reset_other ? tile_acc_other : (int32_t *)nullptr,
                               reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call);
+            if (reset_other) t->tile_acc_clean[1 - cb] = true;
         } else if (n > 0) {
             launch_scan(s, t, n_tiles, d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
                         reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call, ++t->call_seq,
@@ -1084,8 +1086,12 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             auto enqueue_attempt = [&]() -> int {
                 if (need_reset) {
                     launch_prologue(s, d_ctl, (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk_this_call, side_first_this_call);
-                    if (tile_acc_cur) RT_HIP(hipMemsetAsync(tile_acc_cur, 0, (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
                 }
+                // (the tile sums' half of this control block: clean when the previous two-phase call's scan has cleared it — not after a
+                //  void attempt, and not when a call without cheap steps came in between)
+                if (tile_acc_cur && (need_reset || !t->tile_acc_clean[cb]))
+                    RT_HIP(hipMemsetAsync(tile_acc_cur, 0, (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
+                if (tile_acc_cur) t->tile_acc_clean[cb] = false;
                 if (int rc = rec(1)) return rc;
                 if (n > 0 && split) {
                     hipStream_t ps = s;  // the stream the pieces march on

@@ -294,6 +294,38 @@ def test_reserved_and_cursor_chunks_mix(rt, traced, oracle_run, pct):
         dt.close(); dm.close()
 
 
+def test_one_handle_through_changing_regimes(rt, traced, oracle_run):
+    """Calls on ONE track-set handle while the mesh's options change between them: cheap steps on and off (the two-phase march leaves
+    tile sums for its one-kernel scan in one of two buffers, which a call without cheap steps neither uses nor clears), records
+    written or left staged, the two-launch scan forced.  Every call returns the reference's offsets, records and volumes."""
+    from raytracing_jl_amd import _capi
+
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    aq = tg.azimuthal_quadrature
+    dm = _capi.DeviceMesh(tg.mesh, 0)
+    dm.set_option("split", 0)
+    dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+    seq = [dict(topo=1), dict(topo=0), dict(topo=1), dict(topo=1), dict(topo=0), dict(topo=0), dict(topo=1, compact=0), dict(topo=1, compact=1),
+           dict(fused_scan=0), dict(fused_scan=1), dict(topo=0), dict(topo=2), dict(topo=1)]
+    for i, opts in enumerate(seq):
+        for k, v in opts.items():
+            dm.set_option(k, v)
+        assert dt.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == ref["total"], (i, opts)
+        off, st = dt.fetch_offsets()
+        assert np.array_equal(off, ref["offsets"]) and np.array_equal(st, ref["status"]), (i, opts)
+        seg = dt.fetch_segments()
+        for k in ("px", "py", "qx", "qy", "ell", "element"):
+            assert np.array_equal(seg[k], ref[k]), (i, opts, k)
+        np.testing.assert_allclose(dt.fetch_volumes(), ref["volumes"], rtol=1e-10)
+        s = dt.stats()
+        state = {"topo": 1}
+        for d in seq[:i + 1]:
+            state.update(d)
+        assert s["generic_records"] > 0 and (s["cheap_records"] > 0) == (state["topo"] > 0), (i, s)
+    dt.close(); dm.close()
+
+
 def test_enqueue_hook_runs_once_per_call_beside_the_kernels(rt, traced, oracle_run):
     """rt_mesh_set_enqueue_hook: called after the kernels are enqueued and before the wait; not on removal."""
     from raytracing_jl_amd import _capi
