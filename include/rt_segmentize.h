@@ -155,16 +155,19 @@ int32_t rt_failed_tracks(rt_tracks *tracks, int64_t *n_failed, int64_t *first_ui
  * Calls that march track pieces, or with the "timing" option on, always complete before they return. */
 int32_t rt_wait(rt_tracks *tracks);
 
-/* Copy results into caller-allocated host buffers (any pointer may be NULL to skip it). */
+/* Copy results into caller-allocated host buffers (any pointer may be NULL to skip it).  rt_fetch_segments moves the records in
+ * pieces through a page-locked block the library keeps — the copy engine fills one half while host threads move the other into
+ * place — so that pageable, freshly allocated destinations are filled at close to the PCIe rate (C3's 410 MB: 10 ms, C5's 5 GB:
+ * 114 ms; a plain copy into pageable memory took 25-42 / 330-600 ms): what a caller that runs segmentize! ONCE should use. */
 int32_t rt_fetch_offsets(rt_tracks *tracks, int64_t *seg_offsets, int32_t *status);
 int32_t rt_fetch_segments(rt_tracks *tracks, double *px, double *py, double *qx, double *qy,
                           double *ell, int32_t *element);
 int32_t rt_fetch_volumes(rt_tracks *tracks, double *volumes);
 /* Like rt_fetch_segments, but into page-locked host buffers owned by the handle (allocated on first use and
  * reused): host_ptrs[6] receives px, py, qx, qy, ell (double *) and element (int32_t *), `total` entries
- * each.  A fresh pageable destination costs a page fault per 4 KB while the copy runs (C3's 410 MB: 25-42 ms);
- * these buffers take the same records at the PCIe rate (7 ms).  Page-locking itself is slow (≈45 ms for
- * 410 MB), so one set of buffers survives its handle in a process-wide cache and serves the next handle.
+ * each.  These buffers take the records at the PCIe rate (C3's 410 MB: 7.3 ms) and hand them out without a copy —
+ * for a caller that fetches REPEATEDLY: page-locking itself is slow (≈0.08 ms per MB: 25-40 ms for 410 MB, 260-550 ms
+ * for 5 GB, on the first call), so one set of buffers survives its handle in a process-wide cache and serves the next handle.
  * The pointers stay valid until the next rt_segmentize, rt_fetch_segments_pinned or rt_tracks_destroy on
  * this handle. */
 int32_t rt_fetch_segments_pinned(rt_tracks *tracks, void **host_ptrs);
