@@ -116,7 +116,7 @@ function destroy!(y::TrackSetHandle)   # idempotent: release_mesh! / atexit may 
 end
 
 """
-    segmentize_amd!(t::TrackGenerator{Float64}; k=5, rtol=Base.rtoldefault(Float64), device=0, materialize=true)
+    segmentize_amd!(t::TrackGenerator{Float64}; k=5, rtol=Base.rtoldefault(Float64), device=0, materialize=true, pinned=!materialize)
 
 Same contract as `RayTracing.segmentize!` (src/trackgenerator.jl:357-369): requires `trace!`,
 refills every `track.segments` in march order, overwrites `t.volumes`, returns `t`, and
@@ -125,7 +125,7 @@ throws the reference's `ErrorException`s for point-location failure and Σℓ mi
 `track.segments` untouched (no per-segment allocation; see `SegmentsView`).
 """
 function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.rtoldefault(Float64),
-                         device::Int=0, materialize::Bool=true)
+                         device::Int=0, materialize::Bool=true, pinned::Bool=!materialize)
     tracks = t.tracks_by_uid
     !isassigned(tracks, 1) && error("Segmentation is intended after tracing. Please, " *
                                     "call `trace!` first!")
@@ -166,13 +166,29 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
         # arrive at the PCIe rate instead of page-faulting into fresh Julia arrays (C3: 7 ms instead of 25-40 ms), and the
         # offsets / status no longer cost two synchronous copies of their own (6 ms); read-only views, copied into the
         # Segments below, gone with the handle
-        hp = Vector{Ptr{Cvoid}}(undef, 8)
-        rc = ccall((:rt_fetch_pinned, LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ht, hp)
-        rc != 0 && error("rt_fetch_pinned: " * lasterror())
-        offs = unsafe_wrap(Array, Ptr{Int64}(hp[1]), n + 1)
-        spx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total); spy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total)
-        sqx = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[6]), total)
-        sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[7]), total); sel = unsafe_wrap(Array, Ptr{Int32}(hp[8]), total)
+        # `pinned=false` (the default of the eager rebuild): plain Julia arrays, filled by rt_fetch_offsets / rt_fetch_segments — pipelined
+        # through a small page-locked block inside the library, close to the PCIe rate WITHOUT page-locking the whole result first
+        # (the first rt_fetch_pinned of a process pins its buffers: 0.08 ms per MB, 260-550 ms for a BWR assembly's 5 GB)
+        local offs, spx, spy, sqx, sqy, sℓ, sel
+        if pinned
+            hp = Vector{Ptr{Cvoid}}(undef, 8)
+            rc = ccall((:rt_fetch_pinned, LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ht, hp)
+            rc != 0 && error("rt_fetch_pinned: " * lasterror())
+            offs = unsafe_wrap(Array, Ptr{Int64}(hp[1]), n + 1)
+            spx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total); spy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total)
+            sqx = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[6]), total)
+            sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[7]), total); sel = unsafe_wrap(Array, Ptr{Int32}(hp[8]), total)
+        else
+            offs = Vector{Int64}(undef, n + 1)
+            spx = Vector{Float64}(undef, total); spy = similar(spx); sqx = similar(spx); sqy = similar(spx); sℓ = similar(spx)
+            sel = Vector{Int32}(undef, total)
+            rc = ccall((:rt_fetch_offsets, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}), ht, offs, C_NULL)
+            rc != 0 && error("rt_fetch_offsets: " * lasterror())
+            rc = ccall((:rt_fetch_segments, LIB), Int32,
+                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                       ht, spx, spy, sqx, sqy, sℓ, sel)
+            rc != 0 && error("rt_fetch_segments: " * lasterror())
+        end
         if materialize
             # eager rebuild: real Vector{Segment}s, the reference's layout (src/segment.jl:23-33); one `τ` per segment
             Threads.@threads for u in 1:n
