@@ -336,16 +336,39 @@ def cpu_baseline(tg):
     }
 
 
+def _launch_ranks(n, real_stdout):
+    """`python bench.py --gpus N` without a launcher around it: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    bench.py <same arguments>` as a child process on 127.0.0.1 and a free port, pass its stdout (rank 0's JSON line) through, its
+    stderr too, and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on these hosts)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, text=True)
+    for line in proc.stdout:
+        real_stdout.write(line)
+        real_stdout.flush()
+    return proc.wait()
+
+
 def main():
     # RCCL prints a version banner on stdout when a communicator is created: keep the real stdout for the
     # one JSON line and send everything else that writes to fd 1 to stderr
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    rc = 0
     try:
-        _main(real_stdout)
+        rc = _main(real_stdout)
     finally:
         real_stdout.flush()
+    return rc or 0
 
 
 def _main(real_stdout):
@@ -372,6 +395,12 @@ def _main(real_stdout):
     ap.add_argument("--force-dist", action="store_true", help="development: run the multi-GPU code path with a one-rank RCCL group")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes the launcher — it starts the N ranks with torch.distributed.run as a
+        # CHILD process (no exec; it has not imported torch, loaded the library or touched a GPU), relays the child's one JSON line
+        # and leaves with the child's exit code.
+        return _launch_ranks(args.gpus, real_stdout)
+
     import torch
     import torch.distributed as dist
 
@@ -382,10 +411,8 @@ def _main(real_stdout):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus and (world > 1 or args.gpus > 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # Rehearsal of the N > 1 code path on a box with ONE GPU (development; RT_BENCH_REHEARSAL=1): every rank uses GPU 0 and
@@ -828,4 +855,4 @@ def _main(real_stdout):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

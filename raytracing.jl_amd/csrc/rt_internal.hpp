@@ -2,6 +2,7 @@
 // handles behind include/rt_segmentize.h and the host helpers that cross a TU boundary.  Not installed; not part of the C ABI.
 //   rt_march.hip       k_march (+ k_seed, k_resolve) and their launchers
 //   rt_records.hip     staging -> records: k_compact3, k_materialise, k_finish, the offsets scan, k_volumes, k_fill_tau
+//   rt_materialise.hip k_materialise_lin: a two-phase call's records in output order
 //   rt_sweep.hip       rt_sweep: k_sweep, k_sweep_link, the sweep's host code and entry points
 //   rt_segmentize.hip  handles, rt_tracks_create, rt_segmentize (the call's host logic), fetches, statistics
 #pragma once
@@ -194,6 +195,7 @@ constexpr int kC3Pitch = kChunkRows + 4;  // doubles per track in a tile: slot 0
 // k_materialise's arguments (rt_records.hip)
 struct DMat {
     const RT_G EdgeABC *etab;
+    int32_t etab_bytes;           // 3 n_cells entries of 32 B (k_materialise_lin's buffer resource; < 2^32)
     const RT_G int32_t *corder;   // large batches: march waves in the order of their output addresses (as k_compact3)
     int64_t n_units;              // 4 per march wave
     double rtol;
@@ -205,6 +207,7 @@ struct DMat {
     RT_G int32_t *cell_rows;
     RT_G double *vacc;            // fill_volumes' accumulator: the terms of the records the march flagged (kWordExactTally) are added here
     unsigned long long *ctl;      // the call's control block ([0] failed tracks, [1] first failing uid + 1)
+    unsigned long long *dbg;      // development (-DRT_LIN_TIMING): cycle sums between the kernel's stamps
 };
 
 constexpr int kScanBlock = 256;
@@ -265,6 +268,8 @@ struct rt_mesh {
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
     int sweep_ell = 1;  // rt_sweep over staged rows: keep ℓ of every row from the first pass for the later ones (0: every pass derives it)
     int sweep_debug = 0, compact_debug = 0;
+    int mat_kernel = 0;      // records of a two-phase call: 0 k_materialise_lin (output order, 16-B stores), 1 k_materialise (chunk tiles; A/B)
+    int mat_units = 0;       // k_materialise_lin: 0 persistent workgroups (as many as the chip holds), N > 0 at most N units per workgroup (A/B)
     int march_waves = 0;     // 4 / 6: waves per workgroup of the fused march (0: automatic)
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
                            // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is
@@ -310,7 +315,7 @@ struct rt_tracks {
     DevView<double> px, py, phi, cs, sn, A, B, C, ell;
     DevView<int32_t> corder;  // march waves sorted by the uid of their first track (the compaction order of large batches)
     DevView<int32_t> azim, perm;  // perm: march order of all tracks
-    DevView<double> As, Bs, Cs;   // the track lines in march order (k_materialise)
+    DevView<double> As, Bs, Cs, Ls;   // the track lines and lengths in march order (k_materialise)
     DevView<int32_t> iperm;       // uid -> march slot
     DevBuf<int32_t> cnt_slot;     // record counts / CSR offsets in march-slot order (whole-track two-phase calls)
     DevBuf<int64_t> off_slot;
@@ -414,6 +419,9 @@ int upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s) {
 // rt_records.hip
 int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out);
 int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl);
+// rt_materialise.hip
+void launch_materialise_lin(const rt::DTracks &d, int32_t *status, const rt::DStage &stg, const rt::DOut &out, const rt::DMat &a, hipStream_t s,
+                            int n_cus, int units_per_wg);
 void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_rows, bool scale_volumes, double n_azim_2,
                    unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq);
 void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s);
@@ -429,8 +437,8 @@ void launch_scan(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long lon
 int launch_volumes_pass(hipStream_t s, rt_tracks *t, const int32_t *overflow, int64_t cap);  // fill_volumes over the compact records
 void launch_scale_volumes(hipStream_t s, double *volumes, int32_t n_cells, double n_azim_2);
 void launch_fill_tau(hipStream_t s, rt_tracks *t, int32_t n_groups);
-void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, double *As,
-                        double *Bs, double *Cs, int32_t *iperm);
+void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, const double *ell,
+                        double *As, double *Bs, double *Cs, double *Ls, int32_t *iperm);
 // rt_march.hip
 int launch_march(int mode, int waves, bool split, bool widek, bool topo, unsigned blocks, size_t smem, hipStream_t s, const rt::DMesh &m,
                  const rt::DTracks &t, const rt::DParams &prm, int32_t *counts, int32_t *status, const int64_t *offsets, const rt::DOut &out,

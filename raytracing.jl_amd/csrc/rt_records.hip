@@ -737,14 +737,14 @@ __global__ void k_scale_volumes(double *__restrict__ vol, int32_t n_cells, doubl
 
 
 // rt_tracks_create: the line coefficients in march-slot order and the inverse of the march order, from the uploaded arrays
-// (28 B per track that need not cross PCIe).
+// (36 B per track that need not cross PCIe).
 __global__ void k_slot_arrays(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ A, const double *__restrict__ B,
-                              const double *__restrict__ C, double *__restrict__ As, double *__restrict__ Bs, double *__restrict__ Cs,
-                              int32_t *__restrict__ iperm) {
+                              const double *__restrict__ C, const double *__restrict__ ell, double *__restrict__ As, double *__restrict__ Bs,
+                              double *__restrict__ Cs, double *__restrict__ Ls, int32_t *__restrict__ iperm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t u = perm[i];  // slot i holds track perm[i]
-    As[i] = A[u]; Bs[i] = B[u]; Cs[i] = C[u];
+    As[i] = A[u]; Bs[i] = B[u]; Cs[i] = C[u]; Ls[i] = ell[u];
     iperm[u] = (int32_t)i;
 }
 
@@ -753,9 +753,9 @@ __global__ void k_slot_arrays(int64_t n, const int32_t *__restrict__ perm, const
 // ------------------------------------------------------------------- launchers -------------
 namespace rtx {
 
-void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, double *As,
-                        double *Bs, double *Cs, int32_t *iperm) {
-    if (n > 0) hipLaunchKernelGGL(rt::k_slot_arrays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, perm, A, B, C, As, Bs, Cs, iperm);
+void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, const double *ell,
+                        double *As, double *Bs, double *Cs, double *Ls, int32_t *iperm) {
+    if (n > 0) hipLaunchKernelGGL(rt::k_slot_arrays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, perm, A, B, C, ell, As, Bs, Cs, Ls, iperm);
 }
 
 // The six record arrays of a handle, sized for `tot` records, as the kernels see them.
@@ -779,6 +779,7 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
     if (t->n <= 0 || c.n_whole_waves <= 0) return RT_SUCCESS;
     rt::DMat a{};
     a.etab = m->d.etab; a.corder = as_global(c.corder);
+    a.etab_bytes = (int32_t)(uint32_t)std::min<uint64_t>((uint64_t)3 * (uint64_t)m->n_cells * sizeof(rt::EdgeABC), 0xffffffffull);
     a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.tally = tally ? 1 : 0;
     a.force_exact = m->test_exact_sums; a.ctl = d_ctl; a.vacc = as_global(t->vacc.p);
     if (tally) {
@@ -792,6 +793,11 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
         a.ell_rows = as_global(t->sw_ell.p); a.cell_rows = as_global(t->sw_cell.p);
     }
     const unsigned blocks = (unsigned)a.n_units;
+    // (k_materialise_lin addresses the result arrays through 32-bit buffer offsets: arrays below 4 GB, i.e. 2^29 records)
+    if (records && !rows && m->mat_kernel != 1 && out.cap < ((int64_t)1 << 29) - 64 && c.stg.side_cap > 0) {
+        launch_materialise_lin(c.d_whole, t->status.p, c.stg, out, a, s, m->n_cus, m->mat_units);
+        return RT_SUCCESS;
+    }
     if (records && rows)
         hipLaunchKernelGGL((rt::k_materialise<true, true>), dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
                            (const int64_t *)t->offsets.p, c.stg, out, a);

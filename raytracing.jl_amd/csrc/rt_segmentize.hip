@@ -211,10 +211,14 @@ void free_tracks(rt_tracks *t) {
 // per MB: 11 ms for a BWR assembly's 90 MB, the whole of round 3's upload again) and the page-locked memory a process holds is bounded.
 namespace {
 constexpr size_t kStageBytes = 32u << 20;
-struct StagingBlock { void *p = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy = false; };
+// A block belongs to the device that was current when it was made: its two events can only be recorded on that device's streams
+// (an event of device A on a stream of device B is hipErrorInvalidHandle), so a caller gets a block of ITS device or a new one.
+struct StagingBlock { void *p = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy = false; int device = -1; };
 std::vector<StagingBlock> g_staging;
 std::mutex g_staging_mutex;
-bool staging_new_block(StagingBlock &b) {
+bool staging_new_block(StagingBlock &b, int device) {
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    b.device = device;
     if (hipHostMalloc(&b.p, kStageBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return false; }
     for (auto &e : b.ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(b.p); b.p = nullptr; return false; }
@@ -224,14 +228,13 @@ bool staging_new_block(StagingBlock &b) {
 // and its own preprocessing and upload take longer than that — so that the first rt_tracks_create does not wait for it.
 struct StagingPrefetch {
     std::thread th;
-    std::once_flag once;
+    std::once_flag once, joined;
     void start(int device) {
         std::call_once(once, [&] {
             try {
                 th = std::thread([device] {
-                    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
                     StagingBlock b;
-                    if (!staging_new_block(b)) return;
+                    if (!staging_new_block(b, device)) return;
                     memset(b.p, 0, kStageBytes);  // (the host's first touch of its pages, here rather than in the first upload)
                     std::lock_guard<std::mutex> lk(g_staging_mutex);
                     g_staging.push_back(b);
@@ -240,17 +243,21 @@ struct StagingPrefetch {
             }
         });
     }
-    void wait() { if (th.joinable()) th.join(); }
+    // (rt_multi_create reaches this from several host threads at once: the join happens once, the others wait for it)
+    void wait() { std::call_once(joined, [&] { if (th.joinable()) th.join(); }); }
     ~StagingPrefetch() { wait(); }
 } g_staging_prefetch;
-int staging_acquire(StagingBlock *out) {
+int staging_acquire(StagingBlock *out, int device) {
     g_staging_prefetch.wait();
-    std::lock_guard<std::mutex> lk(g_staging_mutex);
-    for (size_t i = 0; i < g_staging.size(); ++i)
-        if (!g_staging[i].busy) { g_staging[i].busy = true; *out = g_staging[i]; return (int)i; }
+    {
+        std::lock_guard<std::mutex> lk(g_staging_mutex);
+        for (size_t i = 0; i < g_staging.size(); ++i)
+            if (!g_staging[i].busy && g_staging[i].device == device) { g_staging[i].busy = true; *out = g_staging[i]; return (int)i; }
+    }
     StagingBlock b;
-    if (!staging_new_block(b)) return -1;
+    if (!staging_new_block(b, device)) return -1;  // (page-locking takes a millisecond: not under the lock)
     b.busy = true;
+    std::lock_guard<std::mutex> lk(g_staging_mutex);
     g_staging.push_back(b);
     *out = b;
     return (int)g_staging.size() - 1;
@@ -345,11 +352,13 @@ void par_ranges(size_t n, size_t grain, F f) {
 static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, void *const *dst, const size_t *bytes) {
     hipStream_t s = t->mesh->stream;
     StagingBlock stage;
-    const int slot = staging_acquire(&stage);
-    struct Rel { int s; ~Rel() { staging_release(s); } } rel{slot};
+    const int slot = staging_acquire(&stage, t->mesh->device);
+    // (an early return may leave a copy into the block in flight: the stream is drained before the block goes back to the pool)
+    struct Rel { int slot; hipStream_t st; bool ok; ~Rel() { if (!ok && slot >= 0) (void)hipStreamSynchronize(st); staging_release(slot); } } rel{slot, s, false};
     if (slot < 0) {  // no page-locked block to be had
         for (int a = 0; a < n_arrays; ++a)
             if (dst[a] && bytes[a]) RT_HIP(hipMemcpy(dst[a], src[a], bytes[a], hipMemcpyDeviceToHost));
+        rel.ok = true;
         return RT_SUCCESS;
     }
     const size_t half = kStageBytes / 2;
@@ -375,7 +384,9 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
             prev = Piece{(char *)dst[a] + o, nbp, h};
         }
     }
-    return drain(prev);
+    const int rc = drain(prev);
+    rel.ok = rc == RT_SUCCESS;
+    return rc;
 }
 
 // ------------------------------------------------------------------- C ABI ---------------
@@ -538,6 +549,8 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_debug")) { mesh->compact_debug = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "mat_kernel")) { mesh->mat_kernel = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "mat_units")) { mesh->mat_units = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "march_waves")) { mesh->march_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }
@@ -630,6 +643,9 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                 need[w] = (int32_t)std::min<double>((double)rt::kStaticRegions, std::max(1.0, std::ceil(est / (double)rt::kChunkRows)));
             }
         });
+        // region j = the waves [0, reg_cap[j]): the estimates do not fall monotonically along the march order in every sort mode
+        // (nor behind a partial wave of uids packed into the middle), so a wave reserves what any wave behind it needs
+        for (size_t w = nw; w-- > 1;) need[w - 1] = std::max(need[w - 1], need[w]);
         for (int j = 0; j < rt::kStaticRegions; ++j) {
             size_t c = 0;
             while (c < nw && need[c] > j) ++c;
@@ -719,13 +735,14 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         const size_t na = (n + 31) & ~(size_t)31;  // every array starts on a 256-B boundary
         const size_t ncord = (h_corder.size() + 63) & ~(size_t)63;
         // the arena: what goes up — nine double arrays, azim_idx, the march order, the materialise order — and behind it what a small
-        // kernel derives on the device (the lines' coefficients in march-slot order, the inverse of the march order: 28 B per track
+        // kernel derives on the device (the lines' coefficients in march-slot order, the inverse of the march order, the lengths: 36 B per track
         // that need not cross PCIe)
         const size_t up_bytes = 9 * na * sizeof(double) + 2 * na * sizeof(int32_t) + ncord * sizeof(int32_t);
-        const size_t bytes = up_bytes + 3 * na * sizeof(double) + na * sizeof(int32_t) + 256;
+        const size_t bytes = up_bytes + 4 * na * sizeof(double) + na * sizeof(int32_t) + 256;
         StagingBlock stage;
-        const int slot = staging_acquire(&stage);
-        struct Rel { int s; ~Rel() { staging_release(s); } } rel{slot};
+        const int slot = staging_acquire(&stage, mesh->device);
+        // (a failed upload may leave a copy out of the block in flight: the stream is drained before the block goes back to the pool)
+        struct Rel { int slot; hipStream_t st; const bool *ok; ~Rel() { if (!*ok && slot >= 0) (void)hipStreamSynchronize(st); staging_release(slot); } } rel{slot, s, &ok};
         ok = t->in_arena.reserve(bytes) == hipSuccess;
         unsigned char *db = t->in_arena.p;
         const double *src8[9] = {px, py, phi, cos_phi, sin_phi, A, B, C, ell};
@@ -735,8 +752,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             for (int a = 0; a < 9; ++a) dst8[a]->p = (double *)(db + (size_t)a * na * sizeof(double));
             t->azim.p = (int32_t *)(db + ints_off); t->perm.p = t->azim.p + na;
             t->corder.p = h_corder.empty() ? nullptr : t->perm.p + na;
-            t->As.p = (double *)(db + up_bytes); t->Bs.p = t->As.p + na; t->Cs.p = t->Bs.p + na;
-            t->iperm.p = (int32_t *)(t->Cs.p + na);
+            t->As.p = (double *)(db + up_bytes); t->Bs.p = t->As.p + na; t->Cs.p = t->Bs.p + na; t->Ls.p = t->Cs.p + na;
+            t->iperm.p = (int32_t *)(t->Ls.p + na);
         }
         cstamp[2] = cnow();
         if (ok && n > 0) {
@@ -786,7 +803,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                 if (ok && !h_corder.empty())
                     ok = hipMemcpyAsync(t->corder.p, h_corder.data(), h_corder.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess;
             }
-            if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->As.p, t->Bs.p, t->Cs.p, t->iperm.p);
+            if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->ell.p, t->As.p, t->Bs.p, t->Cs.p, t->Ls.p, t->iperm.p);
             ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
             cstamp[4] = cnow();
         }
@@ -814,7 +831,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     d.px = as_global(t->px.p); d.py = as_global(t->py.p); d.phi = as_global(t->phi.p); d.cs = as_global(t->cs.p);
     d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
     d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
-    d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.iperm = as_global(t->iperm.p);
+    d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.Ls = as_global(t->Ls.p); d.iperm = as_global(t->iperm.p);
     d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p); d.w_slot = as_global(t->w_slot.p);
     d.n = n_tracks;
     guard.p = nullptr;
@@ -1350,8 +1367,11 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
     t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
     t->first_failed_status = 0;
     if (fi[0]) {
+        // (on the call's own stream, behind its last kernel: a two-phase call returns on the sequence number k_finish wrote, and a
+        //  copy on the null stream is not ordered against a kernel of this non-blocking stream)
         int32_t stt = 0;
-        RT_HIP(hipMemcpy(&stt, t->status.p + (fi[1] - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpyAsync(&stt, t->status.p + (fi[1] - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        RT_HIP(rtx::wait_stream(s));
         t->first_failed_status = stt;
     }
     t->segmentized = true;
