@@ -20,9 +20,10 @@ every rank (direct sends and receives into the final buffers, ``distributed.Segm
 timed region and always reported beside it (``allgather.ms``, ``segments_per_s_including_allgather``); rank 0 then
 runs the whole problem alone (``single_gpu_same_workload``) so that the speed-up is measured inside one run.
 
-The JSON line also carries ``roofline`` (dominant kernel: algorithmic bytes ÷ HIP-event duration against the
-8 TB/s HBM peak; ``pipeline``: the same for the whole step; ``traffic`` only when the committed PMC summary was
-taken from the very library that is running), ``latency`` (p50/p95 of single steps), ``e2e`` (the costs of the
+The JSON line also carries ``roofline`` (the record-writing kernel — the one that moves the per-segment bytes: algorithmic
+bytes ÷ HIP-event duration against the 8 TB/s HBM peak; ``pipeline_frac``: the same for the whole step; ``march``: the march's
+own limits — latency / issue — with real bytes by counters; ``traffic`` only when the committed PMC summary was taken from the
+very library that is running), ``latency`` (p50/p95 of single steps), ``e2e`` (the costs of the
 boundary around the step: mesh preparation, track upload, record download) and, at N=1, ``cpu_baseline`` (the
 oracle — a C port of the reference's algorithm — timed on the host cores of the same box).
 """
@@ -50,7 +51,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 BYTES_PER_SEGMENT = {"march": 45.0, "compact": 64.0, "scan": 0.0}
 BYTES_PER_SEGMENT_TWO_PHASE = {"march": 45.0, "compact": 48.0, "scan": 0.0}
 STEP_BYTES_PER_SEGMENT = 45.0  # the whole step, by the same definition (what one segmentize! must at least move)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "pmc_summary.json")
 
 WORKLOADS = {
     "c3": dict(mesh="pincell.msh", n_azim=128, delta=1e-3, name="BASELINE configs[2]: demo/pincell.msh, nφ=128, δ=1e-3"),
@@ -65,6 +66,9 @@ def lib_sha256():
     return hashlib.sha256(open(_capi.LIB_PATH, "rb").read()).hexdigest()
 
 
+PMC_KERNELS = {}  # raw counters per kernel of the committed PMC passes (filled by pmc_traffic when they belong to this library)
+
+
 def pmc_traffic():
     """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes — only if they were taken from the
     library that is running now (sha256 of the .so recorded by tools/pmc_summary.py).  FETCH_SIZE and WRITE_SIZE are
@@ -73,9 +77,11 @@ def pmc_traffic():
     try:
         d = json.load(open(PMC_SUMMARY))
         if d.get("lib_sha256") != lib_sha256():
-            return {}, "profiles/r04/pmc_summary.json was taken from another build of the library"
+            return {}, "profiles/r05/pmc_summary.json was taken from another build of the library"
+        global PMC_KERNELS
+        PMC_KERNELS = d["kernels"]
         return ({k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in d["kernels"].items()
-                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r04/pmc_summary.json (same library, sha256 match)")
+                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r05/pmc_summary.json (same library, sha256 match)")
     except Exception as e:
         return {}, "no PMC summary: %r" % (e,)
 
@@ -88,7 +94,7 @@ def kernel_names(stats):
     cheap = stats.get("cheap_records", 0) > 0  # the TOPO instantiation (cheap steps) ran
     return {"march": "rt::k_march<2, %d, %s, %s, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
                                                            "true" if cheap else "false"),
-            "compact": "rt::k_materialise<true, false>" if cheap else "rt::k_compact3<%s>" % ("true" if sp else "false"),
+            "compact": "rt::k_materialise_lin" if cheap else "rt::k_compact3<%s>" % ("true" if sp else "false"),
             "scan": "rt::k_scan_fused" if cheap else "rt::k_scan_write"}
 
 
@@ -573,7 +579,7 @@ def _main(real_stdout):
                 if rank == 0:
                     ms_step = t_max / args.steps * 1e3
                     per_k = {key: kern[key] / args.steps for key in ("march", "compact")}
-                    dom = max(per_k, key=per_k.get)
+                    dom = "compact"  # (the record-writing kernel: the one that moves the per-segment bytes)
                     bps_fb = bytes_per_segment(stats)
                     ach = bps_fb[dom] * local_total / (per_k[dom] * 1e-3) / 1e9 if per_k[dom] > 0 else 0.0
                     fb = {"metric": "segments/sec (whole node)", "value": global_segments * args.steps / t_max, "unit": "segments/s",
@@ -736,12 +742,27 @@ def _main(real_stdout):
             per_kernel.append({"kernel": names[key], "ms_avg": ms, "bytes_per_segment": bps,
                                "achieved_GBs": bps * local_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                                "traffic": traffic.get(names[key]) if wkey == "c3" and world == 1 else None})
-        # (the scan moves no per-segment bytes: it is reported, never the roofline's kernel — on a GPU shared by two rehearsal
-        #  ranks its events can span the other rank's kernels)
-        dom_k = max((k for k in per_kernel if k["bytes_per_segment"] > 0), key=lambda k: k["ms_avg"])
-        achieved = dom_k["achieved_GBs"]
+        # The roofline's kernel is the one that moves SURVEY §8(d)'s bytes — the record-writing kernel (k_materialise_lin: 4 B read +
+        # 44 B written per segment; k_compact3 for calls that march with exact steps) — priced with its own bytes and its own HIP-event
+        # time.  The march writes 4 B per segment and is bound by its lanes' dependent chains: it is reported as such (`march`: real
+        # bytes and VALU issue by counters when the committed PMC passes belong to this library), never priced with bytes it does not move.
+        rec_k = next(k for k in per_kernel if k["kernel"] == names["compact"])
+        march_k = next(k for k in per_kernel if k["kernel"] == names["march"])
+        achieved = rec_k["achieved_GBs"]
         step_GBs = STEP_BYTES_PER_SEGMENT * global_segments / (ms_per_step * 1e-3) / 1e9
         tr_all = [k["traffic"] for k in per_kernel]
+        traffic_ratio = (sum(tr_all) / (STEP_BYTES_PER_SEGMENT * local_total)) if all(t is not None for t in tr_all) else None
+        march_pmc = PMC_KERNELS.get(names["march"], {}) if (wkey == "c3" and world == 1) else {}
+        march_report = {"kernel": march_k["kernel"], "bound": "latency/issue", "ms_avg": march_k["ms_avg"],
+                        "bytes_by_counters": march_k["traffic"],
+                        "achieved_GBs_by_counters": (march_k["traffic"] / (march_k["ms_avg"] * 1e-3) / 1e9) if march_k["traffic"] and march_k["ms_avg"] > 0 else None,
+                        "frac_of_hbm_peak_by_counters": (march_k["traffic"] / (march_k["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if march_k["traffic"] and march_k["ms_avg"] > 0 else None,
+                        # SQ_INSTS_VALU wave-instructions x 4 issue cycles over (SIMDs x the kernel's cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                        "valu_issue_frac": (march_pmc["SQ_INSTS_VALU"] * 4.0 / (4 * info_cus * march_pmc["GRBM_GUI_ACTIVE"] / 8.0))
+                                           if "SQ_INSTS_VALU" in march_pmc and march_pmc.get("GRBM_GUI_ACTIVE") else None,
+                        "wait_frac": (march_pmc["SQ_WAIT_ANY"] / march_pmc["SQ_WAVE_CYCLES"]) if march_pmc.get("SQ_WAVE_CYCLES") else None,
+                        "note": "one lane = one track: the kernel lasts as long as its longest lane's chain of dependent 32-B fetches; "
+                                "it stages 4 B per segment"}
         out = {
             "metric": "segments/sec (whole node)",
             "value": global_segments * args.steps / t_max,
@@ -776,17 +797,21 @@ def _main(real_stdout):
                 "library_sha256": lib_sha256(),
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom_k["kernel"],
+                "bound": "hbm", "kernel": rec_k["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": dom_k["traffic"], "traffic_source": traffic_src,
-                "bytes_per_segment": dom_k["bytes_per_segment"], "segments_per_launch": int(local_total),
-                "kernel_ms_avg": dom_k["ms_avg"],
+                "traffic": rec_k["traffic"], "traffic_source": traffic_src,
+                "bytes_per_segment": rec_k["bytes_per_segment"], "segments_per_launch": int(local_total),
+                "kernel_ms_avg": rec_k["ms_avg"],
+                "pipeline_frac": step_GBs / (HBM_PEAK_GBS * world),
+                "traffic_over_algorithmic": traffic_ratio,
+                "march": march_report,
                 "pipeline": {"achieved": step_GBs, "frac": step_GBs / (HBM_PEAK_GBS * world), "unit": "GB/s",
                              "bytes_per_segment": STEP_BYTES_PER_SEGMENT, "ms_per_step": ms_per_step,
-                             "traffic_over_algorithmic": (sum(tr_all) / (STEP_BYTES_PER_SEGMENT * local_total)) if all(t is not None for t in tr_all) else None,
+                             "traffic_over_algorithmic": traffic_ratio,
                              "note": "whole step: algorithmic bytes (45 B/segment) ÷ ms_per_step against the peak of the GPUs in use"},
-                "note": "dominant kernel by HIP-event duration; algorithmic bytes = bytes_per_segment x segments per launch "
-                        "(DESIGN.md §4).  The march is FP64 traversal bound by its per-track dependent chain, not by HBM",
+                "note": "kernel = the record-writing kernel (the one that moves SURVEY §8(d)'s bytes): bytes_per_segment x segments per "
+                        "launch ÷ its HIP-event time (DESIGN.md §4); pipeline_frac = 45 B/segment ÷ ms_per_step; the march is FP64 "
+                        "traversal bound by its per-track dependent chain, see `march`",
             },
             "kernels": per_kernel,
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},

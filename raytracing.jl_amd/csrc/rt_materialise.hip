@@ -279,7 +279,11 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 p.t0 = p.w0 != 0 ? (int32_t)(tt & 15u) : 0;
                 p.t1 = p.w1 != 0 ? (int32_t)((tt >> 8) & 15u) : 0;
             }
+#ifdef RT_LIN_PROBE_GATHER0
+            const uint32_t o0 = (uint32_t)(p.w0 > 0 ? 1 : 0) << 5, o1 = (uint32_t)(p.w1 > 0 ? 2 : 0) << 5;  // (probe: every gather hits the same two entries; results void)
+#else
             const uint32_t o0 = (uint32_t)(p.w0 > 0 ? (p.w0 & kWordCode) - 1 : 0) << 5, o1 = (uint32_t)(p.w1 > 0 ? (p.w1 & kWordCode) - 1 : 0) << 5;
+#endif
             const lin_d2 ab0 = __builtin_bit_cast(lin_d2, __builtin_amdgcn_raw_buffer_load_b128(r_etab, o0, 0, 0));
             const lin_d2 ab1 = __builtin_bit_cast(lin_d2, __builtin_amdgcn_raw_buffer_load_b128(r_etab, o1, 0, 0));
             p.e0A = ab0.x; p.e0B = ab0.y; p.e0C = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_etab, o0 + 16u, 0, 0));
@@ -493,7 +497,11 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         }
     }
 #endif
+#ifdef RT_LIN_PROBE_GATHER0
+    if (false) {
+#else
     if (a.tally) {
+#endif
         __syncthreads();
         if (threadIdx.x < 16 && have) {
             // Σℓ = first record + chain from its q to the last record's q − gaps (a track of one record: the first record alone)

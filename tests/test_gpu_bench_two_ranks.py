@@ -37,6 +37,23 @@ def test_bench_two_ranks_rehearsal():
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "rehearsal" in d, (d.get("kernel_ms"), d["roofline"], d.get("per_rank"), r.stderr[-1500:])
 
 
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2`, exactly as the driver types it for N = 1 with another number: no launcher around it, no WORLD_SIZE.
+    bench.py must become the launcher itself — start the ranks with torch.distributed.run as a child process, pass rank 0's one
+    JSON line through and leave with the child's exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RT_BENCH_REHEARSAL"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["segments_global"] == 114447177 and d["value"] > 0
+    assert sum(d["per_rank"]["segments"]) == 114447177 and "rehearsal" in d
+
+
 def test_bench_two_ranks_extras_watchdog():
     """An extra after the timed region that does not return in time must not cost the run its line: with a 1-s limit the gloo
     all-gather of the 5-GB global list is still running when rank 0 prints the headline line without the extras and every rank
