@@ -1,0 +1,239 @@
+// rt_hostpar.hpp — the host-side, device-free parts of rt_tracks_create and of the pipelined fetch (librt_segmentize.so): the team of
+// host threads, the march order / reserved-chunk / compaction-order plan of a track set, the packing of a track set's image into a
+// page-locked block, the copy of a fetched piece into the caller's arrays.  No HIP call in here: tests/sanitize/hostpar_san.cpp
+// builds this header with AddressSanitizer + UBSan and with ThreadSanitizer (tests/sanitize/run.sh), with the device copies of the
+// callers replaced by memcpy.
+#pragma once
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <numeric>
+#include <thread>
+#include <utility>
+#include <vector>
+#include <unistd.h>
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
+
+namespace rthostpar {
+
+// A few host threads that stay: starting a thread costs ≈30 µs and rt_tracks_create makes four passes over the track arrays — with
+// threads per pass that was a third of the call at the headline configuration.  One job at a time; a caller that finds the team
+// busy (rt_multi_create uploads its shards from several threads) does its work alone.
+class WorkerTeam {
+  public:
+    ~WorkerTeam() {
+        if (pid_ != getpid()) return;  // (a forked child never had the threads)
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : *th_) t.join();
+    }
+    // f(k) for k in [0, parts): part 0 on the caller's thread; `parts` comes back as the number that run (the team may not get all
+    // its threads) before the first one starts; false if the team is busy (nothing was run)
+    template <typename F>
+    bool run(unsigned &parts, F &f, std::vector<std::exception_ptr> &err) {
+        std::unique_lock<std::mutex> job(job_, std::try_to_lock);
+        if (!job.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (pid_ != getpid()) { th_ = new std::vector<std::thread>; pid_ = getpid(); }  // after a fork: the parent's threads are not here
+            while (th_->size() + 1 < parts) {
+                const unsigned id = (unsigned)th_->size() + 1;
+                try { th_->emplace_back([this, id] { loop(id); }); } catch (...) { break; }
+            }
+            parts = std::min<unsigned>(parts, (unsigned)th_->size() + 1);
+            call_ = [&f, &err](unsigned k) { try { f(k); } catch (...) { err[k] = std::current_exception(); } };
+            parts_ = parts; pending_ = parts - 1; ++gen_;
+        }
+        cv_.notify_all();
+        call_(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        return true;
+    }
+  private:
+    void loop(unsigned id) {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            if (id >= parts_) continue;
+            lk.unlock();
+            call_(id);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex m_, job_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> *th_ = new std::vector<std::thread>;
+    pid_t pid_ = getpid();
+    std::function<void(unsigned)> call_;
+    unsigned parts_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+inline WorkerTeam g_team;
+
+// f(i0, i1) over [0, n) on a few host threads (results must not depend on the split); what a worker throws is rethrown here
+template <typename F>
+inline void par_ranges(size_t n, size_t grain, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n / std::max<size_t>(grain, 1) + 1}));
+    if (nt == 1) { f((size_t)0, n); return; }
+    std::vector<std::exception_ptr> err(nt);
+    unsigned parts = nt;  // (the team may run fewer: part k is [n·k/parts, n·(k+1)/parts) of however many do)
+    auto body = [&](unsigned k) { f(n * k / parts, n * (k + 1) / parts); };
+    const bool ran = g_team.run(parts, body, err);
+    if (!ran) { f((size_t)0, n); return; }
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+}
+
+// What rt_tracks_create derives from the tracks' lengths before anything is uploaded.
+struct MarchPlan {
+    std::vector<int32_t> perm;     // march slot -> uid
+    int32_t reg_cap[16] = {};      // DStage: the leading march waves that get a reserved j-th chunk
+    std::vector<int32_t> corder;   // large batches: march waves in the order of their output addresses (else empty)
+};
+inline void plan_march_order(const double *ell, size_t n, int sort_mode, double kappa, int64_t test_reserved_pct, int n_regions, int chunk_rows,
+                             MarchPlan &out) {
+    // march order (default 2): waves of 64 CONSECUTIVE uids, longest wave first.  Neighbouring
+    // tracks of one angle cross the same cells at the same time (shared walk records, coherent
+    // branches) and have nearly equal lengths; sorting individual tracks by length measured 20 %
+    // slower because it scatters the lanes of a wave over the whole mesh.
+    // (one call is what the reference makes, src/trackgenerator.jl:357-369: the host's share of it — wave maxima, the fills,
+    //  the copy into the staging block — runs on a few threads; the sorts are over waves, not tracks)
+    std::vector<int32_t> &perm = out.perm;
+    perm.assign(n, 0);
+    if (sort_mode == 1) {
+        std::iota(perm.begin(), perm.end(), 0);
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
+    } else if (sort_mode == 2) {
+        const size_t nw = (n + 63) / 64;
+        std::vector<double> wmax(nw, 0.0);
+        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                double mx = 0.0;
+                for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[i]);
+                wmax[w] = mx;
+            }
+        });
+        // (keys and indices side by side: the comparator of a sort over indices alone jumps through wmax)
+        std::vector<std::pair<double, int32_t>> wkey(nw);
+        for (size_t w = 0; w < nw; ++w) wkey[w] = {wmax[w], (int32_t)w};
+        std::stable_sort(wkey.begin(), wkey.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
+        std::vector<int32_t> worder(nw);
+        for (size_t w = 0; w < nw; ++w) worder[w] = wkey[w].second;
+        // the batch's last wave of uids may be partial: the slots behind it are packed (no padding), so its position shifts them
+        std::vector<size_t> first(nw + 1, 0);
+        for (size_t w = 0; w < nw; ++w) first[w + 1] = first[w] + std::min<size_t>(64, n - (size_t)worder[w] * 64);
+        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                size_t k2 = first[w];
+                for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
+            }
+        });
+    } else {
+        std::iota(perm.begin(), perm.end(), 0);
+    }
+    {
+        // Reserved staging chunks (DStage): march wave w (64 slots of the march order) is expected to need
+        // ceil((1.15·κ·ℓ_max + 12) / 32) chunks — κ·ℓ is the Cauchy–Crofton mean, a wave through a denser part of the mesh takes
+        // its further chunks from the cursor — and region j serves the leading waves that need a j-th chunk
+        const size_t nw = (n + 63) / 64;
+        std::vector<int32_t> need(nw, 1);
+        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                double mx = 0.0;
+                for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[perm[i]]);
+                const double est = (1.15 * kappa * mx + 12.0) * (test_reserved_pct >= 0 ? 0.01 * (double)test_reserved_pct : 1.0);
+                need[w] = (int32_t)std::min<double>((double)n_regions, std::max(1.0, std::ceil(est / (double)chunk_rows)));
+            }
+        });
+        // region j = the waves [0, reg_cap[j]): the estimates do not fall monotonically along the march order in every sort mode
+        // (nor behind a partial wave of uids packed into the middle), so a wave reserves what any wave behind it needs
+        for (size_t w = nw; w-- > 1;) need[w - 1] = std::max(need[w - 1], need[w]);
+        for (int j = 0; j < n_regions; ++j) {
+            size_t c = 0;
+            while (c < nw && need[c] > j) ++c;
+            out.reg_cap[j] = (int32_t)c;
+        }
+    }
+    std::vector<int32_t> &h_corder = out.corder;
+    h_corder.clear();
+    if (((n + 63) / 64) > 4096) {  // batches of many rounds: compaction in output order (measured -8 % at 16 k waves, +1.5 % at 2 k)
+        const size_t nw = (n + 63) / 64;
+        // march waves (64 slots each) in the order of the uid of their first track.  Every march wave starts in another wave of
+        // uids (the slots behind a partial last uid-wave are packed, so a march wave may straddle two of them — its first slot
+        // still lies in one no other march wave starts in): a counting sort over uid-waves
+        std::vector<int32_t> at(nw, -1);
+        for (size_t a = 0; a < nw; ++a) {
+            int32_t &slot_of = at[(size_t)perm[a * 64] >> 6];
+            if (slot_of >= 0) { at.clear(); break; }  // (not expected: fall back to the sort)
+            slot_of = (int32_t)a;
+        }
+        if (!at.empty()) {
+            h_corder.reserve(nw);
+            for (size_t w = 0; w < nw; ++w)
+                if (at[w] >= 0) h_corder.push_back(at[w]);
+        }
+        if (h_corder.size() != nw) {
+            h_corder.resize(nw);
+            std::iota(h_corder.begin(), h_corder.end(), 0);
+            std::stable_sort(h_corder.begin(), h_corder.end(), [&](int32_t a, int32_t b) { return perm[(size_t)a * 64] < perm[(size_t)b * 64]; });
+        }
+    }
+}
+
+// The image of tracks [i0, i0 + m) as it lies in the arena / in a range's half of the staging block: nine double arrays of `stride`
+// entries each, then azim_idx and the march order (int32, `stride` entries each).  Written by the team's threads.
+inline void pack_tracks_image(unsigned char *hb, size_t stride, size_t i0, size_t m, const double *const src8[9], const int32_t *azim_idx,
+                              const int32_t *perm) {
+    int32_t *h_az = (int32_t *)(hb + 9 * stride * sizeof(double)), *h_pm = h_az + stride;
+    par_ranges(m, 16384, [&](size_t j0, size_t j1) {
+        for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * stride * sizeof(double)) + j0, src8[a] + i0 + j0, (j1 - j0) * sizeof(double));
+        memcpy(h_az + j0, azim_idx + i0 + j0, (j1 - j0) * sizeof(int32_t));
+        memcpy(h_pm + j0, perm + i0 + j0, (j1 - j0) * sizeof(int32_t));
+    });
+}
+
+// The caller's (often freshly allocated) destination range is made resident before a piece is copied into it — while that piece is
+// still in flight from the device: transparent huge pages are asked for where the range covers whole ones (512 times fewer
+// faults), then the pages are populated in one call per thread (Linux >= 5.14; where either is unknown the copy takes the faults as
+// before).  Best effort: every error is ignored.
+inline void prefault_range(char *dst, size_t bytes) {
+#if defined(__linux__)
+    const uintptr_t page = 4096;
+    const uintptr_t a = ((uintptr_t)dst + page - 1) & ~(page - 1), b = ((uintptr_t)dst + bytes) & ~(page - 1);
+    if (b <= a) return;
+#ifdef MADV_HUGEPAGE
+    (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
+#endif
+#ifndef MADV_POPULATE_WRITE
+#define RT_MADV_POPULATE_WRITE 23
+#else
+#define RT_MADV_POPULATE_WRITE MADV_POPULATE_WRITE
+#endif
+    par_ranges((size_t)((b - a) / page), 512, [&](size_t p0, size_t p1) {
+        if (p1 > p0) (void)madvise((void *)(a + p0 * page), (p1 - p0) * page, RT_MADV_POPULATE_WRITE);
+    });
+#else
+    (void)dst; (void)bytes;
+#endif
+}
+
+// A fetched piece from its half of the staging block into the caller's array (the threads also take the page faults of a fresh
+// destination in parallel).
+inline void copy_into_place(char *dst, const char *src, size_t bytes) {
+    par_ranges(bytes, (size_t)1 << 20, [&](size_t b0, size_t b1) { memcpy(dst + b0, src + b0, b1 - b0); });
+}
+
+}  // namespace rthostpar

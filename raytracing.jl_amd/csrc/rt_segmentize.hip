@@ -9,6 +9,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (csrc/Makefile).
 // There is no CPU fallback in this library: without a GPU every compute entry point fails.
 #include "rt_internal.hpp"
+#include "rt_hostpar.hpp"
 
 #include <condition_variable>
 #include <functional>
@@ -267,80 +268,6 @@ void staging_release(int slot) {
     std::lock_guard<std::mutex> lk(g_staging_mutex);
     g_staging[(size_t)slot].busy = false;
 }
-// A few host threads that stay: starting a thread costs ≈30 µs and rt_tracks_create makes four passes over the track arrays — with
-// threads per pass that was a third of the call at the headline configuration.  One job at a time; a caller that finds the team
-// busy (rt_multi_create uploads its shards from several threads) does its work alone.
-class WorkerTeam {
-  public:
-    ~WorkerTeam() {
-        if (pid_ != getpid()) return;  // (a forked child never had the threads)
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &t : *th_) t.join();
-    }
-    // f(k) for k in [0, parts): part 0 on the caller's thread; `parts` comes back as the number that run (the team may not get all
-    // its threads) before the first one starts; false if the team is busy (nothing was run)
-    template <typename F>
-    bool run(unsigned &parts, F &f, std::vector<std::exception_ptr> &err) {
-        std::unique_lock<std::mutex> job(job_, std::try_to_lock);
-        if (!job.owns_lock()) return false;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            if (pid_ != getpid()) { th_ = new std::vector<std::thread>; pid_ = getpid(); }  // after a fork: the parent's threads are not here
-            while (th_->size() + 1 < parts) {
-                const unsigned id = (unsigned)th_->size() + 1;
-                try { th_->emplace_back([this, id] { loop(id); }); } catch (...) { break; }
-            }
-            parts = std::min<unsigned>(parts, (unsigned)th_->size() + 1);
-            call_ = [&f, &err](unsigned k) { try { f(k); } catch (...) { err[k] = std::current_exception(); } };
-            parts_ = parts; pending_ = parts - 1; ++gen_;
-        }
-        cv_.notify_all();
-        call_(0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
-        return true;
-    }
-  private:
-    void loop(unsigned id) {
-        unsigned long seen = 0;
-        for (;;) {
-            std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-            if (stop_) return;
-            seen = gen_;
-            if (id >= parts_) continue;
-            lk.unlock();
-            call_(id);
-            lk.lock();
-            if (--pending_ == 0) done_.notify_one();
-        }
-    }
-    std::mutex m_, job_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> *th_ = new std::vector<std::thread>;
-    pid_t pid_ = getpid();
-    std::function<void(unsigned)> call_;
-    unsigned parts_ = 0, pending_ = 0;
-    unsigned long gen_ = 0;
-    bool stop_ = false;
-};
-WorkerTeam g_team;
-
-// f(i0, i1) over [0, n) on a few host threads (results must not depend on the split); what a worker throws is rethrown here
-template <typename F>
-void par_ranges(size_t n, size_t grain, F f) {
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n / std::max<size_t>(grain, 1) + 1}));
-    if (nt == 1) { f((size_t)0, n); return; }
-    std::vector<std::exception_ptr> err(nt);
-    unsigned parts = nt;  // (the team may run fewer: part k is [n·k/parts, n·(k+1)/parts) of however many do)
-    auto body = [&](unsigned k) { f(n * k / parts, n * (k + 1) / parts); };
-    const bool ran = g_team.run(parts, body, err);
-    if (!ran) { f((size_t)0, n); return; }
-    for (auto &e : err)
-        if (e) std::rethrow_exception(e);
-}
 }  // namespace
 
 
@@ -362,13 +289,14 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
         return RT_SUCCESS;
     }
     const size_t half = kStageBytes / 2;
+    static const bool prefault = getenv("RT_FETCH_NO_PREFAULT") == nullptr;  // (development: A/B of the destination's pre-fault)
     struct Piece { char *d; size_t bytes; int h; };
     Piece prev{nullptr, 0, 0};
     auto drain = [&](const Piece &pc) -> int {  // the piece has arrived in its half: into place
         if (!pc.d) return RT_SUCCESS;
         RT_HIP(hipEventSynchronize(stage.ev[pc.h]));
         const char *hb = (const char *)stage.p + (size_t)pc.h * half;
-        par_ranges(pc.bytes, (size_t)1 << 20, [&](size_t b0, size_t b1) { memcpy(pc.d + b0, hb + b0, b1 - b0); });
+        rthostpar::copy_into_place(pc.d, hb, pc.bytes);
         return RT_SUCCESS;
     };
     int k = 0;
@@ -380,6 +308,7 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
             // (half h was drained two pieces ago: `prev` is the piece in the OTHER half)
             RT_HIP(hipMemcpyAsync((char *)stage.p + (size_t)h * half, (const char *)src[a] + o, nbp, hipMemcpyDeviceToHost, s));
             RT_HIP(hipEventRecord(stage.ev[h], s));
+            if (prefault) rthostpar::prefault_range((char *)dst[a] + o, nbp);  // (while the piece is in flight)
             if (int rc = drain(prev)) return rc;
             prev = Piece{(char *)dst[a] + o, nbp, h};
         }
@@ -591,96 +520,18 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     const bool ctime = getenv("RT_CREATE_TIMING") != nullptr;
     auto cnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double cstamp[6] = {cnow(), 0, 0, 0, 0, 0};
-    // march order (default 2): waves of 64 CONSECUTIVE uids, longest wave first.  Neighbouring
-    // tracks of one angle cross the same cells at the same time (shared walk records, coherent
-    // branches) and have nearly equal lengths; sorting individual tracks by length measured 20 %
-    // slower because it scatters the lanes of a wave over the whole mesh.
-    // (one call is what the reference makes, src/trackgenerator.jl:357-369: the host's share of it — wave maxima, the fills,
-    //  the copy into the staging block — runs on a few threads; the sorts are over waves, not tracks)
-    std::vector<int32_t> perm(n);
-    if (mesh->sort_mode == 1) {
-        std::iota(perm.begin(), perm.end(), 0);
-        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
-    } else if (mesh->sort_mode == 2) {
-        const size_t nw = (n + 63) / 64;
-        std::vector<double> wmax(nw, 0.0);
-        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
-            for (size_t w = w0; w < w1; ++w) {
-                double mx = 0.0;
-                for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[i]);
-                wmax[w] = mx;
-            }
-        });
-        // (keys and indices side by side: the comparator of a sort over indices alone jumps through wmax)
-        std::vector<std::pair<double, int32_t>> wkey(nw);
-        for (size_t w = 0; w < nw; ++w) wkey[w] = {wmax[w], (int32_t)w};
-        std::stable_sort(wkey.begin(), wkey.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
-        std::vector<int32_t> worder(nw);
-        for (size_t w = 0; w < nw; ++w) worder[w] = wkey[w].second;
-        // the batch's last wave of uids may be partial: the slots behind it are packed (no padding), so its position shifts them
-        std::vector<size_t> first(nw + 1, 0);
-        for (size_t w = 0; w < nw; ++w) first[w + 1] = first[w] + std::min<size_t>(64, n - (size_t)worder[w] * 64);
-        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
-            for (size_t w = w0; w < w1; ++w) {
-                size_t k2 = first[w];
-                for (size_t l = 0; l < 64 && (size_t)worder[w] * 64 + l < n; ++l) perm[k2++] = (int32_t)(worder[w] * 64 + l);
-            }
-        });
-    } else {
-        std::iota(perm.begin(), perm.end(), 0);
-    }
-    {
-        // Reserved staging chunks (DStage): march wave w (64 slots of the march order) is expected to need
-        // ceil((1.15·κ·ℓ_max + 12) / 32) chunks — κ·ℓ is the Cauchy–Crofton mean, a wave through a denser part of the mesh takes
-        // its further chunks from the cursor — and region j serves the leading waves that need a j-th chunk
-        const size_t nw = (n + 63) / 64;
-        std::vector<int32_t> need(nw, 1);
-        par_ranges(nw, 512, [&](size_t w0, size_t w1) {
-            for (size_t w = w0; w < w1; ++w) {
-                double mx = 0.0;
-                for (size_t i = w * 64; i < std::min(n, w * 64 + 64); ++i) mx = std::max(mx, ell[perm[i]]);
-                const double est = (1.15 * mesh->kappa * mx + 12.0) * (mesh->test_reserved_pct >= 0 ? 0.01 * (double)mesh->test_reserved_pct : 1.0);
-                need[w] = (int32_t)std::min<double>((double)rt::kStaticRegions, std::max(1.0, std::ceil(est / (double)rt::kChunkRows)));
-            }
-        });
-        // region j = the waves [0, reg_cap[j]): the estimates do not fall monotonically along the march order in every sort mode
-        // (nor behind a partial wave of uids packed into the middle), so a wave reserves what any wave behind it needs
-        for (size_t w = nw; w-- > 1;) need[w - 1] = std::max(need[w - 1], need[w]);
-        for (int j = 0; j < rt::kStaticRegions; ++j) {
-            size_t c = 0;
-            while (c < nw && need[c] > j) ++c;
-            t->reg_cap[j] = (int32_t)c;
-        }
-    }
-    std::vector<int32_t> h_corder;
-    if (nw_all_early(n) > 4096) {  // batches of many rounds: compaction in output order (measured -8 % at 16 k waves, +1.5 % at 2 k)
-        const size_t nw = (n + 63) / 64;
-        // march waves (64 slots each) in the order of the uid of their first track.  Every march wave starts in another wave of
-        // uids (the slots behind a partial last uid-wave are packed, so a march wave may straddle two of them — its first slot
-        // still lies in one no other march wave starts in): a counting sort over uid-waves
-        std::vector<int32_t> at(nw, -1);
-        for (size_t a = 0; a < nw; ++a) {
-            int32_t &slot_of = at[(size_t)perm[a * 64] >> 6];
-            if (slot_of >= 0) { at.clear(); break; }  // (not expected: fall back to the sort)
-            slot_of = (int32_t)a;
-        }
-        if (!at.empty()) {
-            h_corder.reserve(nw);
-            for (size_t w = 0; w < nw; ++w)
-                if (at[w] >= 0) h_corder.push_back(at[w]);
-        }
-        if (h_corder.size() != nw) {
-            h_corder.resize(nw);
-            std::iota(h_corder.begin(), h_corder.end(), 0);
-            std::stable_sort(h_corder.begin(), h_corder.end(), [&](int32_t a, int32_t b) { return perm[(size_t)a * 64] < perm[(size_t)b * 64]; });
-        }
-    }
+    // march order, reserved staging chunks, compaction order: host-only code (rt_hostpar.hpp — also built under the sanitizers)
+    rthostpar::MarchPlan plan;
+    rthostpar::plan_march_order(ell, n, mesh->sort_mode, mesh->kappa, mesh->test_reserved_pct, rt::kStaticRegions, rt::kChunkRows, plan);
+    std::vector<int32_t> &perm = plan.perm;
+    std::vector<int32_t> &h_corder = plan.corder;
+    for (int j = 0; j < rt::kStaticRegions; ++j) t->reg_cap[j] = plan.reg_cap[j];
     {
         // Σℓ in a fixed order (blocks of 4096 tracks, added in block order) whatever the number of threads; range of azim_idx
         const size_t nb = (n + 4095) / 4096;
         std::vector<double> bs(nb, 0.0);
         std::vector<int32_t> bmin(nb, 0x7fffffff), bmax(nb, (int32_t)0x80000000);
-        par_ranges(nb, 16, [&](size_t b0, size_t b1) {
+        rthostpar::par_ranges(nb, 16, [&](size_t b0, size_t b1) {
             for (size_t b = b0; b < b1; ++b) {
                 double sl = 0.0;
                 int32_t lo = 0x7fffffff, hi = (int32_t)0x80000000;
@@ -761,11 +612,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                 // everything fits in half a block: the image of the uploaded part as it lies in the arena, ONE copy
                 unsigned char *hb = (unsigned char *)stage.p;
                 int32_t *h_az = (int32_t *)(hb + ints_off), *h_pm = h_az + na, *h_co = h_pm + na;
-                par_ranges(n, 16384, [&](size_t i0, size_t i1) {
-                    for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * na * sizeof(double)) + i0, src8[a] + i0, (i1 - i0) * sizeof(double));
-                    memcpy(h_az + i0, azim_idx + i0, (i1 - i0) * sizeof(int32_t));
-                    memcpy(h_pm + i0, perm.data() + i0, (i1 - i0) * sizeof(int32_t));
-                });
+                rthostpar::pack_tracks_image(hb, na, 0, n, src8, azim_idx, perm.data());
+                (void)h_az; (void)h_pm;
                 if (!h_corder.empty()) memcpy(h_co, h_corder.data(), h_corder.size() * sizeof(int32_t));
                 cstamp[3] = cnow();
                 ok = hipMemcpyAsync(db, hb, up_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -780,11 +628,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                     unsigned char *hb = (unsigned char *)stage.p + (size_t)(k & 1) * half;
                     if (k >= 2) ok = hipEventSynchronize(stage.ev[k & 1]) == hipSuccess;  // the half's previous range has left it
                     int32_t *h_az = (int32_t *)(hb + 9 * rcap * sizeof(double)), *h_pm = h_az + rcap;
-                    par_ranges(m, 16384, [&](size_t j0, size_t j1) {
-                        for (int a = 0; a < 9; ++a) memcpy((double *)(hb + (size_t)a * rcap * sizeof(double)) + j0, src8[a] + i0 + j0, (j1 - j0) * sizeof(double));
-                        memcpy(h_az + j0, azim_idx + i0 + j0, (j1 - j0) * sizeof(int32_t));
-                        memcpy(h_pm + j0, perm.data() + i0 + j0, (j1 - j0) * sizeof(int32_t));
-                    });
+                    rthostpar::pack_tracks_image(hb, rcap, i0, m, src8, azim_idx, perm.data());
                     for (int a = 0; a < 9 && ok; ++a)
                         ok = hipMemcpyAsync(dst8[a]->p + i0, hb + (size_t)a * rcap * sizeof(double), m * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
                     ok = ok && hipMemcpyAsync(t->azim.p + i0, h_az, m * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess &&
