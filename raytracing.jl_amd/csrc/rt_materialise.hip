@@ -93,6 +93,13 @@ struct LinHalf { int64_t o; double px, py, qx, qy, l; int32_t cell, pad; };
 
 constexpr int32_t kWordLast = 1 << 29;  // (in the LDS copy only) the word of a track's last record
 constexpr int32_t kWordCode = ~(kWordExactTally | kWordLast);
+// The record stores are NON-TEMPORAL (aux bit 1 = nt): whole 128-B lines leave the XCD's L2 without displacing the edges' general
+// forms and the next units' words — same-box A/B: record kernel −12 % at C3, −7 % at C5, and the march of the NEXT call −3 % (it
+// starts in a cache that is not full of dirty record lines).  (Round 3's compaction, whose 256-B runs ended in half-written lines,
+// lost 30 % with them.)
+#ifndef RT_LIN_STORE_AUX
+#define RT_LIN_STORE_AUX 2
+#endif
 constexpr int kWaitVm0 = 0x0F70;  // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt fields at their maxima)
 
 #ifdef RT_LIN_TIMING
@@ -393,13 +400,13 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 const uint32_t vo8 = full ? (uint32_t)oa << 3 : 0xffffffffu;
                 const uint32_t vo4 = full ? (uint32_t)oa << 2 : 0xffffffffu;
                 lin_d2 v;
-                v.x = p0x; v.y = p1x; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_px, vo8, 0, 0);
-                v.x = p0y; v.y = p1y; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_py, vo8, 0, 0);
-                v.x = q0x; v.y = q1x; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_qx, vo8, 0, 0);
-                v.x = q0y; v.y = q1y; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_qy, vo8, 0, 0);
-                v.x = l0; v.y = l1; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_ell, vo8, 0, 0);
+                v.x = p0x; v.y = p1x; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_px, vo8, 0, RT_LIN_STORE_AUX);
+                v.x = p0y; v.y = p1y; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_py, vo8, 0, RT_LIN_STORE_AUX);
+                v.x = q0x; v.y = q1x; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_qx, vo8, 0, RT_LIN_STORE_AUX);
+                v.x = q0y; v.y = q1y; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_qy, vo8, 0, RT_LIN_STORE_AUX);
+                v.x = l0; v.y = l1; __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lin_i4, v), r_ell, vo8, 0, RT_LIN_STORE_AUX);
                 lin_i2 c;
-                c.x = cell0; c.y = cell1; __builtin_amdgcn_raw_buffer_store_b64(c, r_el, vo4, 0, 0);
+                c.x = cell0; c.y = cell1; __builtin_amdgcn_raw_buffer_store_b64(c, r_el, vo4, 0, RT_LIN_STORE_AUX);
             }
             // Half pairs — the first or last record of a run group whose neighbour in memory is not this unit's — wait in LDS for the
             // wave's epilogue (at most two per run group; a list that is full writes directly)
