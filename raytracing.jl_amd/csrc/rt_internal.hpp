@@ -269,7 +269,6 @@ struct rt_mesh {
     int sweep_ell = 1;  // rt_sweep over staged rows: keep ℓ of every row from the first pass for the later ones (0: every pass derives it)
     int sweep_debug = 0, compact_debug = 0;
     int mat_kernel = 0;      // records of a two-phase call: 0 k_materialise_lin (output order, 16-B stores), 1 k_materialise (chunk tiles; A/B)
-    int mat_units = 0;       // k_materialise_lin: 0 persistent workgroups (as many as the chip holds), N > 0 at most N units per workgroup (A/B)
     int march_waves = 0;     // 4 / 6: waves per workgroup of the fused march (0: automatic)
     int topo = 1;          // 1: cheap steps (k_march<..., TOPO>) for whole-track batches when the mesh allows it; 2: forced — also on
                            // meshes where fewer than 90 % of the walkable records carry a cheap certificate, and a wave that is

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     // generic step's, behind tiny steps) the gap ‖p_i − q_(i−1)‖ is missing from the chain: those are added up here.  What the
     // margin cannot decide, k_finish sums left to right as before.
     __shared__ lin_d2 s_qlast[16];   // exit point of the track's last record
-    __shared__ double s_gap[16];     // Σ gaps in front of the records that keep their own p (not the first)
+    __shared__ double s_gap[16];     // Σ gaps (signed: overlaps count negative) in front of the records that keep their own p (not the first)
     __shared__ LinHalf s_half[4][kLinHalfCap];   // per wave: half pairs for the epilogue
     __shared__ double s_fval[4][kLinFlagCap];    // per wave: fill_volumes terms of marked records (value, cell) for the epilogue
     __shared__ int32_t s_fcell[4][kLinFlagCap];
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     LIN_STAMP(0);
 #endif
-    const int64_t unit = blockIdx.x;
+    const int64_t unit = blockIdx.x;  // (a unit on the XCD whose march workgroup staged its words was tried: no difference — the words come from the
+                                      //  memory-side cache either way, profiles/r05/exp_materialise_variants.log)
     if (unit >= a.n_units) return;
     // the result arrays as buffer resources (raw, no stride, bounds = the arrays' capacity; the host takes this kernel only for
     // arrays below 4 GB): see the stores
@@ -380,12 +381,22 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             const double l0 = norm2(p0x - q0x, p0y - q0y);  // Segment ctor, src/segment.jl:31-33
             const double l1 = norm2(p1x - q1x, p1y - q1y);
             if (__builtin_expect(__ballot(gap0 || gap1) != 0, 0)) {  // (the gaps in the chain of Σℓ, see s_qlast)
+                // (the record in front: the slot before — or, for the first row of a later round, the last row of the round before)
+                double b0x = prev_x, b0y = prev_y, b1x = q0x, b1y = q0y;
+                if (many_rounds && s > 0) {
+                    if (gap0 && 2 * m == s_trk[t0].lb) { b0x = s_trk[t0].cx[s & 1]; b0y = s_trk[t0].cy[s & 1]; }
+                    if (gap1 && 2 * m + 1 == s_trk[t1].lb) { b1x = s_trk[t1].cx[s & 1]; b1y = s_trk[t1].cy[s & 1]; }
+                }
                 if (a.tally && gap0) {
-                    atomicAdd(&s_gap[t0], norm2(p0x - prev_x, p0y - prev_y));
+                    // (signed along the march: a record that begins BEHIND the exit point before it — near-vertical tracks, cells that
+                    //  overlap within the locate's tolerance — adds its overlap to Σℓ instead of leaving a gap)
+                    const double g = norm2(p0x - b0x, p0y - b0y);
+                    atomicAdd(&s_gap[t0], (p0x - b0x) * (q0x - p0x) + (p0y - b0y) * (q0y - p0y) < 0.0 ? -g : g);
                     if ((-w0 - 1) & kWordLast) { lin_d2 v; v.x = q0x; v.y = q0y; s_qlast[t0] = v; }  // ... and the chain's end, if it is the last record
                 }
                 if (a.tally && gap1) {
-                    atomicAdd(&s_gap[t1], norm2(p1x - q0x, p1y - q0y));
+                    const double g = norm2(p1x - b1x, p1y - b1y);
+                    atomicAdd(&s_gap[t1], (p1x - b1x) * (q1x - p1x) + (p1y - b1y) * (q1y - p1y) < 0.0 ? -g : g);
                     if ((-w1 - 1) & kWordLast) { lin_d2 v; v.x = q1x; v.y = q1y; s_qlast[t1] = v; }
                 }
             }

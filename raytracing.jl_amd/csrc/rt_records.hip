@@ -795,7 +795,7 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
     const unsigned blocks = (unsigned)a.n_units;
     // (k_materialise_lin addresses the result arrays through 32-bit buffer offsets: arrays below 4 GB, i.e. 2^29 records)
     if (records && !rows && m->mat_kernel != 1 && out.cap < ((int64_t)1 << 29) - 64 && c.stg.side_cap > 0) {
-        launch_materialise_lin(c.d_whole, t->status.p, c.stg, out, a, s, m->n_cus, m->mat_units);
+        launch_materialise_lin(c.d_whole, t->status.p, c.stg, out, a, s, m->n_cus, 0);
         return RT_SUCCESS;
     }
     if (records && rows)

@@ -479,7 +479,6 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_debug")) { mesh->compact_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "mat_kernel")) { mesh->mat_kernel = (int)value; return RT_SUCCESS; }
-    if (!strcmp(name, "mat_units")) { mesh->mat_units = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "march_waves")) { mesh->march_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }

@@ -121,6 +121,44 @@ def test_tracks_longer_than_a_round(rt, orc):
     print(f"longest track {counts.max()} records, {int((counts > 256).sum())} of {len(counts)} tracks beyond one round")
 
 
+@pytest.mark.parametrize("seed", [520017, 520021, 520332, 520050, 520139, 520159, 520479])
+def test_fuzz_cases_that_found_the_chain_errors(rt, orc, seed):
+    """Cases of tools/fuzz_many.py (round 5, seeds 520000 ...) on which the first version of the Σℓ chain failed.  (i) Tracks of
+    258-344 records whose second round begins with a generic step's record: the gap in front of it is measured from the LAST ROW OF
+    THE ROUND BEFORE (kept in LDS), not from the slot before it.  (ii) `steep` tracks (hand-made, within 1e-5 ... 1e-8 of ϕ = π/2):
+    records that begin BEHIND the exit point before them — the gap is signed, an overlap adds to Σℓ.  Forced and gated cheap
+    steps; status, records and volumes against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_cpu
+    import meshgen
+
+    kind, model, n_azim, delta, k = fuzz_cpu.case(seed)
+    tg = rt.TrackGenerator(model, min(n_azim, 256), delta)
+    rt.trace(tg)
+    if kind == "steep":
+        meshgen.steep_tracks(rt, tg, seed)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi, tiny_step=tg.tiny_step,
+                        k=k, iter_cap=4000000, n_threads=0)
+    from raytracing_jl_amd import _capi
+    for topo in (1, 2):
+        dm = _capi.DeviceMesh(tg.mesh, 0)
+        for kk, v in dict(walk=1, split=0, topo=topo, mat_kernel=0).items():
+            dm.set_option(kk, v)
+        dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        aq = tg.azimuthal_quadrature
+        assert dt.segmentize(tg.tiny_step, k, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2) == int(ref["offsets"][-1])
+        off, st = dt.fetch_offsets()
+        seg = dt.fetch_segments()
+        assert np.array_equal(off, ref["offsets"])
+        assert np.array_equal(st, ref["status"]), (seed, kind, topo, np.nonzero(st != ref["status"])[0][:10])
+        for f in FIELDS:
+            assert np.array_equal(seg[f], ref[f]), (seed, f)
+        dt.close(); dm.close()
+
+
 @pytest.mark.parametrize("rtol", [1e-13, 3e-12, 1e-9])
 def test_length_check_by_first_and_last_point(rt, orc, traced, rtol):
     """`isapprox(track.ℓ, Σℓ; rtol)` (src/track.jl:171-175) with tolerances at which many, some and no tracks fail: the kernel forms Σℓ
