@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     // generic step's, behind tiny steps) the gap ‖p_i − q_(i−1)‖ is missing from the chain: those are added up here.  What the
     // margin cannot decide, k_finish sums left to right as before.
     __shared__ lin_d2 s_qlast[16];   // exit point of the track's last record
-    __shared__ double s_gap[16];     // Σ gaps (signed: overlaps count negative) in front of the records that keep their own p (not the first)
+    __shared__ double s_gap[16];     // what the chain misses: Σ gaps in front of records that keep their own p (signed: an overlap counts
+                                     // negative), minus twice the length of such a record if it walks backwards
     __shared__ LinHalf s_half[4][kLinHalfCap];   // per wave: half pairs for the epilogue
     __shared__ double s_fval[4][kLinFlagCap];    // per wave: fill_volumes terms of marked records (value, cell) for the epilogue
     __shared__ int32_t s_fcell[4][kLinFlagCap];
@@ -387,17 +388,30 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                     if (gap0 && 2 * m == s_trk[t0].lb) { b0x = s_trk[t0].cx[s & 1]; b0y = s_trk[t0].cy[s & 1]; }
                     if (gap1 && 2 * m + 1 == s_trk[t1].lb) { b1x = s_trk[t1].cx[s & 1]; b1y = s_trk[t1].cy[s & 1]; }
                 }
-                if (a.tally && gap0) {
-                    // (signed along the march: a record that begins BEHIND the exit point before it — near-vertical tracks, cells that
-                    //  overlap within the locate's tolerance — adds its overlap to Σℓ instead of leaving a gap)
-                    const double g = norm2(p0x - b0x, p0y - b0y);
-                    atomicAdd(&s_gap[t0], (p0x - b0x) * (q0x - p0x) + (p0y - b0y) * (q0y - p0y) < 0.0 ? -g : g);
-                    if ((-w0 - 1) & kWordLast) { lin_d2 v; v.x = q0x; v.y = q0y; s_qlast[t0] = v; }  // ... and the chain's end, if it is the last record
-                }
-                if (a.tally && gap1) {
-                    const double g = norm2(p1x - b1x, p1y - b1y);
-                    atomicAdd(&s_gap[t1], (p1x - b1x) * (q1x - p1x) + (p1y - b1y) * (q1y - p1y) < 0.0 ? -g : g);
-                    if ((-w1 - 1) & kWordLast) { lin_d2 v; v.x = q1x; v.y = q1y; s_qlast[t1] = v; }
+                // Signed along the MARCH — its direction (cos ϕ, sin ϕ) is fetched here, in the cold path: a record that begins BEHIND the
+                // exit point before it (cells that overlap within the locate's tolerance) adds its overlap to Σℓ instead of leaving a
+                // gap; and a record whose own two points are in the wrong order — order_intersection_points compares x coordinates,
+                // src/intersection.jl:151-159, which near ϕ = π/2 are equal to the last bit — walks BACKWARDS: the chain loses its length
+                // twice.  (Records that take p from the record before are never reversed: the walk step's certificate 6.)
+                if (a.tally && (gap0 || gap1)) {
+                    const int32_t ug = t.perm[slot0 + (gap0 ? t0 : t1)];
+                    const int32_t uh = t.perm[slot0 + (gap1 ? t1 : t0)];
+                    const double d0x = t.cs[ug], d0y = t.sn[ug], d1x = t.cs[uh], d1y = t.sn[uh];
+                    __builtin_amdgcn_s_waitcnt(kWaitVm0);  // (waited for here, not at the join with the hot path)
+                    if (gap0) {
+                        const double g = norm2(p0x - b0x, p0y - b0y);
+                        double acc = (p0x - b0x) * d0x + (p0y - b0y) * d0y < 0.0 ? -g : g;
+                        if ((q0x - p0x) * d0x + (q0y - p0y) * d0y < 0.0) acc -= 2.0 * l0;
+                        atomicAdd(&s_gap[t0], acc);
+                        if ((-w0 - 1) & kWordLast) { lin_d2 v; v.x = q0x; v.y = q0y; s_qlast[t0] = v; }  // ... and the chain's end, if it is the last record
+                    }
+                    if (gap1) {
+                        const double g = norm2(p1x - b1x, p1y - b1y);
+                        double acc = (p1x - b1x) * d1x + (p1y - b1y) * d1y < 0.0 ? -g : g;
+                        if ((q1x - p1x) * d1x + (q1y - p1y) * d1y < 0.0) acc -= 2.0 * l1;
+                        atomicAdd(&s_gap[t1], acc);
+                        if ((-w1 - 1) & kWordLast) { lin_d2 v; v.x = q1x; v.y = q1y; s_qlast[t1] = v; }
+                    }
                 }
             }
             const int32_t oa = g0 + 2 * m, ob = g1 + 2 * m + 1;

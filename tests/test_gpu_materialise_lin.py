@@ -121,12 +121,14 @@ def test_tracks_longer_than_a_round(rt, orc):
     print(f"longest track {counts.max()} records, {int((counts > 256).sum())} of {len(counts)} tracks beyond one round")
 
 
-@pytest.mark.parametrize("seed", [520017, 520021, 520332, 520050, 520139, 520159, 520479])
+@pytest.mark.parametrize("seed", [520017, 520021, 520332, 520050, 520139, 520159, 520479, 520979])
 def test_fuzz_cases_that_found_the_chain_errors(rt, orc, seed):
     """Cases of tools/fuzz_many.py (round 5, seeds 520000 ...) on which the first version of the Σℓ chain failed.  (i) Tracks of
     258-344 records whose second round begins with a generic step's record: the gap in front of it is measured from the LAST ROW OF
     THE ROUND BEFORE (kept in LDS), not from the slot before it.  (ii) `steep` tracks (hand-made, within 1e-5 ... 1e-8 of ϕ = π/2):
-    records that begin BEHIND the exit point before them — the gap is signed, an overlap adds to Σℓ.  Forced and gated cheap
+    records that begin BEHIND the exit point before them — the gap is signed along the march, an overlap adds to Σℓ — and (seed
+    520979) a generic step's record whose own two points are in the wrong order (order_intersection_points compares x coordinates,
+    equal to the last bit near π/2): it walks backwards, the chain loses its length twice.  Forced and gated cheap
     steps; status, records and volumes against the oracle."""
     import os
     import sys

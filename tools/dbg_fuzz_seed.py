@@ -38,7 +38,14 @@ for mk in (1, 0):
         for u in bs[:6]:
             a, b = off[u], off[u + 1]
             print("      kernel S", seg["ell"][a], "qlast", seg["px"][a], seg["py"][a], "true qlast", ref["qx"][b - 1], ref["qy"][b - 1], "gap", seg["qx"][a], "q0x", seg["qy"][a], ref["qx"][a],
-                  "expected S", ref["ell"][a] + np.hypot(ref["qx"][a] - ref["qx"][b - 1], ref["qy"][a] - ref["qy"][b - 1]), "last rows elements", ref["element"][b-4:b])
+                  "chain", ref["ell"][a] + np.hypot(ref["qx"][a] - ref["qx"][b - 1], ref["qy"][a] - ref["qy"][b - 1]), "true sum", ref["ell"][a:b].sum(), "own-p rows", np.nonzero((ref["px"][a+1:b] != ref["qx"][a:b-1]) | (ref["py"][a+1:b] != ref["qy"][a:b-1]))[0][:12] + 1, "phi", tg.phi[u])
+    if os.environ.get("DBG_S") and mk == 0:
+        for u in bs[:2]:
+            a, b = off[u], off[u + 1]
+            rows = np.nonzero((ref["px"][a+1:b] != ref["qx"][a:b-1]) | (ref["py"][a+1:b] != ref["qy"][a:b-1]))[0] + 1
+            for r in rows[:6]:
+                i = a + r
+                print("         row", r, "prev q", repr(ref["qx"][i-1]), repr(ref["qy"][i-1]), "p", repr(ref["px"][i]), repr(ref["py"][i]), "q", repr(ref["qx"][i]), repr(ref["qy"][i]), "ell", ref["ell"][i], "el", ref["element"][i-1], ref["element"][i])
     bv = np.nonzero(np.abs(v - vol) > 1e-10 * np.abs(vol))[0]
     if len(bv): print("   volumes off at cells", bv[:8], v[bv[:4]], vol[bv[:4]])
     dt.close(); dm.close()
