@@ -120,7 +120,7 @@ struct DTracks {
     int64_t n;
     // in MARCH-SLOT order, for k_materialise (one level of dependent loads less than through perm): the track lines, the record
     // counts (written by the whole-track march beside counts[uid]) and the CSR offsets (k_scan_write, through iperm: uid -> slot)
-    const RT_G double *As, *Bs, *Cs, *Ls;  // (Ls: the tracks' lengths ℓ)
+    const RT_G double *As, *Bs, *Cs, *Ls, *Dxs, *Dys;  // (Ls: the tracks' lengths ℓ; Dxs, Dys: cos ϕ, sin ϕ)
     const RT_G int32_t *iperm;
     RT_G int32_t *cnt_slot;
     RT_G int64_t *off_slot;

@@ -52,14 +52,13 @@ static_assert(kLinRows % kChunkRows == 0 && kLinRows / kChunkRows == 8, "a wave 
 struct __attribute__((aligned(16))) LinTrack {
     double g0[4];          // A, B, C of the track's line; its length ℓ
     double g1[4];          // δs of its azimuthal angle; the first record's p (x, y) and q.x — the track's reserved side-list entry
-    double q0y;            // ... and q.y
+    double g2[4];          // ... and q.y; the march's direction cos ϕ, sin ϕ (the signs of the Σℓ chain's corrections); unused
     int64_t goff;          // record index in the result arrays = goff + linear slot (this round)
     double cx[2], cy[2];   // exit point of the last row of the previous round (rounds alternate)
     int32_t el0;           // cell + 1 of the first record
     int32_t lb;            // linear slot of the track's first row of this round
-    int64_t pad_;
 };
-static_assert(sizeof(LinTrack) == 128, "LinTrack layout");
+static_assert(sizeof(LinTrack) == 144, "LinTrack layout");
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_f64(double old, double v) {
@@ -191,10 +190,12 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         const int64_t ss = sc < side_last ? sc : side_last;
         const RT_G double *pg0 = rr == 0 ? t.As : (rr == 1 ? t.Bs : (rr == 2 ? t.Cs : t.Ls));
         const RT_G double *pg1 = rr == 0 ? (const RT_G double *)t.w_slot : (rr == 1 ? (const RT_G double *)stg.s_px : (rr == 2 ? (const RT_G double *)stg.s_py : (const RT_G double *)stg.s_qx));
-        const double tb0 = pg0[sc], tb1 = pg1[rr == 0 ? sc : ss];
+        const RT_G double *pg2 = rr == 0 ? (const RT_G double *)stg.s_qy : (rr == 1 ? t.Dxs : t.Dys);
+        const double tb0 = pg0[sc], tb1 = pg1[rr == 0 ? sc : ss], tb2 = pg2[rr == 0 ? ss : sc];
         s_trk[tl].g0[rr] = tb0;
         s_trk[tl].g1[rr] = tb1;
-        if (lane < 16) { s_trk[tl].q0y = stg.s_qy[ss]; s_trk[tl].el0 = stg.s_el[ss]; s_gap[tl] = 0.0; }
+        s_trk[tl].g2[rr] = tb2;
+        if (lane < 16) { s_trk[tl].el0 = stg.s_el[ss]; s_gap[tl] = 0.0; }
     }
     int32_t gmax = cnt;
     for (int o = 8; o > 0; o >>= 1) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             edge_exit_point(s_trk[tp].g0[0], s_trk[tp].g0[1], s_trk[tp].g0[2], epA, epB, epC, carry_x, carry_y);
             if (__builtin_expect(wp < 0, 0)) {
                 const int64_t idx = (-(int64_t)wp - 1) & (kWordLast - 1);
-                if (idx == slot0 + tp) { carry_x = s_trk[tp].g1[3]; carry_y = s_trk[tp].q0y; }
+                if (idx == slot0 + tp) { carry_x = s_trk[tp].g1[3]; carry_y = s_trk[tp].g2[0]; }
                 else { carry_x = stg.s_qx[idx]; carry_y = stg.s_qy[idx]; __builtin_amdgcn_s_waitcnt(kWaitVm0); }
             }
         }
@@ -343,12 +344,12 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 const int32_t i0 = (-w0 - 1) & (kWordLast - 1), i1 = (-w1 - 1) & (kWordLast - 1);  // side-list entries (if w < 0)
                 if (w0 < 0) {
                     own0 = true;
-                    if ((int64_t)i0 == slot0 + t0) { q0x = s_trk[t0].g1[3]; q0y = s_trk[t0].q0y; o0x = s_trk[t0].g1[1]; o0y = s_trk[t0].g1[2]; cell0 = s_trk[t0].el0; }
+                    if ((int64_t)i0 == slot0 + t0) { q0x = s_trk[t0].g1[3]; q0y = s_trk[t0].g2[0]; o0x = s_trk[t0].g1[1]; o0y = s_trk[t0].g1[2]; cell0 = s_trk[t0].el0; }
                     else slow = true;
                 }
                 if (w1 < 0) {
                     own1 = true;
-                    if ((int64_t)i1 == slot0 + t1) { q1x = s_trk[t1].g1[3]; q1y = s_trk[t1].q0y; o1x = s_trk[t1].g1[1]; o1y = s_trk[t1].g1[2]; cell1 = s_trk[t1].el0; }
+                    if ((int64_t)i1 == slot0 + t1) { q1x = s_trk[t1].g1[3]; q1y = s_trk[t1].g2[0]; o1x = s_trk[t1].g1[1]; o1y = s_trk[t1].g1[2]; cell1 = s_trk[t1].el0; }
                     else slow = true;
                 }
                 if (__builtin_expect(slow, 0)) {
@@ -388,16 +389,13 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                     if (gap0 && 2 * m == s_trk[t0].lb) { b0x = s_trk[t0].cx[s & 1]; b0y = s_trk[t0].cy[s & 1]; }
                     if (gap1 && 2 * m + 1 == s_trk[t1].lb) { b1x = s_trk[t1].cx[s & 1]; b1y = s_trk[t1].cy[s & 1]; }
                 }
-                // Signed along the MARCH — its direction (cos ϕ, sin ϕ) is fetched here, in the cold path: a record that begins BEHIND the
+                // Signed along the MARCH (its direction cos ϕ, sin ϕ is in the table): a record that begins BEHIND the
                 // exit point before it (cells that overlap within the locate's tolerance) adds its overlap to Σℓ instead of leaving a
                 // gap; and a record whose own two points are in the wrong order — order_intersection_points compares x coordinates,
                 // src/intersection.jl:151-159, which near ϕ = π/2 are equal to the last bit — walks BACKWARDS: the chain loses its length
                 // twice.  (Records that take p from the record before are never reversed: the walk step's certificate 6.)
                 if (a.tally && (gap0 || gap1)) {
-                    const int32_t ug = t.perm[slot0 + (gap0 ? t0 : t1)];
-                    const int32_t uh = t.perm[slot0 + (gap1 ? t1 : t0)];
-                    const double d0x = t.cs[ug], d0y = t.sn[ug], d1x = t.cs[uh], d1y = t.sn[uh];
-                    __builtin_amdgcn_s_waitcnt(kWaitVm0);  // (waited for here, not at the join with the hot path)
+                    const double d0x = s_trk[t0].g2[1], d0y = s_trk[t0].g2[2], d1x = s_trk[t1].g2[1], d1y = s_trk[t1].g2[2];
                     if (gap0) {
                         const double g = norm2(p0x - b0x, p0y - b0y);
                         double acc = (p0x - b0x) * d0x + (p0y - b0y) * d0y < 0.0 ? -g : g;
@@ -537,10 +535,11 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         __syncthreads();
         if (threadIdx.x < 16 && have) {
             // Σℓ = first record + chain from its q to the last record's q − gaps (a track of one record: the first record alone)
-            const double fx = s_trk[tl].g1[1], fy = s_trk[tl].g1[2], gx = s_trk[tl].g1[3], gy = s_trk[tl].q0y;
+            const double fx = s_trk[tl].g1[1], fy = s_trk[tl].g1[2], gx = s_trk[tl].g1[3], gy = s_trk[tl].g2[0];
             const lin_d2 ql = s_qlast[tl];
+            // (the chain as a PROJECTION on the march direction: a last record that walks backwards may end behind the first one's q)
             double S = cnt > 0 ? norm2(fx - gx, fy - gy) : 0.0;
-            if (cnt > 1) S += norm2(gx - ql.x, gy - ql.y) - s_gap[tl];
+            if (cnt > 1) S += ((ql.x - gx) * s_trk[tl].g2[1] + (ql.y - gy) * s_trk[tl].g2[2]) - s_gap[tl];
             const double L = s_trk[tl].g0[3];
             // any-order sum against the left-to-right one: within cnt·2⁻⁵³·Σ; 96 bands hold the statistic's 64 (k_finish)
             if (a.force_exact || sum_check_is_marginal(L, S, a.rtol, cnt, 96.0)) {

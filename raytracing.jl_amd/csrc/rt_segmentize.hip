@@ -585,10 +585,10 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         const size_t na = (n + 31) & ~(size_t)31;  // every array starts on a 256-B boundary
         const size_t ncord = (h_corder.size() + 63) & ~(size_t)63;
         // the arena: what goes up — nine double arrays, azim_idx, the march order, the materialise order — and behind it what a small
-        // kernel derives on the device (the lines' coefficients in march-slot order, the inverse of the march order, the lengths: 36 B per track
+        // kernel derives on the device (the lines' coefficients in march-slot order, the inverse of the march order, the lengths, the directions: 52 B per track
         // that need not cross PCIe)
         const size_t up_bytes = 9 * na * sizeof(double) + 2 * na * sizeof(int32_t) + ncord * sizeof(int32_t);
-        const size_t bytes = up_bytes + 4 * na * sizeof(double) + na * sizeof(int32_t) + 256;
+        const size_t bytes = up_bytes + 6 * na * sizeof(double) + na * sizeof(int32_t) + 256;
         StagingBlock stage;
         const int slot = staging_acquire(&stage, mesh->device);
         // (a failed upload may leave a copy out of the block in flight: the stream is drained before the block goes back to the pool)
@@ -603,7 +603,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             t->azim.p = (int32_t *)(db + ints_off); t->perm.p = t->azim.p + na;
             t->corder.p = h_corder.empty() ? nullptr : t->perm.p + na;
             t->As.p = (double *)(db + up_bytes); t->Bs.p = t->As.p + na; t->Cs.p = t->Bs.p + na; t->Ls.p = t->Cs.p + na;
-            t->iperm.p = (int32_t *)(t->Ls.p + na);
+            t->Dxs.p = t->Ls.p + na; t->Dys.p = t->Dxs.p + na;
+            t->iperm.p = (int32_t *)(t->Dys.p + na);
         }
         cstamp[2] = cnow();
         if (ok && n > 0) {
@@ -646,7 +647,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                 if (ok && !h_corder.empty())
                     ok = hipMemcpyAsync(t->corder.p, h_corder.data(), h_corder.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess;
             }
-            if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->ell.p, t->As.p, t->Bs.p, t->Cs.p, t->Ls.p, t->iperm.p);
+            if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->ell.p, t->cs.p, t->sn.p, t->As.p, t->Bs.p, t->Cs.p, t->Ls.p, t->Dxs.p, t->Dys.p, t->iperm.p);
             ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
             cstamp[4] = cnow();
         }
@@ -674,7 +675,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     d.px = as_global(t->px.p); d.py = as_global(t->py.p); d.phi = as_global(t->phi.p); d.cs = as_global(t->cs.p);
     d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
     d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
-    d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.Ls = as_global(t->Ls.p); d.iperm = as_global(t->iperm.p);
+    d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.Ls = as_global(t->Ls.p); d.Dxs = as_global(t->Dxs.p); d.Dys = as_global(t->Dys.p); d.iperm = as_global(t->iperm.p);
     d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p); d.w_slot = as_global(t->w_slot.p);
     d.n = n_tracks;
     guard.p = nullptr;

@@ -179,14 +179,15 @@ def test_record_limit_switches_walk_off(rt, pincell, monkeypatch):
 def test_host_code_under_sanitizers(tmp_path):
     """csrc/rt_host.cpp, csrc/rt_mesh_prep.hpp, the device geometry header on the host and the checker under
     AddressSanitizer + UBSan over fixtures, seeded fuzz meshes (degenerate cell, non-manifold edge included) and
-    malformed mesh files (tests/sanitize/run.sh; the 200-mesh log is kept as profiles/r02/host_sanitizers.log)."""
+    malformed mesh files; the host threading of rt_tracks_create and of the pipelined fetch (csrc/rt_hostpar.hpp) under ASan + UBSan and
+    under ThreadSanitizer (tests/sanitize/run.sh; the 200-mesh log is kept as profiles/r05/host_sanitizers.log)."""
     import subprocess
 
     log = tmp_path / "san.log"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["bash", os.path.join(root, "tests", "sanitize", "run.sh"), "15", str(log)], stdout=subprocess.DEVNULL)
     text = log.read_text()
-    assert text.count("exit code: 0") == 2 and "ERROR" not in text and "runtime error" not in text, text[-2000:]
+    assert text.count("exit code: 0") == 4 and "WARNING: ThreadSanitizer" not in text and "ERROR" not in text and "runtime error" not in text, text[-2000:]
     assert "12 refused" in text and "exact walk steps == walk off == cheap steps == checker: yes" in text
 
 
