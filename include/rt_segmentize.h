@@ -380,7 +380,7 @@ void rt_msh_free(rt_msh *msh);
  *   "walk"     0: literal step only (find_element + intersections every iteration)
  *   "iter_cap" guard on the reference's unbounded `continue` paths (default 4,000,000 iterations per track)
  *   "split"    (read by rt_tracks_create) 0: never march track pieces; L > 0: pieces of about L records; default −1: pieces for
- *                 batches that do not fill the chip (< 1,536 march waves)
+ *                 batches far below the chip's capacity (< 160 march waves; above that the two-phase march of whole tracks is faster)
  * Development and test knobs ("march_waves", "pool_chunks_hint", "side_entries_hint", "test_*", "sweep_*", "sort_mode") are
  * listed in DESIGN.md / tools/README.md; "single_pass" and "volumes_mode" exist only in a library built with -DRT_EXPERIMENTAL. */
 int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value);

@@ -548,12 +548,14 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     }
     // split plan: pieces per wave of 64 consecutive uids, canonical numbering, dispatch order
     std::vector<int32_t> h_vorder, h_vw_wave, h_vw_k, h_w_base, h_w_P;
-    // Splitting pays when the batch has too few waves to fill the chip (the march is then bound by its
-    // longest dependent chain: -36 % at 6.5 k tracks, -50 % at 420).  On a batch whose waves are all resident
-    // anyway the split variant of the march plus its seed and resolve kernels costs more than shorter
-    // chains win back (+17 % march time at 130 k tracks even with one piece per track).
+    // Splitting pays when the batch has far too few waves to fill the chip (the march is then bound by its
+    // longest dependent chain).  Pieces march with exact steps (k_march<SPLIT>), whole tracks with the two-phase march's cheap
+    // steps since round 4 — and against THAT march the pieces win only below ≈150 waves (same box, ms per call whole / in pieces,
+    // profiles/r05/exp_split_threshold.log: 7 waves 0.127 / 0.116, 26 waves 0.184 / 0.131, 103 waves (C2) 0.181 / 0.160;
+    // 204 waves 0.167 / 0.218, 510 waves 0.161 / 0.272, 1,019 waves — C3 on two GPUs — 0.199 / 0.310, 1,530 waves 0.259 / 0.448).
+    // Rounds 2-4 split every batch below 1,536 waves, a rule measured against the exact-step march of round 2.
     const size_t nw_all = (n + 63) / 64;
-    const bool auto_split = mesh->split < 0 && nw_all < 1536;
+    const bool auto_split = mesh->split < 0 && nw_all < 160;
     const int p_auto = auto_split ? (int)std::min<size_t>(16, (2048 + nw_all - 1) / std::max<size_t>(1, nw_all)) : 1;
     if ((mesh->split > 0 || (auto_split && p_auto > 1)) && n > 0) {
         const size_t nw = (n + 63) / 64;
