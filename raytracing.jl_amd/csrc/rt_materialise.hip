@@ -67,16 +67,6 @@ __device__ __forceinline__ double dpp_f64(double old, double v) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xf, false);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
-// Sum over the wave, valid in lane 63 (row_shr 1, 2, 4, 8 = inclusive scan of every row of 16; row_bcast 15 / 31 carry the rows' sums up)
-__device__ __forceinline__ double wave_sum_lane63(double x) {
-    x += dpp_f64<0x111, 0xf>(0.0, x);
-    x += dpp_f64<0x112, 0xf>(0.0, x);
-    x += dpp_f64<0x114, 0xf>(0.0, x);
-    x += dpp_f64<0x118, 0xf>(0.0, x);
-    x += dpp_f64<0x142, 0xa>(0.0, x);
-    x += dpp_f64<0x143, 0xc>(0.0, x);
-    return x;
-}
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const uint64_t b = __builtin_bit_cast(uint64_t, v);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
@@ -289,11 +279,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 p.t0 = p.w0 != 0 ? (int32_t)(tt & 15u) : 0;
                 p.t1 = p.w1 != 0 ? (int32_t)((tt >> 8) & 15u) : 0;
             }
-#ifdef RT_LIN_PROBE_GATHER0
-            const uint32_t o0 = (uint32_t)(p.w0 > 0 ? 1 : 0) << 5, o1 = (uint32_t)(p.w1 > 0 ? 2 : 0) << 5;  // (probe: every gather hits the same two entries; results void)
-#else
             const uint32_t o0 = (uint32_t)(p.w0 > 0 ? (p.w0 & kWordCode) - 1 : 0) << 5, o1 = (uint32_t)(p.w1 > 0 ? (p.w1 & kWordCode) - 1 : 0) << 5;
-#endif
             const lin_d2 ab0 = __builtin_bit_cast(lin_d2, __builtin_amdgcn_raw_buffer_load_b128(r_etab, o0, 0, 0));
             const lin_d2 ab1 = __builtin_bit_cast(lin_d2, __builtin_amdgcn_raw_buffer_load_b128(r_etab, o1, 0, 0));
             p.e0A = ab0.x; p.e0B = ab0.y; p.e0C = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_etab, o0 + 16u, 0, 0));
@@ -527,11 +513,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         }
     }
 #endif
-#ifdef RT_LIN_PROBE_GATHER0
-    if (false) {
-#else
     if (a.tally) {
-#endif
         __syncthreads();
         if (threadIdx.x < 16 && have) {
             // Σℓ = first record + chain from its q to the last record's q − gaps (a track of one record: the first record alone)

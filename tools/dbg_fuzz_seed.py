@@ -34,12 +34,7 @@ for mk in (1, 0):
         ell = ref["ell"][a:b]
         print("   uid", u, "cnt", cnt[u], "status", st[u], "ref", ref["status"][u], "L", tg.ell[u], "sum", ell.sum(), "L-sum", tg.ell[u] - ell.sum(),
               "chain ok", bool(np.array_equal(ref["px"][a + 1:b], ref["qx"][a:b - 1]) and np.array_equal(ref["py"][a + 1:b], ref["qy"][a:b - 1])))
-    if os.environ.get("DBG_S") and mk == 0:
-        for u in bs[:6]:
-            a, b = off[u], off[u + 1]
-            print("      kernel S", seg["ell"][a], "qlast", seg["px"][a], seg["py"][a], "true qlast", ref["qx"][b - 1], ref["qy"][b - 1], "gap", seg["qx"][a], "q0x", seg["qy"][a], ref["qx"][a],
-                  "chain", ref["ell"][a] + np.hypot(ref["qx"][a] - ref["qx"][b - 1], ref["qy"][a] - ref["qy"][b - 1]), "true sum", ref["ell"][a:b].sum(), "own-p rows", np.nonzero((ref["px"][a+1:b] != ref["qx"][a:b-1]) | (ref["py"][a+1:b] != ref["qy"][a:b-1]))[0][:12] + 1, "phi", tg.phi[u])
-    if os.environ.get("DBG_S") and mk == 0:
+    if mk == 0:  # (the records that keep their own p: the gaps of k_materialise_lin's Σℓ chain)
         for u in bs[:2]:
             a, b = off[u], off[u + 1]
             rows = np.nonzero((ref["px"][a+1:b] != ref["qx"][a:b-1]) | (ref["py"][a+1:b] != ref["qy"][a:b-1]))[0] + 1
