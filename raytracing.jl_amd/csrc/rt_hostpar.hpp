@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <functional>
@@ -231,26 +232,16 @@ inline void pack_tracks_image(unsigned char *hb, size_t stride, size_t i0, size_
     });
 }
 
-// The caller's (often freshly allocated) destination range is made resident before a piece is copied into it — while that piece is
-// still in flight from the device: transparent huge pages are asked for where the range covers whole ones (512 times fewer
-// faults), then the pages are populated in one call per thread (Linux >= 5.14; where either is unknown the copy takes the faults as
-// before).  Best effort: every error is ignored.
-inline void prefault_range(char *dst, size_t bytes) {
-#if defined(__linux__)
+// The destination of a fetched piece — usually arrays the caller has just allocated — is asked for as transparent huge pages
+// before the host copies into it (512 times fewer faults; a no-op where the allocator has asked already, as numpy does; Julia's and
+// malloc's large blocks have not).  Measured on 410 MB into fresh arrays (profiles/r05/exp_fetch_fresh_modes.log): 9.5-9.6 ms with the
+// hint against 18-24 ms with 4-KB pages.  Populating the pages ahead of the copy (MADV_POPULATE_WRITE by the worker team, round 5's
+// first version) was SLOWER than letting the copy take the faults: 11-18 ms.  Best effort: errors are ignored.
+inline void hint_huge_pages(char *dst, size_t bytes) {
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
     const uintptr_t page = 4096;
     const uintptr_t a = ((uintptr_t)dst + page - 1) & ~(page - 1), b = ((uintptr_t)dst + bytes) & ~(page - 1);
-    if (b <= a) return;
-#ifdef MADV_HUGEPAGE
-    (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
-#endif
-#ifndef MADV_POPULATE_WRITE
-#define RT_MADV_POPULATE_WRITE 23
-#else
-#define RT_MADV_POPULATE_WRITE MADV_POPULATE_WRITE
-#endif
-    par_ranges((size_t)((b - a) / page), 512, [&](size_t p0, size_t p1) {
-        if (p1 > p0) (void)madvise((void *)(a + p0 * page), (p1 - p0) * page, RT_MADV_POPULATE_WRITE);
-    });
+    if (b > a) (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
 #else
     (void)dst; (void)bytes;
 #endif

@@ -289,7 +289,7 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
         return RT_SUCCESS;
     }
     const size_t half = kStageBytes / 2;
-    static const bool prefault = getenv("RT_FETCH_NO_PREFAULT") == nullptr;  // (development: A/B of the destination's pre-fault)
+    static const bool huge_hint = getenv("RT_FETCH_NO_HUGEPAGE_HINT") == nullptr;  // (development: A/B)
     struct Piece { char *d; size_t bytes; int h; };
     Piece prev{nullptr, 0, 0};
     auto drain = [&](const Piece &pc) -> int {  // the piece has arrived in its half: into place
@@ -308,7 +308,7 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
             // (half h was drained two pieces ago: `prev` is the piece in the OTHER half)
             RT_HIP(hipMemcpyAsync((char *)stage.p + (size_t)h * half, (const char *)src[a] + o, nbp, hipMemcpyDeviceToHost, s));
             RT_HIP(hipEventRecord(stage.ev[h], s));
-            if (prefault) rthostpar::prefault_range((char *)dst[a] + o, nbp);  // (while the piece is in flight)
+            if (huge_hint) rthostpar::hint_huge_pages((char *)dst[a] + o, nbp);  // (while the piece is in flight)
             if (int rc = drain(prev)) return rc;
             prev = Piece{(char *)dst[a] + o, nbp, h};
         }

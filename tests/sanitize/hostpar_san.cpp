@@ -178,7 +178,7 @@ static void test_fetch(size_t bytes, size_t block_bytes, std::mt19937 &rng) {
         { std::lock_guard<std::mutex> lk(mu); queue.push_back(Req{o, nb, h}); ++asked[h]; }
         cv.notify_all();
         const int seq = asked[h];
-        prefault_range((char *)dst + o, nb);  // (the destination of the piece in flight, as fetch_pipelined does)
+        hint_huge_pages((char *)dst + o, nb);  // (the destination of the piece in flight, as fetch_pipelined does)
         drain(prev);  // (half h was drained two pieces ago: `prev` is the piece in the OTHER half)
         prev = Piece{dst + o, nb, h, seq};
     }
