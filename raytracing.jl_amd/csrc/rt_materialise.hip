@@ -308,7 +308,11 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 n_flag = 0;
             }
         };
+#ifdef RT_LIN_LEAN
+        auto process = [&](Pre &pre, const int mb) {
+#else
         auto process = [&](const Pre &pre, const int mb) {
+#endif
             const int m = mb + lane;
             const int32_t w0 = pre.w0, w1 = pre.w1;
             const int t0 = pre.t0, t1 = pre.t1;
@@ -400,6 +404,11 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             }
             const int32_t oa = g0 + 2 * m, ob = g1 + 2 * m + 1;
             const bool v0 = w0 != 0 && oa < cap32 && !nostore, v1 = w1 != 0 && ob < cap32 && !nostore;
+#ifdef RT_LIN_LEAN
+            // (lean variant: ONE register set — the next pairs' words and gathers are fetched here, behind the last use of this
+            //  iteration's and in front of its stores: fewer registers for more waves per SIMD, the gathers' latency is the other waves')
+            pre = prefetch(mb + 64 + lane);
+#endif
             {
                 // Whole pairs: one 16-B store per f64 array, 8 B of cell ids.  BUFFER stores: a lane without a whole pair hands in an
                 // offset beyond the array and the hardware drops its store — the six stores are unconditional instructions, so the
@@ -485,6 +494,9 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             __builtin_amdgcn_raw_buffer_store_b64(z2, r_el, 0xffffffffu, 0, 0);
         }
         LIN_STAMP(5);
+#ifdef RT_LIN_LEAN
+        for (int mb = m0; mb < m1; mb += 64) process(cur, mb);
+#else
         for (int mb = m0; mb < m1; mb += 128) {
             const Pre nxt = prefetch(mb + 64 + lane);
             process(cur, mb);
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             cur = prefetch(mb + 128 + lane);
             process(nxt, mb + 64);
         }
+#endif
         LIN_STAMP(6);
         // ---- the wave's epilogue: half pairs, marked records' fill_volumes terms
         if (__builtin_expect(n_half != 0, 0)) {
