@@ -117,7 +117,7 @@ inline void plan_march_order(const double *ell, size_t n, int sort_mode, double 
     if (sort_mode == 1) {
         std::iota(perm.begin(), perm.end(), 0);
         std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ell[a] > ell[b]; });
-    } else if (sort_mode >= 2) {
+    } else if (sort_mode == 2) {
         const size_t nw = (n + 63) / 64;
         std::vector<double> wmax(nw, 0.0);
         par_ranges(nw, 512, [&](size_t w0, size_t w1) {
@@ -133,32 +133,6 @@ inline void plan_march_order(const double *ell, size_t n, int sort_mode, double 
         std::stable_sort(wkey.begin(), wkey.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
         std::vector<int32_t> worder(nw);
         for (size_t w = 0; w < nw; ++w) worder[w] = wkey[w].second;
-        if (sort_mode >= 3 && nw > 8) {
-            // (experiments: which workgroups — 4 waves — share a CU when the batch is resident at once.  3: the longer half longest
-            //  first, then the shorter half SHORTEST first; 4: long and short alternate; 5: as 3 in blocks of 8 workgroups, one per XCD)
-            const size_t ng = (nw + 3) / 4, half = (ng + 1) / 2;
-            std::vector<size_t> gorder;
-            gorder.reserve(ng);
-            if (sort_mode == 3) {
-                for (size_t g = 0; g < half; ++g) gorder.push_back(g);
-                for (size_t g = ng; g-- > half;) gorder.push_back(g);
-            } else if (sort_mode == 4) {
-                for (size_t g = 0; g < half; ++g) { gorder.push_back(g); if (ng - 1 - g >= half) gorder.push_back(ng - 1 - g); }
-            } else {
-                for (size_t g = 0; g < half; ++g) gorder.push_back(g);
-                // second half: blocks of 8 in ascending length, each block kept in its order
-                std::vector<size_t> rest;
-                for (size_t g = half; g < ng; ++g) rest.push_back(g);
-                const size_t nb = (rest.size() + 7) / 8;
-                for (size_t b = nb; b-- > 0;)
-                    for (size_t k = b * 8; k < std::min(rest.size(), b * 8 + 8); ++k) gorder.push_back(rest[k]);
-            }
-            std::vector<int32_t> wo2;
-            wo2.reserve(nw);
-            for (const size_t g : gorder)
-                for (size_t w = 4 * g; w < std::min(nw, 4 * g + 4); ++w) wo2.push_back(worder[w]);
-            worder.swap(wo2);
-        }
         // the batch's last wave of uids may be partial: the slots behind it are packed (no padding), so its position shifts them
         std::vector<size_t> first(nw + 1, 0);
         for (size_t w = 0; w < nw; ++w) first[w + 1] = first[w] + std::min<size_t>(64, n - (size_t)worder[w] * 64);
