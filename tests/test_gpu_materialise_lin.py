@@ -176,3 +176,22 @@ def test_length_check_by_first_and_last_point(rt, orc, traced, rtol):
     assert np.array_equal(new["status"], ref["status"]) and np.array_equal(old["status"], ref["status"])
     for k in FIELDS:
         assert np.array_equal(new[k], ref[k]), k
+
+
+@pytest.mark.parametrize("n_azim,delta,pieces", [(32, 5e-3, True), (64, 5e-3, False), (32, 1e-3, False)])
+def test_default_plan_by_batch_size(rt, orc, traced, n_azim, delta, pieces):
+    """Which march a call takes with DEFAULT options (round 5, profiles/r05/exp_split_threshold.log): below 160 march waves the tracks
+    are marched in pieces (exact steps, k_compact3), from there on whole with the two-phase march (k_materialise_lin) — 103 waves (C2),
+    204 waves and 511 waves (a shard of C3 on four GPUs) here; records, offsets and status against the oracle in either regime."""
+    tg = traced(n_azim, delta)
+    n_waves = (len(tg.px) + 63) // 64
+    assert (n_waves < 160) == pieces, n_waves
+    ref = _oracle(orc, tg)
+    new = _run(rt, tg, {})
+    st = new["stats"]
+    assert (st["split"] == 1) == pieces, st
+    assert (st["cheap_records"] > 0) == (not pieces), st
+    assert new["total"] == ref["total"] and np.array_equal(new["offsets"], ref["offsets"]) and np.array_equal(new["status"], ref["status"])
+    for k in FIELDS:
+        assert np.array_equal(new[k], ref[k]), k
+    np.testing.assert_allclose(new["volumes"], ref["volumes"], rtol=1e-10, atol=0)
