@@ -47,13 +47,22 @@ se = (hw >> np.uint64(13)) & np.uint64(7)
 xcc = xcc.astype(np.int64)
 place = ((((xcc * 8 + se.astype(np.int64)) * 2 + sh.astype(np.int64)) * 16 + cu.astype(np.int64)) * 4 + simd.astype(np.int64))
 start = np.zeros(nw, dtype=np.int64)
-for x in range(8):  # (every XCD has its own counter)
-    sel = ok & (xcc == x)
+# (every XCD has its own counter, and the XCC_ID field does not separate them on every box: cluster the raw stamps instead —
+#  counters of different XCDs are millions of cycles apart, a kernel lasts a few hundred thousand)
+order_t = np.argsort(tstart)
+cl = np.zeros(nw, dtype=np.int64)
+c = 0
+for a_, b_ in zip(order_t[:-1], order_t[1:]):
+    if tstart[b_] - tstart[a_] > 2_000_000: c += 1
+    cl[b_] = c
+for x in range(c + 1):
+    sel = ok & (cl == x)
     if sel.any():
         start[sel] = tstart[sel] - tstart[sel].min()
+print(f"{c + 1} counter clusters (XCDs)")
 end = start + dur
 print(f"{ok.sum()} waves (march order: longest first); cycles; kernel span (per-XCD clocks, start of the XCD's first wave = 0) {end[ok].max()}")
-print("start stamps: percentiles 0/50/90/99/100:", np.percentile(start[ok], [0, 50, 90, 99, 100]).astype(int))
+print("start stamps: percentiles 0/10/25/50/75/90/99/100:", np.percentile(start[ok], [0, 10, 25, 50, 75, 90, 99, 100]).astype(int))
 print("end stamps:   percentiles 0/50/90/99/100:", np.percentile(end[ok], [0, 50, 90, 99, 100]).astype(int))
 cuid = place // 4
 print("wave  start    end    dur   place(cu,simd)  same-SIMD partners (wave,start,end) | waves on the CU")
