@@ -117,6 +117,13 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     __shared__ double s_fval[4][kLinFlagCap];    // per wave: fill_volumes terms of marked records (value, cell) for the epilogue
     __shared__ int32_t s_fcell[4][kLinFlagCap];
     if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
+    // A workgroup's header phase (first trip to memory, run groups, transposition, up to the barrier behind it) issues with priority
+    // over the other workgroups' store loops: its few instructions no longer queue behind four waves of FP64 work per SIMD, its
+    // loads leave sooner and the unit reaches its own loop sooner — record kernel −4 % at C3, −6.5 % at C4, −5 % at C5, same box
+    // (profiles/r05/exp_issue_priority.log; priority kept until the loop or until behind the first gathers: 1-2 % less; the march
+    // does not respond to priorities).  A/B: option "compact_debug" 8 switches it off.
+    const bool hprio = !(out.dbg & 8);
+    if (hprio) __builtin_amdgcn_s_setprio(3);
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (kw in a scalar register: uniform loops)
     const int tl = lane & 15, rr = lane >> 4;  // transposition: track tl, rows 4 i + rr of a chunk
 #ifdef RT_LIN_TIMING
@@ -198,7 +205,10 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     const bool many_rounds = nrounds > 1;
     for (int s = 0; s < nrounds; ++s) {
         const int r0 = s * kLinRows;
-        if (s > 0) __syncthreads();  // the previous round's linear phase has read its slots
+        if (s > 0) {
+            __syncthreads();  // the previous round's linear phase has read its slots
+            if (hprio) __builtin_amdgcn_s_setprio(3);
+        }
         // ---- the round's words: wave kw takes chunks 8 s + kw and 8 s + kw + 4 (lane = track tl, rows 4 i + rr)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         LIN_STAMP(3);
         __syncthreads();
         LIN_STAMP(4);
+        if (hprio) __builtin_amdgcn_s_setprio(0);
         // ---- the linear phase: wave kw takes pairs [m0, m1) (a multiple of 8 pairs = whole cache lines of the f64 arrays)
         const int P = Lp >> 1;
         const int nit = (P + 63) >> 6;  // iterations of 64 pairs, dealt whole: wave kw takes [nit kw / 4, nit (kw + 1) / 4)
