@@ -181,18 +181,24 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             for (int i = 0; i < 8; ++i) ve[c2][i] = 0;
         }
     }
-    if (kw == 0) {
+    {
+        // (one wave-load per wave: a wave that took all three waited for them — and, the counter being in order, for its words —
+        //  before it could begin with the run groups, and the other three waited for it at the barrier)
         const int64_t sc = have ? slot : t.n - 1;
         const int64_t side_last = stg.side_cap > 0 ? stg.side_cap - 1 : 0;
         const int64_t ss = sc < side_last ? sc : side_last;
-        const RT_G double *pg0 = rr == 0 ? t.As : (rr == 1 ? t.Bs : (rr == 2 ? t.Cs : t.Ls));
-        const RT_G double *pg1 = rr == 0 ? (const RT_G double *)t.w_slot : (rr == 1 ? (const RT_G double *)stg.s_px : (rr == 2 ? (const RT_G double *)stg.s_py : (const RT_G double *)stg.s_qx));
-        const RT_G double *pg2 = rr == 0 ? (const RT_G double *)stg.s_qy : (rr == 1 ? t.Dxs : t.Dys);
-        const double tb0 = pg0[sc], tb1 = pg1[rr == 0 ? sc : ss], tb2 = pg2[rr == 0 ? ss : sc];
-        s_trk[tl].g0[rr] = tb0;
-        s_trk[tl].g1[rr] = tb1;
-        s_trk[tl].g2[rr] = tb2;
-        if (lane < 16) { s_trk[tl].el0 = stg.s_el[ss]; s_gap[tl] = 0.0; }
+        if (kw == 0) {
+            const RT_G double *pg0 = rr == 0 ? t.As : (rr == 1 ? t.Bs : (rr == 2 ? t.Cs : t.Ls));
+            s_trk[tl].g0[rr] = pg0[sc];
+        } else if (kw == 1) {
+            const RT_G double *pg1 = rr == 0 ? (const RT_G double *)t.w_slot : (rr == 1 ? (const RT_G double *)stg.s_px : (rr == 2 ? (const RT_G double *)stg.s_py : (const RT_G double *)stg.s_qx));
+            s_trk[tl].g1[rr] = pg1[rr == 0 ? sc : ss];
+        } else if (kw == 2) {
+            const RT_G double *pg2 = rr == 0 ? (const RT_G double *)stg.s_qy : (rr == 1 ? t.Dxs : t.Dys);
+            s_trk[tl].g2[rr] = pg2[rr == 0 ? ss : sc];
+        } else if (lane < 16) {
+            s_trk[tl].el0 = stg.s_el[ss]; s_gap[tl] = 0.0;
+        }
     }
     int32_t gmax = cnt;
     for (int o = 8; o > 0; o >>= 1) {
@@ -225,7 +231,21 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         cr = cr < 0 ? 0 : (cr > kLinRows ? kLinRows : cr);
         const int64_t o = off + r0;
         int32_t end = 0, my_lb = 0, my_gap = 0;
-        {
+        // The usual unit is ONE run group — sixteen tracks with records whose runs follow one another in memory: every track starts
+        // where the one before it ends (one DPP shift), and its first slot is its distance from the first track's.  (The general
+        // recurrence below is a chain of sixteen dependent scalar steps: 4,000 cycles of a workgroup's 30,000, in-kernel stamps.)
+        const uint32_t o_lo = (uint32_t)(uint64_t)o, o_hi = (uint32_t)((uint64_t)o >> 32);
+        const uint32_t po_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_lo, 0x111, 0xf, 0xf, false);  // row_shr:1 — track tl − 1's
+        const uint32_t po_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_hi, 0x111, 0xf, 0xf, false);
+        const int32_t pcr = __builtin_amdgcn_update_dpp(0, cr, 0x111, 0xf, 0xf, false);
+        const int64_t po = (int64_t)(((uint64_t)po_hi << 32) | po_lo);
+        const bool one_group = __ballot(cr > 0 && (tl == 0 || o == po + pcr)) == ~0ull;
+        if (one_group) {
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)o_lo, 0);
+            my_lb = (int32_t)(o0 & 15u) + (int32_t)(o_lo - o0);
+            my_gap = tl == 0 ? 0 : my_lb;
+            end = __builtin_amdgcn_readlane(my_lb + cr, 15);
+        } else {
             int64_t next_o = -1;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         }
         const int Lp = (end + 1) & ~1;
         LIN_STAMP(2);
-        if (threadIdx.x < 16) {
+        if (kw == 3 && lane < 16) {
             s_trk[tl].goff = o - my_lb;
             s_trk[tl].lb = my_lb;
             for (int k = my_gap; k < my_lb; ++k) s_meta[k] = 0;  // pads in front of a run group
