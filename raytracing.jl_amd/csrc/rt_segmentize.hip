@@ -699,447 +699,488 @@ static double g_ht[6];
 static long g_hn;
 static inline double ht_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #endif
-static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s,
-                      int32_t n_azim_2) {
-#ifdef RT_HOST_TIMING
-    const double ht0 = ht_now();
-#endif
-    if (!t || !delta_s || n_azim_2 <= 0) { set_error("rt_segmentize: bad arguments"); return RT_ERR_INVALID; }
-    if (k < 0) {  // knn(kdtree, x, k, ...) rejects a negative k (src/mesh.jl:123); any k >= 0 is honoured
-        set_error("rt_segmentize: k = %d (must be >= 0)", k);
-        return RT_ERR_INVALID;
-    }
-    if (t->n > 0 && t->azim_max > n_azim_2) {
-        set_error("rt_segmentize: track azim_idx reaches %d but delta_s has n_azim_2 = %d entries", t->azim_max, n_azim_2);
-        return RT_ERR_INVALID;
-    }
-    rt_mesh *m = t->mesh;
-    RT_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    const int64_t n = t->n;
-    t->segmentized = false;
-    t->tau_groups = 0;  // τ of the previous records is void
-    for (double &v : t->ms) v = 0.0;
 
-    rt::DParams prm;
-    prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
-    prm.topo_tiny_max = m->topo_tiny_max; prm.topo_rmax = m->topo_rmax; prm.topo_end_err = m->topo_end_err;
-    prm.topo_force = m->topo == 2 ? 1 : 0; prm.pad_ = 0;
-    {
-        // the chord of a cheap record is used for fill_volumes where its error bound a + b/D_x (rt_mesh_prep.hpp) is at most ε of the
-        // chord: ε/8 for a, 7ε/8 for b.  "test_tally_tau" (tests, A/B): ε in 1e-12; < 0: every cheap record is tallied from its length
-        const double eps = m->test_tally_tau > 0 ? 1e-12 * (double)m->test_tally_tau : 8e-11;
-        prm.tally_c1 = m->test_tally_tau < 0 ? (double)INFINITY : m->tally_a / (0.125 * eps);
-        prm.tally_c2 = m->test_tally_tau < 0 ? (double)INFINITY : m->tally_b / (0.875 * eps);
-    }
+namespace {
 
-    const int64_t n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
-    const int64_t n_waves = (n + 63) / 64;
-    RT_HIP(t->counts.reserve(n + 1));
-    RT_HIP(t->status.reserve(n + 1));
-    RT_HIP(t->offsets.reserve(n + 1));
-    RT_HIP(t->tile_sums.reserve(n_tiles + 1));
-    if (t->tile_acc_tiles != n_tiles + 1 || !t->tile_acc.p) {  // (two zeroed halves: k_march<TOPO> adds to one, the scan clears the other)
-        RT_HIP(t->tile_acc.reserve(2 * (size_t)(n_tiles + 1) * rt::kTileAccStride));
-        RT_HIP(hipMemsetAsync(t->tile_acc.p, 0, 2 * (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
-        t->tile_acc_tiles = n_tiles + 1;
-        t->tile_acc_clean[0] = t->tile_acc_clean[1] = true;
-    }
-    RT_HIP(t->ctl.reserve(2 * rt::kCtlWords));
-    RT_HIP(t->vacc.reserve(m->n_cells));
-    if (!t->h_ctl) {
-        RT_HIP(hipHostMalloc((void **)&t->h_ctl, (2 * rt::kCtlWords + 8) * sizeof(unsigned long long), hipHostMallocDefault));
-        for (int i = 0; i < 2 * rt::kCtlWords + 8; ++i) t->h_ctl[i] = 0;  // (h_res[kCtlWords]: the sequence number of the call it holds)
-        t->h_ctl[1] = ~0ull;  // first failing uid: atomicMin target
-    }
-    // the call's control block: calls alternate between two, and the scan of a call resets the other one for the next call —
-    // in the steady state no reset kernel runs in front of the march (its launch gap was 5 µs of every step)
-    const int cb = t->ctl_idx;
-    unsigned long long *const d_ctl = t->ctl.p + (size_t)cb * rt::kCtlWords;
-    unsigned long long *const d_ctl_other = t->ctl.p + (size_t)(1 - cb) * rt::kCtlWords;
-    const bool ctl_was_clean = t->ctl_clean[cb];
-    const int64_t ctl_was_first = t->ctl_first_chunk[cb];
-    const bool vacc_was_clean = t->vacc_clean;
-    t->ctl_clean[0] = t->ctl_clean[1] = false;  // (set again when this call has succeeded)
-    t->vacc_clean = false;
-    unsigned long long *const d_fail = d_ctl;
-    int64_t *const d_total = reinterpret_cast<int64_t *>(d_ctl + 16);
-    int32_t *const d_cursor = reinterpret_cast<int32_t *>(d_ctl + 18);
-    unsigned long long *const h_res = t->h_ctl + rt::kCtlWords;
-    // the same pinned block as the device sees it (k_scan_tile_sums writes it); looked up once per handle
-    if (!t->h_res_dev) RT_HIP(hipHostGetDevicePointer((void **)&t->h_res_dev, h_res, 0));
-    unsigned long long *const h_res_dev = t->h_res_dev;
-    std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
-    RT_HIP(t->volumes.reserve(m->n_cells));
-    if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
-        t->h_delta_s.assign(delta_s, delta_s + n_azim_2);
-        if (int rc = upload(t->delta_s, t->h_delta_s.data(), (size_t)n_azim_2, s)) return rc;
-    }
+// One rt_segmentize call (segmentize!, src/trackgenerator.jl:357-369): its arguments, the plan chosen for it, the state of its
+// attempts and what it leaves on the handle.  segmentize_impl (below) is the driver: begin -> choose_plan -> [single pass:
+// estimate_pools, then per attempt grow_pools, bind_stage, enqueue_attempt, wait_attempt, after_attempt] -> finish.
+struct SegmentizeCall {
+    // ---- arguments
+    rt_tracks *const t;
+    const double tiny_step;
+    const int32_t k;
+    const double rtol;
+    const double *const delta_s;
+    const int32_t n_azim_2;
+    SegmentizeCall(rt_tracks *t_, double tiny_, int32_t k_, double rtol_, const double *ds_, int32_t na_)
+        : t(t_), tiny_step(tiny_), k(k_), rtol(rtol_), delta_s(ds_), n_azim_2(na_) {}
 
+    // ---- begin(): handle, sizes, parameters, the call's control block
+    rt_mesh *m = nullptr;
+    hipStream_t s = nullptr;
+    int64_t n = 0, n_tiles = 0, n_waves = 0;
+    rt::DParams prm{};
+    int cb = 0;  // calls alternate between two control blocks; the scan of a call resets the other one for the next call
+    unsigned long long *d_ctl = nullptr, *d_ctl_other = nullptr, *d_fail = nullptr, *h_res = nullptr, *h_res_dev = nullptr;
+    int64_t *d_total = nullptr;
+    int32_t *d_cursor = nullptr;
+    bool ctl_was_clean = false, vacc_was_clean = false;
+    int64_t ctl_was_first = -1;
     rt::DOut out{};
-    using rt::as_global;
-    out.volumes = as_global(t->volumes.p);  // (single pass with fused fill_volumes: the accumulator `vacc`, see below)
-    out.delta_s = as_global(t->delta_s.p);
-    out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
-    out.dbg = m->compact_debug;
     rt::DStage stg{};
     rt::DSplit sp{};
-    // Track pieces (DSplit): every wave of a batch too small to fill the chip; a call that cannot use the plan (once a track
-    // reached MAX_ITER segments) marches every track whole.
-    const bool widek_ = k > rt::kMaxK;
-    const size_t hist_bytes_ = (size_t)m->n_cells * sizeof(double);
-    int fuse_waves_ = (3 * (hist_bytes_ + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || (n + 63) / 64 > 3072) ? 4 : 6;
-    if (m->march_waves == 4 || m->march_waves == 6) fuse_waves_ = m->march_waves;  // (experiments)
-    const bool fuse_ = m->volumes_mode == 2 && m->fuse_volumes && 2 * (hist_bytes_ + fuse_waves_ * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 && !widek_;
-    // Option "compact" = 0: stop after march + scan (a device-resident consumer, rt_sweep, reads the staged rows); the separate
-    // volumes pass needs the compact records, so a call that cannot fuse fill_volumes compacts anyway.  Whole tracks only.
-    const bool do_compact = m->compact || !fuse_ || !m->single_pass;
-    const bool plan_ok = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit && do_compact;
-    const bool split = plan_ok;  // pieces are marched in this call
-    // Cheap steps (k_march<..., TOPO>): whole-track batches on meshes with cheap-step records, the usual k, fill_volumes fused.
-    const bool topo = m->single_pass && m->topo && m->topo_available && m->d.walk_ok && !split && !widek_ && n > 0 &&
-                      fuse_ && tiny_step > 0 && tiny_step <= m->topo_tiny_max &&
-                      (m->topo == 2 || 10 * m->n_records_topo >= 9 * m->n_records_walk);
-    t->last_topo = topo ? 1 : 0;
-    if (split) {
-        sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
-        sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
-        sp.s_el = as_global(t->s_el.p); sp.s_eq = as_global(t->s_eq.p);
-        sp.s_px = as_global(t->s_px.p); sp.s_py = as_global(t->s_py.p); sp.s_qx = as_global(t->s_qx.p);
-        sp.s_qy = as_global(t->s_qy.p); sp.s_ell = as_global(t->s_ell.p);
-        sp.p_count = as_global(t->p_count.p); sp.p_flags = as_global(t->p_flags.p); sp.p_sum = as_global(t->p_sum.p);
-        sp.p_valid = as_global(t->p_valid.p); sp.p_rel = as_global(t->p_rel.p);
-        sp.n_vwaves = t->n_vwaves;
-    }
-    [[maybe_unused]] const unsigned grid = (unsigned)n_waves;  // (the two-pass march's launches)
-    // compaction order of the whole-track waves (only when every track marches whole with the full march order)
-    const int32_t *corder = (t->corder.p && m->single_pass && !t->n_vwaves) ? (const int32_t *)t->corder.p : (const int32_t *)nullptr;
+    // ---- choose_plan()
+    bool widek = false;       // find_element's knn fallback beyond the in-register list: separate kernel instantiations
+    bool fuse = false;        // fill_volumes in the march's LDS copy of `volumes`
+    bool do_compact = true;   // the call writes the 44-B records
+    bool split = false;       // track pieces (DSplit)
+    bool topo = false;        // cheap steps: the two-phase march
+    int fuse_waves = 4;
+    size_t hist_bytes = 0, fuse_smem = 0;
+    const int32_t *corder = nullptr;  // compaction order of the whole-track waves
+    // ---- estimate_pools() / grow_pools()
+    int64_t want = 0, side_want = 0, side_static = 0;
+    // ---- one attempt
+    int32_t first_chunk = 0, side_first = 0;
+    int64_t reset_key = 0;
+    bool need_reset = false;
+    int32_t *tile_acc_cur = nullptr, *tile_acc_other = nullptr;  // (set for two-phase calls)
+    rt::DStage stg_pieces{};
+    rt::DTracks d_whole{};
+    bool fused_volumes = false;  // fill_volumes rode along with the march (until a recovery path recomputes it from the records)
+    bool volumes_pass = true;    // false: no separate pass, no ev[6]
+    // ---- results
     int64_t total = 0;
     unsigned long long fi[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float f = 0;
+    int32_t cur[4] = {0, 0, 0, 0};  // pool cursor, pool overflow / argument mismatch, side-list cursor, side-list overflow
+#ifdef RT_HOST_TIMING
+    double ht0 = 0, ht1 = 0, ht2 = 0;
+#endif
+    enum After { kDone = 0, kRetry = 1, kRestartWhole = 2 };
+
+    // HIP events between the kernels (rt_last_timing) only on request: each costs ≈4 µs of stream time
+    int rec(int i) {
+        if (m->timing) RT_HIP(hipEventRecord(t->ev[i], s));
+        return RT_SUCCESS;
+    }
+
+    int begin() {
+#ifdef RT_HOST_TIMING
+        ht0 = ht_now();
+#endif
+        if (!t || !delta_s || n_azim_2 <= 0) { set_error("rt_segmentize: bad arguments"); return RT_ERR_INVALID; }
+        if (k < 0) {  // knn(kdtree, x, k, ...) rejects a negative k (src/mesh.jl:123); any k >= 0 is honoured
+            set_error("rt_segmentize: k = %d (must be >= 0)", k);
+            return RT_ERR_INVALID;
+        }
+        if (t->n > 0 && t->azim_max > n_azim_2) {
+            set_error("rt_segmentize: track azim_idx reaches %d but delta_s has n_azim_2 = %d entries", t->azim_max, n_azim_2);
+            return RT_ERR_INVALID;
+        }
+        m = t->mesh;
+        RT_HIP(hipSetDevice(m->device));
+        s = m->stream;
+        n = t->n;
+        t->segmentized = false;
+        t->tau_groups = 0;  // τ of the previous records is void
+        for (double &v : t->ms) v = 0.0;
+
+        prm.tiny_step = tiny_step; prm.rtol = rtol; prm.k = k; prm.n_azim_2 = n_azim_2; prm.iter_cap = m->iter_cap;
+        prm.topo_tiny_max = m->topo_tiny_max; prm.topo_rmax = m->topo_rmax; prm.topo_end_err = m->topo_end_err;
+        prm.topo_force = m->topo == 2 ? 1 : 0; prm.pad_ = 0;
+        {
+            // the chord of a cheap record is used for fill_volumes where its error bound a + b/D_x (rt_mesh_prep.hpp) is at most ε of the
+            // chord: ε/8 for a, 7ε/8 for b.  "test_tally_tau" (tests, A/B): ε in 1e-12; < 0: every cheap record is tallied from its length
+            const double eps = m->test_tally_tau > 0 ? 1e-12 * (double)m->test_tally_tau : 8e-11;
+            prm.tally_c1 = m->test_tally_tau < 0 ? (double)INFINITY : m->tally_a / (0.125 * eps);
+            prm.tally_c2 = m->test_tally_tau < 0 ? (double)INFINITY : m->tally_b / (0.875 * eps);
+        }
+
+        n_tiles = (n + rt::kScanTile - 1) / rt::kScanTile;
+        n_waves = (n + 63) / 64;
+        RT_HIP(t->counts.reserve(n + 1));
+        RT_HIP(t->status.reserve(n + 1));
+        RT_HIP(t->offsets.reserve(n + 1));
+        RT_HIP(t->tile_sums.reserve(n_tiles + 1));
+        if (t->tile_acc_tiles != n_tiles + 1 || !t->tile_acc.p) {  // (two zeroed halves: k_march<TOPO> adds to one, the scan clears the other)
+            RT_HIP(t->tile_acc.reserve(2 * (size_t)(n_tiles + 1) * rt::kTileAccStride));
+            RT_HIP(hipMemsetAsync(t->tile_acc.p, 0, 2 * (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
+            t->tile_acc_tiles = n_tiles + 1;
+            t->tile_acc_clean[0] = t->tile_acc_clean[1] = true;
+        }
+        RT_HIP(t->ctl.reserve(2 * rt::kCtlWords));
+        RT_HIP(t->vacc.reserve(m->n_cells));
+        if (!t->h_ctl) {
+            RT_HIP(hipHostMalloc((void **)&t->h_ctl, (2 * rt::kCtlWords + 8) * sizeof(unsigned long long), hipHostMallocDefault));
+            for (int i = 0; i < 2 * rt::kCtlWords + 8; ++i) t->h_ctl[i] = 0;  // (h_res[kCtlWords]: the sequence number of the call it holds)
+            t->h_ctl[1] = ~0ull;  // first failing uid: atomicMin target
+        }
+        // the call's control block: calls alternate between two, and the scan of a call resets the other one for the next call —
+        // in the steady state no reset kernel runs in front of the march (its launch gap was 5 µs of every step)
+        cb = t->ctl_idx;
+        d_ctl = t->ctl.p + (size_t)cb * rt::kCtlWords;
+        d_ctl_other = t->ctl.p + (size_t)(1 - cb) * rt::kCtlWords;
+        ctl_was_clean = t->ctl_clean[cb];
+        ctl_was_first = t->ctl_first_chunk[cb];
+        vacc_was_clean = t->vacc_clean;
+        t->ctl_clean[0] = t->ctl_clean[1] = false;  // (set again when this call has succeeded)
+        t->vacc_clean = false;
+        d_fail = d_ctl;
+        d_total = reinterpret_cast<int64_t *>(d_ctl + 16);
+        d_cursor = reinterpret_cast<int32_t *>(d_ctl + 18);
+        h_res = t->h_ctl + rt::kCtlWords;
+        // the same pinned block as the device sees it (k_scan_tile_sums writes it); looked up once per handle
+        if (!t->h_res_dev) RT_HIP(hipHostGetDevicePointer((void **)&t->h_res_dev, h_res, 0));
+        h_res_dev = t->h_res_dev;
+        std::swap(t->volumes, t->volumes_prev);  // a consumer may still be all-reducing the previous call's volumes
+        RT_HIP(t->volumes.reserve(m->n_cells));
+        if (t->h_delta_s.size() != (size_t)n_azim_2 || memcmp(t->h_delta_s.data(), delta_s, sizeof(double) * n_azim_2) != 0) {
+            t->h_delta_s.assign(delta_s, delta_s + n_azim_2);
+            if (int rc = upload(t->delta_s, t->h_delta_s.data(), (size_t)n_azim_2, s)) return rc;
+        }
+        using rt::as_global;
+        out.volumes = as_global(t->volumes.p);  // (single pass with fused fill_volumes: the accumulator `vacc`, see enqueue_attempt)
+        out.delta_s = as_global(t->delta_s.p);
+        out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
+        out.dbg = m->compact_debug;
+        t->compacted = false;
+        t->sw_ell_valid = false;
+        t->cplan = rt_tracks::CompactPlan{};
+        t->last_split = 0;
+        return RT_SUCCESS;
+    }
+
+    // Which march this call runs: track pieces (DSplit) for every wave of a batch too small to fill the chip — a call that cannot
+    // use the plan (once a track reached MAX_ITER segments) marches every track whole —, cheap steps (k_march<..., TOPO>) for
+    // whole-track batches on meshes with cheap-step records, the usual k and fill_volumes fused.
+    void choose_plan() {
+        using rt::as_global;
+        widek = k > rt::kMaxK;
+        hist_bytes = (size_t)m->n_cells * sizeof(double);
+        // The march fits three waves per SIMD (12 per CU): four-wave workgroups when three copies of the LDS histogram fit in the
+        // CU's 160 KB, six-wave workgroups (two copies) for larger meshes (six-wave workgroups measured -10 % march time on a
+        // batch that is resident at once, BWR-like C4, and +5 % on one that takes many rounds, C5 on one GPU).
+        fuse_waves = (3 * (hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 || (n + 63) / 64 > 3072) ? 4 : 6;
+        if (m->march_waves == 4 || m->march_waves == 6) fuse_waves = m->march_waves;  // (experiments)
+        // fill_volumes fused into the march when an LDS copy of `volumes` (+ the chunk tables) leaves room for two workgroups per
+        // CU; larger meshes use the separate k_volumes pass.  A wide k marches with the one-wave kernels only: fewer
+        // instantiations of a rare case.
+        fuse = m->volumes_mode == 2 && m->fuse_volumes && 2 * (hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t)) <= 158 * 1024 && !widek;
+        fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
+        // Option "compact" = 0: stop after march + scan (a device-resident consumer, rt_sweep, reads the staged rows); the separate
+        // volumes pass needs the compact records, so a call that cannot fuse fill_volumes compacts anyway.  Whole tracks only.
+        do_compact = m->compact || !fuse || !m->single_pass;
+        split = m->single_pass && t->n_vwaves > 0 && !t->force_unsplit && do_compact;  // pieces are marched in this call
+        topo = m->single_pass && m->topo && m->topo_available && m->d.walk_ok && !split && !widek && n > 0 && fuse && tiny_step > 0 &&
+               tiny_step <= m->topo_tiny_max && (m->topo == 2 || 10 * m->n_records_topo >= 9 * m->n_records_walk);
+        t->last_topo = topo ? 1 : 0;
+        if (split) {
+            sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
+            sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
+            sp.s_el = as_global(t->s_el.p); sp.s_eq = as_global(t->s_eq.p);
+            sp.s_px = as_global(t->s_px.p); sp.s_py = as_global(t->s_py.p); sp.s_qx = as_global(t->s_qx.p);
+            sp.s_qy = as_global(t->s_qy.p); sp.s_ell = as_global(t->s_ell.p);
+            sp.p_count = as_global(t->p_count.p); sp.p_flags = as_global(t->p_flags.p); sp.p_sum = as_global(t->p_sum.p);
+            sp.p_valid = as_global(t->p_valid.p); sp.p_rel = as_global(t->p_rel.p);
+            sp.n_vwaves = t->n_vwaves;
+        }
+        // compaction order of the whole-track waves (only when every track marches whole with the full march order)
+        corder = (t->corder.p && m->single_pass && !t->n_vwaves) ? (const int32_t *)t->corder.p : (const int32_t *)nullptr;
+    }
 
     // copy_out: k_scan_tile_sums' last block also writes the control block to the pinned host copy; scale: k_scan_write also
-    // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended)
-    int32_t first_chunk_this_call = 0, side_first_this_call = 0;
-    int32_t *tile_acc_cur = nullptr, *tile_acc_other = nullptr;  // (set for two-phase calls)
-    // reset_other: the scan's last block also resets the OTHER control block for the next call (single-pass calls)
-    auto scan_counts = [&](bool copy_out, bool scale, bool reset_other, bool slot_order = false) -> int {
+    // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended); reset_other: the
+    // scan's last block also resets the OTHER control block for the next call (single-pass calls)
+    int scan_counts(bool copy_out, bool scale, bool reset_other, bool slot_order = false) {
         if (n > 0 && slot_order && tile_acc_cur) {  // (two-phase calls: the march has left the tile sums)
             ++t->call_seq;
             launch_scan_fused(s, t, n_tiles, d_ctl, tile_acc_cur, reset_other ? tile_acc_other : (int32_t *)nullptr,
-                              reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call);
+                              reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk, side_first);
             if (reset_other) t->tile_acc_clean[1 - cb] = true;
         } else if (n > 0) {
             launch_scan(s, t, n_tiles, d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
-                        reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk_this_call, side_first_this_call, ++t->call_seq,
+                        reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk, side_first, ++t->call_seq,
                         scale ? t->volumes.p : (double *)nullptr, (double)n_azim_2, slot_order);
         } else {
             RT_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
             RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
         }
         return RT_SUCCESS;
-    };
-    auto reserve_out = [&](int64_t tot) -> int { return reserve_records(t, tot, out); };
-    // HIP events between the kernels (rt_last_timing) only on request: each costs ≈4 µs of stream time
-    auto rec = [&](int i) -> int {
-        if (m->timing) RT_HIP(hipEventRecord(t->ev[i], s));
-        return RT_SUCCESS;
-    };
-    t->compacted = false;
-    t->sw_ell_valid = false;
-    t->cplan = rt_tracks::CompactPlan{};
+    }
+
     // fill_volumes as its own pass over the compact records + volumes ./= n_azim_2
-    bool fused_volumes_this_call = false;
-    bool volumes_pass = true;  // false: fill_volumes rode along with the march and the scan, no ev[6]
-    auto launch_volumes = [&]() -> int {
-        if (m->volumes_mode == 2 && n > 0 && !fused_volumes_this_call)
+    int launch_volumes() {
+        if (m->volumes_mode == 2 && n > 0 && !fused_volumes)
             if (int rc = launch_volumes_pass(s, t, m->single_pass ? (const int32_t *)(d_cursor + 1) : (const int32_t *)nullptr, out.cap)) return rc;
-        if (!(fused_volumes_this_call && n > 0))  // the fused path scales inside k_scan_write
+        if (!(fused_volumes && n > 0))  // the fused path scales inside k_scan_write
             launch_scale_volumes(s, t->volumes.p, m->n_cells, (double)n_azim_2);
         return RT_SUCCESS;
-    };
+    }
+    // the separate pass again, from the (now complete) records: a recovery path's last step
+    int recompute_volumes() {
+        RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+        return launch_volumes();
+    }
 
-    const bool widek = k > rt::kMaxK;  // find_element's knn fallback beyond the in-register list: separate kernel instantiations
-    const int64_t *march_offsets = nullptr;
-    hipStream_t march_stream = s;
-    const rt::DTracks *march_tracks = &t->d;
-    const rt::DStage *march_stage = &stg;
-    auto march = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK, bool TOPO = false>(unsigned blocks, size_t smem) -> int {
-        t->last_march_waves = WAVES; t->last_split = std::max(t->last_split, SPLIT ? 1 : 0); t->last_widek = WIDEK ? 1 : 0;
-        return launch_march(MODE, WAVES, SPLIT, WIDEK, TOPO, blocks, smem, march_stream, m->d, *march_tracks, prm, t->counts.p, t->status.p,
-                            march_offsets, out, *march_stage, d_fail, sp);
-    };
-    t->last_split = 0;
-    if (!m->single_pass) { if (int rc = rec(0)) return rc; }  // single pass: the call is timed from ev[1], after the 2-µs prologue
-    if (!m->single_pass) RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
-    if (m->single_pass) {
-        // ---- staged single-pass march; the pool is sized from the Cauchy–Crofton estimate
-        //      (or from what the previous call needed) and grown + re-run on overflow
-        // fill_volumes fused into the march when an LDS copy of `volumes` (+ 4 chunk tables) leaves room
-        // for two workgroups per CU; larger meshes use the separate k_volumes pass.
-        // The march fits three waves per SIMD (12 per CU): four-wave workgroups when three copies of the
-        // LDS histogram fit in the CU's 160 KB, six-wave workgroups (two copies) for larger meshes
-        // (six-wave workgroups measured -10 % march time on a batch that is resident at once, BWR-like C4, and
-        //  +5 % on one that takes many rounds, C5 on one GPU).  A wide k marches with the one-wave kernels only:
-        // fewer instantiations of a rare case.
-        const size_t hist_bytes = hist_bytes_;
-        const int fuse_waves = fuse_waves_;
-        const size_t fuse_smem = hist_bytes + fuse_waves * rt::kMaxChunks * sizeof(int32_t);
-        const bool fuse = fuse_;
+    int march(int mode, int waves, bool pieces, bool wide, bool cheap, unsigned blocks, size_t smem, const rt::DTracks &tracks,
+              const rt::DStage &stage, const int64_t *offsets = nullptr) {
+        t->last_march_waves = waves; t->last_split = std::max(t->last_split, pieces ? 1 : 0); t->last_widek = wide ? 1 : 0;
+        return launch_march(mode, waves, pieces, wide, cheap, blocks, smem, s, m->d, tracks, prm, t->counts.p, t->status.p, offsets, out,
+                            stage, d_fail, sp);
+    }
+
+    // ---- staged single-pass march: the pool is sized from the Cauchy–Crofton estimate (or from what the previous call needed)
+    //      and grown + re-run on overflow
+    void estimate_pools() {
         const bool split_all = split;  // every wave in pieces (small batches, or "split" > 0)
-        const int64_t n_whole_waves = n_waves;
-        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, split_all ? t->n_vwaves : n_whole_waves) * rt::kMaxChunks));
-        int64_t want = t->chunks_needed_last > 0
-                           ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
-                           : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * ((split ? t->n_vwaves : 0) + (split_all ? 0 : n_whole_waves)) + 64;
+        want = t->chunks_needed_last > 0
+                   ? t->chunks_needed_last + t->chunks_needed_last / 16 + 16
+                   : (int64_t)(1.3 * (m->kappa * t->sum_ell + (double)n) / (64.0 * rt::kChunkRows)) + 2 * ((split ? t->n_vwaves : 0) + (split_all ? 0 : n_waves)) + 64;
         if (!split) {  // (the reserved regions of the whole-track march and some room behind them)
             int64_t res = 0;
             for (int j = 0; j < rt::kStaticRegions; ++j) res += t->reg_cap[j];
             want = std::max(want, res + res / 8 + 64);
         }
         if (m->pool_chunks_hint > 0 && t->pool_chunks == 0) want = m->pool_chunks_hint;
-        fused_volumes_this_call = fuse;
+        fused_volumes = fuse;
         // the side list of the two-phase march: one reserved entry per march slot (a track's first record) + the records the
         // generic step makes further on — estimated from the share of records without a walk certificate (or the last call's need)
-        const int64_t side_static = n_whole_waves * 64;
-        int64_t side_want = 0;
+        side_static = n_waves * 64;
+        side_want = 0;
         if (topo) {
             const double unwalked = m->n_records > 0 ? 1.0 - (double)m->n_records_walk / (double)m->n_records : 1.0;
             const int64_t dyn = t->side_needed_last > 0 ? t->side_needed_last + t->side_needed_last / 8 + 1024
                                                         : (int64_t)(1.3 * unwalked * m->kappa * t->sum_ell) + n / 16 + 4096;
             side_want = side_static + ((m->side_entries_hint > 0 && t->side_cap == 0) ? m->side_entries_hint : dyn);
         }
-        for (int attempt = 0;; ++attempt) {
-            if (want > t->pool_chunks || (!topo && t->gqx.cap < (size_t)t->pool_chunks * rt::kChunkRows * 64)) {
-                want = std::max(want, t->pool_chunks);
-                const size_t slots = (size_t)want * rt::kChunkRows * 64;
-                // (q, ±cell) rows with sparse p for the exact march; the two-phase march stages one 4-B word per record
-                if (!topo) {
-                    RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots)); RT_HIP(t->gqy.reserve(slots));
-                }
-                RT_HIP(t->gelement.reserve(slots));
-                RT_HIP(t->cowner.reserve((size_t)want));
-                t->pool_chunks = want;
-            }
-            if (topo && side_want > t->side_cap) {
-                const size_t ne = (size_t)std::min<int64_t>(side_want, 0x7ffffff0);
-                RT_HIP(t->side_px.reserve(ne)); RT_HIP(t->side_py.reserve(ne)); RT_HIP(t->side_qx.reserve(ne)); RT_HIP(t->side_qy.reserve(ne));
-                RT_HIP(t->side_el.reserve(ne));
-                t->side_cap = (int64_t)ne;
-            }
-            // The six output arrays are sized from the Cauchy–Crofton estimate of the record count (or from what the
-            // previous call produced), not from the pool's slots: march -> scan -> compaction still run back to back
-            // without a host sync — the compaction simply does not write beyond the capacity, and in the rare call
-            // whose total exceeds it the host grows the arrays and compacts again (the staged rows are still there).
-            const int64_t est_records = t->total_last > 0 ? t->total_last + t->total_last / 32 + 4096
-                                                          : (int64_t)(1.08 * m->kappa * t->sum_ell) + 2 * n + 4096;
-            if (do_compact)
-                if (int rc = reserve_out(std::min<int64_t>(m->test_out_records > 0 && t->total_last == 0 ? m->test_out_records : est_records,
-                                                           t->pool_chunks * rt::kChunkRows * 64))) return rc;
-            stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
-            stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
-            stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
-            stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
-            // reserved chunks of the whole-track march (DStage): region j holds chunk j of the first reg_cap[j] march waves
-            int64_t reserved = 0;
-            stg.n_regions = 0;
-            if (!split) {
-                for (int j = 0; j < rt::kStaticRegions && t->reg_cap[j] > 0; ++j) {
-                    if (reserved + t->reg_cap[j] >= stg.pool_chunks) break;
-                    stg.reg_cap[j] = t->reg_cap[j]; stg.reg_base[j] = (int32_t)reserved;
-                    reserved += t->reg_cap[j];
-                    stg.n_regions = j + 1;
-                }
-            }
-            for (int j = stg.n_regions; j < rt::kStaticRegions; ++j) stg.reg_cap[j] = stg.reg_base[j] = 0;
-            stg.tile_acc = nullptr;
-            if (topo && m->fused_scan) {
-                tile_acc_cur = t->tile_acc.p + (size_t)cb * (size_t)(n_tiles + 1) * rt::kTileAccStride;
-                tile_acc_other = t->tile_acc.p + (size_t)(1 - cb) * (size_t)(n_tiles + 1) * rt::kTileAccStride;
-                stg.tile_acc = as_global(tile_acc_cur);
-            }
-            if (topo) {
-                stg.s_px = as_global(t->side_px.p); stg.s_py = as_global(t->side_py.p); stg.s_qx = as_global(t->side_qx.p);
-                stg.s_qy = as_global(t->side_qy.p); stg.s_el = as_global(t->side_el.p);
-                stg.side_cap = (int32_t)t->side_cap; stg.side_static = (int32_t)side_static;
-            }
-#ifdef RT_TIMING
-            RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
-            RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
-            stg.dbg = t->dbg.p;
-#endif
-            rt::DStage stg_pieces = stg;
-            rt::DTracks d_whole = t->d;
-            {
-                rt_tracks::CompactPlan &c = t->cplan;
-                c.stg = stg; c.stg_pieces = stg_pieces; c.d_whole = d_whole; c.sp = sp; c.corder = corder;
-                c.n_whole_waves = n_whole_waves; c.split = split; c.split_all = split_all; c.staged = false;
-                c.codes = topo; c.rtol = rtol;
-            }
-            // Everything one attempt puts on the stream(s), as one function.  (Capturing it once into a HIP graph and replaying it
-            // was tried: the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on
-            // events that were only ever recorded inside a graph — EXPERIMENTS.md §A.)
-            // fused fill_volumes accumulates into `vacc` (zero between calls: k_scan_write leaves it so); otherwise the separate
-            // pass adds into `volumes`, zeroed here.  The reset kernel runs only when the control block or the accumulator is
-            // not known to be clean: a handle's first call, a re-run after a pool overflow, a changed number of reserved chunks.
-            first_chunk_this_call = (int32_t)reserved;
-            side_first_this_call = topo ? (int32_t)side_static : 0;
-            const int64_t reset_key = (int64_t)first_chunk_this_call | ((int64_t)side_first_this_call << 32);
-            if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
-            const bool need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != reset_key || !(fuse && n > 0 && vacc_was_clean);
-            auto enqueue_attempt = [&]() -> int {
-                if (need_reset) {
-                    launch_prologue(s, d_ctl, (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk_this_call, side_first_this_call);
-                }
-                // (the tile sums' half of this control block: clean when the previous two-phase call's scan has cleared it — not after a
-                //  void attempt, and not when a call without cheap steps came in between)
-                if (tile_acc_cur && (need_reset || !t->tile_acc_clean[cb]))
-                    RT_HIP(hipMemsetAsync(tile_acc_cur, 0, (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
-                if (tile_acc_cur) t->tile_acc_clean[cb] = false;
-                if (int rc = rec(1)) return rc;
-                if (n > 0 && split) {
-                    hipStream_t ps = s;  // the stream the pieces march on
-                    launch_seed(widek, (unsigned)t->n_vwaves, ps, m->d, t->d, prm, sp);
-                    int rc;
-                    march_stream = ps; march_stage = &stg_pieces; march_tracks = &t->d;
-                    // (pieces run on batches that leave the chip underfilled: four-wave workgroups whatever the mesh size)
-                    if (fuse) rc = march.template operator()<rt::kStage, 4, true, false>((unsigned)((t->n_vwaves + 3) / 4), hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t));
-                    else if (widek) rc = march.template operator()<rt::kStage, 1, true, true>((unsigned)t->n_vwaves, rt::kMaxChunks * sizeof(int32_t));
-                    else rc = march.template operator()<rt::kStage, 1, true, false>((unsigned)t->n_vwaves, rt::kMaxChunks * sizeof(int32_t));
-                    march_stream = s; march_stage = &stg;
-                    if (rc) return rc;
-                    launch_resolve((unsigned)((n + 255) / 256), ps, t->d, prm, sp, t->counts.p, t->status.p, d_fail);
-                }
-                if (n > 0 && !split_all) {  // whole tracks
-                    int rc;
-                    march_tracks = &d_whole;
-                    if (topo && fuse_waves == 4)
-                        rc = march.template operator()<rt::kStage, 4, false, false, true>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
-                    else if (topo)
-                        rc = march.template operator()<rt::kStage, 6, false, false, true>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
-                    else if (fuse && fuse_waves == 4) rc = march.template operator()<rt::kStage, 4, false, false>((unsigned)((n_whole_waves + 3) / 4), fuse_smem);
-                    else if (fuse) rc = march.template operator()<rt::kStage, 6, false, false>((unsigned)((n_whole_waves + 5) / 6), fuse_smem);
-                    else if (widek) rc = march.template operator()<rt::kStage, 1, false, true>((unsigned)n_whole_waves, rt::kMaxChunks * sizeof(int32_t));
-                    else rc = march.template operator()<rt::kStage, 1, false, false>((unsigned)n_whole_waves, rt::kMaxChunks * sizeof(int32_t));
-                    march_tracks = &t->d;
-                    if (rc) return rc;
-                }
-                if (int rc = rec(2)) return rc;
-                if (int rc = scan_counts(!topo, fuse && !topo, true, topo)) return rc;  // (two-phase: k_finish scales the volumes, behind k_materialise)
-                if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
-                if (topo) {
-                    // codes -> records (or, "compact" = 0, (ℓ, cell) rows) + Σℓ / status; k_finish completes them and copies the control
-                    // block to the host
-                    if (int rc = launch_materialise(t, out, s, do_compact, !do_compact, true, d_ctl)) return rc;
-                    launch_finish(t, out, s, !do_compact, fuse, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
-                } else if (do_compact) {
-                    launch_compaction(t, out, s);
-                }
-                if (int rc = rec(5)) return rc;
-                if (int rc = launch_volumes()) return rc;
-                volumes_pass = !(fuse && n > 0);
-                if (volumes_pass) { if (int rc = rec(6)) return rc; }
+    }
 
-                return RT_SUCCESS;
-            };
-#ifdef RT_HOST_TIMING
-            const double ht1 = ht_now();
-#endif
-            if (int rc_enq = enqueue_attempt()) return rc_enq;
-#ifdef RT_HOST_TIMING
-            const double ht2 = ht_now();
-#endif
-            int32_t cur[4] = {0, 0, 0, 0};  // pool cursor, pool overflow / argument mismatch, side-list cursor, side-list overflow
-            if (n == 0) RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
-            // option "async": back to the caller as soon as the scan's copy of the control block has arrived — total, failure
-            // summary and pool cursor are final then, the compaction goes on behind the call (whole-track calls without events)
-            const bool async_call = m->async_calls && !m->timing && n > 0 && !split;
-            // two-phase calls: the control block's copy and the sequence number behind it are the LAST thing the call's last kernel
-            // writes (k_finish's last block, after every other block of it has finished) — seeing the number in pinned memory is
-            // seeing the call complete, a few microseconds before the stream reports it (hipStreamQuery); what is still to happen
-            // on the stream is that kernel's retirement, which every later operation on the stream is ordered behind anyway
-            const bool seq_done = topo && !m->timing && n > 0;
-            if (async_call || seq_done) RT_HIP(wait_seq(h_res, t->call_seq, s));
-            else RT_HIP(wait_stream(s));
-            t->in_flight = async_call || seq_done;  // (accessors wait for the stream: immediate here)
-#ifdef RT_HOST_TIMING
-            {
-                const double ht3 = ht_now();
-                g_ht[0] += ht1 - ht0; g_ht[1] += ht2 - ht1; g_ht[2] += ht3 - ht2; ++g_hn;
-                if (g_hn % 50 == 0) fprintf(stderr, "[rt host] per call: before enqueue %.1f us, enqueue %.1f us, wait %.1f us\n", g_ht[0] / g_hn, g_ht[1] / g_hn, g_ht[2] / g_hn);
+    int grow_pools() {
+        RT_HIP(t->ctab.reserve((size_t)std::max<int64_t>(1, split ? t->n_vwaves : n_waves) * rt::kMaxChunks));
+        if (want > t->pool_chunks || (!topo && t->gqx.cap < (size_t)t->pool_chunks * rt::kChunkRows * 64)) {
+            want = std::max(want, t->pool_chunks);
+            const size_t slots = (size_t)want * rt::kChunkRows * 64;
+            // (q, ±cell) rows with sparse p for the exact march; the two-phase march stages one 4-B word per record
+            if (!topo) {
+                RT_HIP(t->gpx.reserve(slots)); RT_HIP(t->gpy.reserve(slots)); RT_HIP(t->gqx.reserve(slots)); RT_HIP(t->gqy.reserve(slots));
             }
-#endif
-            memcpy(fi, h_res, sizeof(fi));
-            memcpy(&total, h_res + 16, sizeof(total));
-            memcpy(cur, h_res + 18, sizeof(cur));
-            t->chunks_needed_last = cur[0];
-            if (topo) t->side_needed_last = std::max<int64_t>(0, (int64_t)cur[2] - side_static);
-            if (do_compact && !cur[1] && !cur[3] && total > out.cap) {
-                // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
-                if (int rc = reserve_out(total + total / 32 + 4096)) return rc;
-                launch_compaction(t, out, s);
-                if (topo && h_res[rt::kCtlDeferred] != 0) {
-                    // tracks whose exact Σℓ k_finish could not form from the truncated records: once more, from the complete ones
-                    launch_finish(t, out, s, false, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
-                    RT_HIP(hipStreamSynchronize(s));
-                    memcpy(fi, h_res, sizeof(fi));
-                }
-                if (!fused_volumes_this_call && m->volumes_mode == 2) {  // the separate volumes pass read truncated records
-                    RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
-                    if (int rc = launch_volumes()) return rc;
-                }
-                RT_HIP(hipStreamSynchronize(s));
-            }
-            if (!cur[1] && split && fuse && (fi[7] != 0 || m->test_volumes_fallback)) {
-                // some piece marched past the seed it should have stopped at: its surplus records were dropped by
-                // k_resolve but had already been added to the fused volumes — recompute them from the kept records
-                fused_volumes_this_call = false;
-                RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
-                if (int rc = launch_volumes()) return rc;
-                RT_HIP(hipStreamSynchronize(s));
-            }
-            if (!cur[1] && !cur[3] && topo && fuse && h_res[rt::kCtlRestarts] != 0) {
-                // a track whose iteration bound reached the cap was marched again with exact steps: its cheap records had
-                // already been added to the fused volumes — recompute them from the records
-                if (!do_compact) {
-                    if (int rc = reserve_out(total)) return rc;
-                    launch_compaction(t, out, s);
-                }
-                fused_volumes_this_call = false;
-                RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
-                if (int rc = launch_volumes()) return rc;
-                RT_HIP(hipStreamSynchronize(s));
-                t->compacted = true;
-            }
-            if (!cur[1] && split && h_res[21] != 0) {
-                t->force_unsplit = true;
-                return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
-            }
-            if (!cur[1] && !cur[3]) {
-                t->cplan.staged = true;
-                if (do_compact) t->compacted = true;
-                if (topo && !do_compact) t->sw_ell_valid = true;  // (k_materialise left the (ℓ, cell) rows)
-                if (n > 0) {  // this call's scan has reset the other control block and (fused) left the accumulator zero
-                    t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = reset_key;
-                    t->vacc_clean = fuse;
-                    t->ctl_idx = 1 - cb;
-                }
-                break;
-            }
-            t->marg_clean = false;  // (a void attempt may have left entries in the list of tracks to sum exactly)
-            if (attempt >= 3) { set_error("staging pool / side list overflow persists (%d chunks, %d entries needed)", cur[0], cur[2]); return RT_ERR_HIP; }
-            if (cur[1]) want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
-            if (cur[3]) side_want = (int64_t)cur[2] + cur[2] / 8 + 1024;
+            RT_HIP(t->gelement.reserve(slots));
+            RT_HIP(t->cowner.reserve((size_t)want));
+            t->pool_chunks = want;
         }
-    } else {
+        if (topo && side_want > t->side_cap) {
+            const size_t ne = (size_t)std::min<int64_t>(side_want, 0x7ffffff0);
+            RT_HIP(t->side_px.reserve(ne)); RT_HIP(t->side_py.reserve(ne)); RT_HIP(t->side_qx.reserve(ne)); RT_HIP(t->side_qy.reserve(ne));
+            RT_HIP(t->side_el.reserve(ne));
+            t->side_cap = (int64_t)ne;
+        }
+        // The six output arrays are sized from the Cauchy–Crofton estimate of the record count (or from what the
+        // previous call produced), not from the pool's slots: march -> scan -> compaction still run back to back
+        // without a host sync — the compaction simply does not write beyond the capacity, and in the rare call
+        // whose total exceeds it the host grows the arrays and compacts again (the staged rows are still there).
+        const int64_t est_records = t->total_last > 0 ? t->total_last + t->total_last / 32 + 4096
+                                                      : (int64_t)(1.08 * m->kappa * t->sum_ell) + 2 * n + 4096;
+        if (do_compact)
+            if (int rc = reserve_records(t, std::min<int64_t>(m->test_out_records > 0 && t->total_last == 0 ? m->test_out_records : est_records,
+                                                              t->pool_chunks * rt::kChunkRows * 64), out)) return rc;
+        return RT_SUCCESS;
+    }
+
+    // The staging pool, its reserved regions, the side list and the tile sums as the kernels see them (DStage), and the plan the
+    // compaction may need later (CompactPlan: option "compact" = 0)
+    int bind_stage(int attempt) {
+        using rt::as_global;
+        stg.px = as_global(t->gpx.p); stg.py = as_global(t->gpy.p); stg.qx = as_global(t->gqx.p);
+        stg.qy = as_global(t->gqy.p); stg.element = as_global(t->gelement.p);
+        stg.ctab = as_global(t->ctab.p); stg.cowner = as_global(t->cowner.p); stg.cursor = as_global(d_cursor);
+        stg.pool_chunks = (int32_t)std::min<int64_t>(t->pool_chunks, 0x7fffffff);
+        // reserved chunks of the whole-track march (DStage): region j holds chunk j of the first reg_cap[j] march waves
+        int64_t reserved = 0;
+        stg.n_regions = 0;
+        if (!split) {
+            for (int j = 0; j < rt::kStaticRegions && t->reg_cap[j] > 0; ++j) {
+                if (reserved + t->reg_cap[j] >= stg.pool_chunks) break;
+                stg.reg_cap[j] = t->reg_cap[j]; stg.reg_base[j] = (int32_t)reserved;
+                reserved += t->reg_cap[j];
+                stg.n_regions = j + 1;
+            }
+        }
+        for (int j = stg.n_regions; j < rt::kStaticRegions; ++j) stg.reg_cap[j] = stg.reg_base[j] = 0;
+        stg.tile_acc = nullptr;
+        if (topo && m->fused_scan) {
+            tile_acc_cur = t->tile_acc.p + (size_t)cb * (size_t)(n_tiles + 1) * rt::kTileAccStride;
+            tile_acc_other = t->tile_acc.p + (size_t)(1 - cb) * (size_t)(n_tiles + 1) * rt::kTileAccStride;
+            stg.tile_acc = as_global(tile_acc_cur);
+        }
+        if (topo) {
+            stg.s_px = as_global(t->side_px.p); stg.s_py = as_global(t->side_py.p); stg.s_qx = as_global(t->side_qx.p);
+            stg.s_qy = as_global(t->side_qy.p); stg.s_el = as_global(t->side_el.p);
+            stg.side_cap = (int32_t)t->side_cap; stg.side_static = (int32_t)side_static;
+        }
+#ifdef RT_TIMING
+        RT_HIP(t->dbg.reserve((size_t)std::max<int64_t>(1, n_waves) * 4));
+        RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
+        stg.dbg = t->dbg.p;
+#endif
+        stg_pieces = stg;
+        d_whole = t->d;
+        {
+            rt_tracks::CompactPlan &c = t->cplan;
+            c.stg = stg; c.stg_pieces = stg_pieces; c.d_whole = d_whole; c.sp = sp; c.corder = corder;
+            c.n_whole_waves = n_waves; c.split = split; c.split_all = split; c.staged = false;
+            c.codes = topo; c.rtol = rtol;
+        }
+        // fused fill_volumes accumulates into `vacc` (zero between calls: k_scan_write leaves it so); otherwise the separate
+        // pass adds into `volumes`, zeroed by the prologue.  The reset kernel runs only when the control block or the accumulator
+        // is not known to be clean: a handle's first call, a re-run after a pool overflow, a changed number of reserved chunks.
+        first_chunk = (int32_t)reserved;
+        side_first = topo ? (int32_t)side_static : 0;
+        reset_key = (int64_t)first_chunk | ((int64_t)side_first << 32);
+        if (fuse && n > 0) out.volumes = as_global(t->vacc.p);
+        need_reset = attempt > 0 || !ctl_was_clean || ctl_was_first != reset_key || !(fuse && n > 0 && vacc_was_clean);
+        return RT_SUCCESS;
+    }
+
+    // Everything one attempt puts on the stream, back to back.  (Capturing it once into a HIP graph and replaying it was tried:
+    // the event-record nodes keep the ≈6-µs gaps between the kernels, and hipEventElapsedTime fails on events that were only
+    // ever recorded inside a graph — EXPERIMENTS.md §A.)
+    int enqueue_attempt() {
+        if (need_reset)
+            launch_prologue(s, d_ctl, (fuse && n > 0) ? t->vacc.p : t->volumes.p, m->n_cells, first_chunk, side_first);
+        // (the tile sums' half of this control block: clean when the previous two-phase call's scan has cleared it — not after a
+        //  void attempt, and not when a call without cheap steps came in between)
+        if (tile_acc_cur && (need_reset || !t->tile_acc_clean[cb]))
+            RT_HIP(hipMemsetAsync(tile_acc_cur, 0, (size_t)(n_tiles + 1) * rt::kTileAccStride * sizeof(int32_t), s));
+        if (tile_acc_cur) t->tile_acc_clean[cb] = false;
+        if (int rc = rec(1)) return rc;
+        const size_t one_wave_smem = rt::kMaxChunks * sizeof(int32_t);
+        if (n > 0 && split) {  // pieces (batches that leave the chip underfilled: four-wave workgroups whatever the mesh size)
+            launch_seed(widek, (unsigned)t->n_vwaves, s, m->d, t->d, prm, sp);
+            int rc;
+            if (fuse) rc = march(rt::kStage, 4, true, false, false, (unsigned)((t->n_vwaves + 3) / 4), hist_bytes + 4 * rt::kMaxChunks * sizeof(int32_t), t->d, stg_pieces);
+            else rc = march(rt::kStage, 1, true, widek, false, (unsigned)t->n_vwaves, one_wave_smem, t->d, stg_pieces);
+            if (rc) return rc;
+            launch_resolve((unsigned)((n + 255) / 256), s, t->d, prm, sp, t->counts.p, t->status.p, d_fail);
+        }
+        if (n > 0 && !split) {  // whole tracks
+            int rc;
+            if (topo) rc = march(rt::kStage, fuse_waves, false, false, true, (unsigned)((n_waves + fuse_waves - 1) / fuse_waves), fuse_smem, d_whole, stg);
+            else if (fuse) rc = march(rt::kStage, fuse_waves, false, false, false, (unsigned)((n_waves + fuse_waves - 1) / fuse_waves), fuse_smem, d_whole, stg);
+            else rc = march(rt::kStage, 1, false, widek, false, (unsigned)n_waves, one_wave_smem, d_whole, stg);
+            if (rc) return rc;
+        }
+        if (int rc = rec(2)) return rc;
+        if (int rc = scan_counts(!topo, fuse && !topo, true, topo)) return rc;  // (two-phase: k_finish scales the volumes, behind k_materialise)
+        if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
+        if (topo) {
+            // codes -> records (or, "compact" = 0, (ℓ, cell) rows) + Σℓ / status; k_finish completes them and copies the control
+            // block to the host
+            if (int rc = launch_materialise(t, out, s, do_compact, !do_compact, true, d_ctl)) return rc;
+            launch_finish(t, out, s, !do_compact, fuse, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+        } else if (do_compact) {
+            launch_compaction(t, out, s);
+        }
+        if (int rc = rec(5)) return rc;
+        if (int rc = launch_volumes()) return rc;
+        volumes_pass = !(fuse && n > 0);
+        if (volumes_pass) { if (int rc = rec(6)) return rc; }
+        return RT_SUCCESS;
+    }
+
+    // The host's wait, and the control block's copy: total, failure summary, cursors
+    int wait_attempt(int attempt) {
+        if (n == 0) RT_HIP(hipMemcpyAsync(h_res, d_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        if (attempt == 0 && m->enqueue_hook) m->enqueue_hook(m->enqueue_hook_user);
+        // option "async": back to the caller as soon as the scan's copy of the control block has arrived — total, failure
+        // summary and pool cursor are final then, the compaction goes on behind the call (whole-track calls without events)
+        const bool async_call = m->async_calls && !m->timing && n > 0 && !split;
+        // two-phase calls: the control block's copy and the sequence number behind it are the LAST thing the call's last kernel
+        // writes (k_finish's last block, after every other block of it has finished) — seeing the number in pinned memory is
+        // seeing the call complete, a few microseconds before the stream reports it (hipStreamQuery); what is still to happen
+        // on the stream is that kernel's retirement, which every later operation on the stream is ordered behind anyway
+        const bool seq_done = topo && !m->timing && n > 0;
+        if (async_call || seq_done) RT_HIP(wait_seq(h_res, t->call_seq, s));
+        else RT_HIP(wait_stream(s));
+        t->in_flight = async_call || seq_done;  // (accessors wait for the stream: immediate here)
+        memcpy(fi, h_res, sizeof(fi));
+        memcpy(&total, h_res + 16, sizeof(total));
+        memcpy(cur, h_res + 18, sizeof(cur));
+        t->chunks_needed_last = cur[0];
+        if (topo) t->side_needed_last = std::max<int64_t>(0, (int64_t)cur[2] - side_static);
+        return RT_SUCCESS;
+    }
+
+    // What an attempt may leave to repair — outputs that were too small, fused volumes that counted records twice — and whether
+    // the call is complete (kDone), runs again with larger pools (kRetry) or with whole tracks (kRestartWhole); < 0: error
+    int after_attempt(int attempt) {
+        const bool pools_ok = !cur[1] && !cur[3];
+        if (do_compact && pools_ok && total > out.cap) {
+            // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
+            if (int rc = reserve_records(t, total + total / 32 + 4096, out)) return rc;
+            launch_compaction(t, out, s);
+            if (topo && h_res[rt::kCtlDeferred] != 0) {
+                // tracks whose exact Σℓ k_finish could not form from the truncated records: once more, from the complete ones
+                launch_finish(t, out, s, false, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+                RT_HIP(hipStreamSynchronize(s));
+                memcpy(fi, h_res, sizeof(fi));
+            }
+            if (!fused_volumes && m->volumes_mode == 2)  // the separate volumes pass read truncated records
+                if (int rc = recompute_volumes()) return rc;
+            RT_HIP(hipStreamSynchronize(s));
+        }
+        if (!cur[1] && split && fuse && (fi[7] != 0 || m->test_volumes_fallback)) {
+            // some piece marched past the seed it should have stopped at: its surplus records were dropped by
+            // k_resolve but had already been added to the fused volumes — recompute them from the kept records
+            fused_volumes = false;
+            if (int rc = recompute_volumes()) return rc;
+            RT_HIP(hipStreamSynchronize(s));
+        }
+        if (pools_ok && topo && fuse && h_res[rt::kCtlRestarts] != 0) {
+            // a track whose iteration bound reached the cap was marched again with exact steps: its cheap records had
+            // already been added to the fused volumes — recompute them from the records
+            if (!do_compact) {
+                if (int rc = reserve_records(t, total, out)) return rc;
+                launch_compaction(t, out, s);
+            }
+            fused_volumes = false;
+            if (int rc = recompute_volumes()) return rc;
+            RT_HIP(hipStreamSynchronize(s));
+            t->compacted = true;
+        }
+        if (!cur[1] && split && h_res[21] != 0) {  // a track reached MAX_ITER segments (or the iteration cap) in pieces
+            t->force_unsplit = true;
+            return kRestartWhole;
+        }
+        if (pools_ok) {
+            t->cplan.staged = true;
+            if (do_compact) t->compacted = true;
+            if (topo && !do_compact) t->sw_ell_valid = true;  // (k_materialise left the (ℓ, cell) rows)
+            if (n > 0) {  // this call's scan has reset the other control block and (fused) left the accumulator zero
+                t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = reset_key;
+                t->vacc_clean = fuse;
+                t->ctl_idx = 1 - cb;
+            }
+            return kDone;
+        }
+        t->marg_clean = false;  // (a void attempt may have left entries in the list of tracks to sum exactly)
+        if (attempt >= 3) { set_error("staging pool / side list overflow persists (%d chunks, %d entries needed)", cur[0], cur[2]); return RT_ERR_HIP; }
+        if (cur[1]) want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
+        if (cur[3]) side_want = (int64_t)cur[2] + cur[2] / 8 + 1024;
+        return kRetry;
+    }
+
+    // The two-pass march (count, scan, march again writing at the CSR offsets): round 1's first correct path, kept as an
+    // independent cross-check in builds with -DRT_EXPERIMENTAL
+    int run_two_pass() {
 #ifdef RT_EXPERIMENTAL
+        if (int rc = rec(0)) return rc;
+        RT_HIP(hipMemsetAsync(t->volumes.p, 0, sizeof(double) * m->n_cells, s));
+        const unsigned grid = (unsigned)n_waves;
         RT_HIP(hipMemcpyAsync(d_ctl, t->h_ctl, rt::kCtlWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         if (int rc = rec(1)) return rc;
-        if (n > 0) {
-            if (int rc = widek ? march.template operator()<rt::kCount, 1, false, true>(grid, sizeof(int32_t))
-                               : march.template operator()<rt::kCount, 1, false, false>(grid, sizeof(int32_t))) return rc;
-        }
+        if (n > 0)
+            if (int rc = march(rt::kCount, 1, false, widek, false, grid, sizeof(int32_t), t->d, stg)) return rc;
         if (int rc = rec(2)) return rc;
         if (int rc = scan_counts(false, false, false)) return rc;
         if (int rc = rec(3)) return rc;
@@ -1148,80 +1189,120 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
         RT_HIP(hipStreamSynchronize(s));
         memcpy(fi, h_res, sizeof(fi));
         memcpy(&total, h_res + 16, sizeof(total));
-        if (int rc = reserve_out(total)) return rc;
+        if (int rc = reserve_records(t, total, out)) return rc;
         if (int rc = rec(4)) return rc;
-        if (n > 0) {
-            march_offsets = t->offsets.p;
-            if (int rc = widek ? march.template operator()<rt::kFill, 1, false, true>(grid, sizeof(int32_t))
-                               : march.template operator()<rt::kFill, 1, false, false>(grid, sizeof(int32_t))) return rc;
-        }
+        if (n > 0)
+            if (int rc = march(rt::kFill, 1, false, widek, false, grid, sizeof(int32_t), t->d, stg, t->offsets.p)) return rc;
         if (int rc = rec(5)) return rc;
         if (int rc = launch_volumes()) return rc;
         if (int rc = rec(6)) return rc;
         RT_HIP(hipStreamSynchronize(s));
         t->compacted = true;
-    
+        return RT_SUCCESS;
 #else
         set_error("the two-pass march needs a library built with -DRT_EXPERIMENTAL");
         return RT_ERR_INVALID;
 #endif
     }
-    RT_HIP(hipGetLastError());
-    if (m->timing) {
-        RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 1 : 0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
-        RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
-        RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan (+ volumes ./= n_azim_2 when fused)
-        RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 3 : 4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
-        if (volumes_pass) { RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f; }   // volumes as its own pass
-    }
-#ifdef RT_TIMING
-    if (const char *path = getenv("RT_TIMING_DUMP")) {
-        if (t->dbg.p) {
-            std::vector<unsigned long long> h((size_t)((n + 63) / 64) * 4);
-            RT_HIP(hipMemcpy(h.data(), t->dbg.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+
+    // Timings (option "timing"), development prints, and the call's statistics and failure summary on the handle
+    int finish() {
+        RT_HIP(hipGetLastError());
+        if (m->timing) {
+            float f = 0;
+            RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 1 : 0], t->ev[volumes_pass ? 6 : 5])); t->ms[0] = f;   // whole call, device side
+            RT_HIP(hipEventElapsedTime(&f, t->ev[1], t->ev[2])); t->ms[2] = f;   // march (staged, or count)
+            RT_HIP(hipEventElapsedTime(&f, t->ev[2], t->ev[3])); t->ms[3] = f;   // offsets scan (+ volumes ./= n_azim_2 when fused)
+            RT_HIP(hipEventElapsedTime(&f, t->ev[m->single_pass ? 3 : 4], t->ev[5])); t->ms[4] = f;   // compaction (or fill march)
+            if (volumes_pass) { RT_HIP(hipEventElapsedTime(&f, t->ev[5], t->ev[6])); t->ms[5] = f; }   // volumes as its own pass
         }
-    }
-    fprintf(stderr, "[rt timing] per wave-iteration (lane-0 view, cycles): top+load %.0f | walk_step %.0f | emit %.0f | loop-back %.0f | iters/wave %.1f | loop cycles/wave %.0f\n",
-            (double)fi[8] / fi[12], (double)fi[9] / fi[12], (double)fi[10] / fi[12], (double)fi[11] / fi[12], (double)fi[12] / fi[14], (double)fi[13] / fi[14]);
+#ifdef RT_TIMING
+        if (const char *path = getenv("RT_TIMING_DUMP")) {
+            if (t->dbg.p) {
+                std::vector<unsigned long long> h((size_t)((n + 63) / 64) * 4);
+                RT_HIP(hipMemcpy(h.data(), t->dbg.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
+            }
+        }
+        fprintf(stderr, "[rt timing] per wave-iteration (lane-0 view, cycles): top+load %.0f | walk_step %.0f | emit %.0f | loop-back %.0f | iters/wave %.1f | loop cycles/wave %.0f\n",
+                (double)fi[8] / fi[12], (double)fi[9] / fi[12], (double)fi[10] / fi[12], (double)fi[11] / fi[12], (double)fi[12] / fi[14], (double)fi[13] / fi[14]);
 #endif
 #ifdef RT_STATS_DISTINCT
-    {
-        fprintf(stderr, "[rt distinct] wave-iterations %llu, cheap lanes per iteration %.1f\n  distinct successor records 1..8+:", h_res[63], (double)h_res[62] / (double)std::max<unsigned long long>(1, h_res[63]));
-        for (int b = 1; b <= 8; ++b) fprintf(stderr, " %.3f", (double)h_res[44 + b] / (double)std::max<unsigned long long>(1, h_res[63]));
-        fprintf(stderr, "\n  distinct exit edges 1..8+:");
-        for (int b = 1; b <= 8; ++b) fprintf(stderr, " %.3f", (double)h_res[53 + b] / (double)std::max<unsigned long long>(1, h_res[63]));
-        fprintf(stderr, "\n");
-    }
+        {
+            fprintf(stderr, "[rt distinct] wave-iterations %llu, cheap lanes per iteration %.1f\n  distinct successor records 1..8+:", h_res[63], (double)h_res[62] / (double)std::max<unsigned long long>(1, h_res[63]));
+            for (int b = 1; b <= 8; ++b) fprintf(stderr, " %.3f", (double)h_res[44 + b] / (double)std::max<unsigned long long>(1, h_res[63]));
+            fprintf(stderr, "\n  distinct exit edges 1..8+:");
+            for (int b = 1; b <= 8; ++b) fprintf(stderr, " %.3f", (double)h_res[53 + b] / (double)std::max<unsigned long long>(1, h_res[63]));
+            fprintf(stderr, "\n");
+        }
 #endif
 #ifdef RT_STATS
-    if (split)
-        fprintf(stderr, "[rt stats] split plan: %llu tracks, %llu of %llu seeds alive, %llu pieces kept, %llu records marched by pieces, %llu dropped\n",
-                h_res[22], h_res[23], h_res[24], h_res[26], h_res[25], fi[7]);
-    fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
-            fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
+        if (split)
+            fprintf(stderr, "[rt stats] split plan: %llu tracks, %llu of %llu seeds alive, %llu pieces kept, %llu records marched by pieces, %llu dropped\n",
+                    h_res[22], h_res[23], h_res[24], h_res[26], h_res[25], fi[7]);
+        fprintf(stderr, "[rt stats] walk: generic=%llu skip=%llu emit=%llu | wave-iterations=%llu with-generic-lane=%llu | chunks=%lld pool=%lld\n",
+                fi[2], fi[3], fi[4], fi[5], fi[6], (long long)t->chunks_needed_last, (long long)t->pool_chunks);
 #endif
-    t->total = total;
-    t->total_last = total;
-    t->n_generic_records = (int64_t)fi[15];
-    t->n_exact_walk_records = topo ? (int64_t)fi[14] : 0;
-    for (int b = 0; b < 9; ++b) t->refusals[b] = m->single_pass ? (int64_t)h_res[rt::kCtlRefusal + b] : 0;
-    t->n_near_rtol = (int64_t)h_res[rt::kCtlNearRtol];
-    t->n_exact_tally = (int64_t)h_res[rt::kCtlExactTally];
-    t->n_restarts = m->single_pass ? (int64_t)h_res[rt::kCtlRestarts] : 0;
-    t->n_failed = (int64_t)fi[0];
-    t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
-    t->first_failed_status = 0;
-    if (fi[0]) {
-        // (on the call's own stream, behind its last kernel: a two-phase call returns on the sequence number k_finish wrote, and a
-        //  copy on the null stream is not ordered against a kernel of this non-blocking stream)
-        int32_t stt = 0;
-        RT_HIP(hipMemcpyAsync(&stt, t->status.p + (fi[1] - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        RT_HIP(rtx::wait_stream(s));
-        t->first_failed_status = stt;
+        t->total = total;
+        t->total_last = total;
+        t->n_generic_records = (int64_t)fi[15];
+        t->n_exact_walk_records = topo ? (int64_t)fi[14] : 0;
+        for (int b = 0; b < 9; ++b) t->refusals[b] = m->single_pass ? (int64_t)h_res[rt::kCtlRefusal + b] : 0;
+        t->n_near_rtol = (int64_t)h_res[rt::kCtlNearRtol];
+        t->n_exact_tally = (int64_t)h_res[rt::kCtlExactTally];
+        t->n_restarts = m->single_pass ? (int64_t)h_res[rt::kCtlRestarts] : 0;
+        t->n_failed = (int64_t)fi[0];
+        t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
+        t->first_failed_status = 0;
+        if (fi[0]) {
+            // (on the call's own stream, behind its last kernel: a two-phase call returns on the sequence number k_finish wrote, and a
+            //  copy on the null stream is not ordered against a kernel of this non-blocking stream)
+            int32_t stt = 0;
+            RT_HIP(hipMemcpyAsync(&stt, t->status.p + (fi[1] - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RT_HIP(rtx::wait_stream(s));
+            t->first_failed_status = stt;
+        }
+        t->segmentized = true;
+        return RT_SUCCESS;
     }
-    t->segmentized = true;
-    return total;
+};
+
+}  // namespace
+
+static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double rtol, const double *delta_s, int32_t n_azim_2) {
+    SegmentizeCall c(t, tiny_step, k, rtol, delta_s, n_azim_2);
+    if (int rc = c.begin()) return rc;
+    c.choose_plan();
+    if (!c.m->single_pass) {
+        if (int rc = c.run_two_pass()) return rc;
+    } else {
+        c.estimate_pools();
+        for (int attempt = 0;; ++attempt) {
+            if (int rc = c.grow_pools()) return rc;
+            if (int rc = c.bind_stage(attempt)) return rc;
+#ifdef RT_HOST_TIMING
+            c.ht1 = ht_now();
+#endif
+            if (int rc = c.enqueue_attempt()) return rc;
+#ifdef RT_HOST_TIMING
+            c.ht2 = ht_now();
+#endif
+            if (int rc = c.wait_attempt(attempt)) return rc;
+#ifdef RT_HOST_TIMING
+            {
+                const double ht3 = ht_now();
+                g_ht[0] += c.ht1 - c.ht0; g_ht[1] += c.ht2 - c.ht1; g_ht[2] += ht3 - c.ht2; ++g_hn;
+                if (g_hn % 50 == 0) fprintf(stderr, "[rt host] per call: before enqueue %.1f us, enqueue %.1f us, wait %.1f us\n", g_ht[0] / g_hn, g_ht[1] / g_hn, g_ht[2] / g_hn);
+            }
+#endif
+            const int r = c.after_attempt(attempt);
+            if (r < 0) return r;
+            if (r == SegmentizeCall::kRestartWhole) return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
+            if (r == SegmentizeCall::kDone) break;
+        }
+    }
+    if (int rc = c.finish()) return rc;
+    return c.total;
 }
 
 int32_t rt_wait(rt_tracks *t) {
