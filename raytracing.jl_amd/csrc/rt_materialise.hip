@@ -53,7 +53,8 @@ struct __attribute__((aligned(16))) LinTrack {
     double g0[4];          // A, B, C of the track's line; its length ℓ
     double g1[4];          // δs of its azimuthal angle; the first record's p (x, y) and q.x — the track's reserved side-list entry
     double g2[4];          // ... and q.y; the march's direction cos ϕ, sin ϕ (the signs of the Σℓ chain's corrections); unused
-    int64_t goff;          // record index in the result arrays = goff + linear slot (this round)
+    int32_t goff;          // record index in the result arrays = goff + linear slot (this round; below 2^29, see the host's choice of kernel)
+    int32_t last;          // linear slot of the track's last record, if it lies in this round (else -1): the end of the Σℓ chain
     double cx[2], cy[2];   // exit point of the last row of the previous round (rounds alternate)
     int32_t el0;           // cell + 1 of the first record
     int32_t lb;            // linear slot of the track's first row of this round
@@ -80,8 +81,8 @@ constexpr int kBufWord3 = 0x00020000;  // gfx950 buffer resource word 3: raw buf
 constexpr int kLinHalfCap = 16, kLinFlagCap = 64;
 struct LinHalf { int64_t o; double px, py, qx, qy, l; int32_t cell, pad; };
 
-constexpr int32_t kWordLast = 1 << 29;  // (in the LDS copy only) the word of a track's last record
-constexpr int32_t kWordCode = ~(kWordExactTally | kWordLast);
+constexpr int32_t kWordLast = 1 << 29;  // (side-list references are below it)
+constexpr int32_t kWordCode = ~kWordExactTally;
 // The record stores are NON-TEMPORAL (aux bit 1 = nt): whole 128-B lines leave the XCD's L2 without displacing the edges' general
 // forms and the next units' words — same-box A/B: record kernel −12 % at C3, −7 % at C5, and the march of the NEXT call −3 % (it
 // starts in a cache that is not full of dirty record lines).  (Round 3's compaction, whose 256-B runs ended in half-written lines,
@@ -266,27 +267,26 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         const int Lp = (end + 1) & ~1;
         LIN_STAMP(2);
         if (kw == 3 && lane < 16) {
-            s_trk[tl].goff = o - my_lb;
+            const int lr = cnt - 1 - r0;
+            s_trk[tl].goff = (int32_t)(o - my_lb);
+            s_trk[tl].last = (lr >= 0 && lr < kLinRows) ? my_lb + lr : -1;
             s_trk[tl].lb = my_lb;
             for (int k = my_gap; k < my_lb; ++k) s_meta[k] = 0;  // pads in front of a run group
             if (tl == 0 && end < Lp) s_meta[end] = 0;           // ... and behind the last one (pairs)
         }
-        // ---- transposition: the words to their slots
+        // ---- transposition: the words to their slots — a lane's rows of a chunk lie four slots apart (immediate offsets), and
+        //      the rows beyond its track's end are those from index nv on (round 5: 14 vector instructions per word -> 2; the
+        //      track's last record is no longer marked in the word: its slot is in the table)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const int j = 8 * s + kw + 4 * c2;
+            const int rb = (j << kChunkLog2) + rr;  // the lane's first row of the chunk
+            const int nv = (cnt - rb + 3) >> 2;     // its rows below the track's end (<= 0: none, >= 8: all)
+            int32_t *pm = &s_meta[my_lb + (rb - r0)];
+            uint8_t *pt = &s_tmap[my_lb + (rb - r0)];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = (j << kChunkLog2) + 4 * i + rr;
-                if (row < cnt) {
-                    const int li = my_lb + (row - r0);
-                    int32_t wd = ve[c2][i];
-                    // the track's last record: its q closes the chain of Σℓ (a side-list reference, -(entry + 1), goes down by the same bit)
-                    if (row == cnt - 1) wd = wd > 0 ? (wd | kWordLast) : wd - kWordLast;
-                    s_meta[li] = wd;
-                    s_tmap[li] = (uint8_t)tl;
-                }
-            }
+            for (int i = 0; i < 8; ++i)
+                if (__builtin_expect(i < nv, 1)) { pm[4 * i] = ve[c2][i]; pt[4 * i] = (uint8_t)tl; }
         }
         LIN_STAMP(3);
         __syncthreads();
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             // the tracks' lines and offsets (mostly one track per wave: broadcast reads)
             const lin_d2 ab0 = *(const lin_d2 *)&s_trk[t0].g0[0], ab1 = *(const lin_d2 *)&s_trk[t1].g0[0];
             const double c0 = s_trk[t0].g0[2], c1 = s_trk[t1].g0[2];
-            const int32_t g0 = (int32_t)s_trk[t0].goff, g1 = (int32_t)s_trk[t1].goff;  // (record indices below 2^29: the host takes this kernel for no larger arrays)
+            const lin_i2 gl0 = *(const lin_i2 *)&s_trk[t0].goff, gl1 = *(const lin_i2 *)&s_trk[t1].goff;  // (goff, last)
+            const int32_t g0 = gl0.x, g1 = gl1.x;
             double q0x, q0y, q1x, q1y;
             edge_exit_point(ab0.x, ab0.y, c0, pre.e0A, pre.e0B, pre.e0C, q0x, q0y);  // src/intersection.jl:127-138
             edge_exit_point(ab1.x, ab1.y, c1, pre.e1A, pre.e1B, pre.e1C, q1x, q1y);
@@ -422,14 +423,14 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                         double acc = (p0x - b0x) * d0x + (p0y - b0y) * d0y < 0.0 ? -g : g;
                         if ((q0x - p0x) * d0x + (q0y - p0y) * d0y < 0.0) acc -= 2.0 * l0;
                         atomicAdd(&s_gap[t0], acc);
-                        if ((-w0 - 1) & kWordLast) { lin_d2 v; v.x = q0x; v.y = q0y; s_qlast[t0] = v; }  // ... and the chain's end, if it is the last record
+                        if (2 * m == gl0.y) { lin_d2 v; v.x = q0x; v.y = q0y; s_qlast[t0] = v; }  // ... and the chain's end, if it is the last record
                     }
                     if (gap1) {
                         const double g = norm2(p1x - b1x, p1y - b1y);
                         double acc = (p1x - b1x) * d1x + (p1y - b1y) * d1y < 0.0 ? -g : g;
                         if ((q1x - p1x) * d1x + (q1y - p1y) * d1y < 0.0) acc -= 2.0 * l1;
                         atomicAdd(&s_gap[t1], acc);
-                        if ((-w1 - 1) & kWordLast) { lin_d2 v; v.x = q1x; v.y = q1y; s_qlast[t1] = v; }
+                        if (2 * m + 1 == gl1.y) { lin_d2 v; v.x = q1x; v.y = q1y; s_qlast[t1] = v; }
                     }
                 }
             }
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             }
             if (a.tally) {
                 // Σℓ: the chain's end (see s_qlast)
-                const bool z0 = w0 > 0 && (w0 & kWordLast) != 0, z1 = w1 > 0 && (w1 & kWordLast) != 0;
+                const bool z0 = w0 > 0 && 2 * m == gl0.y, z1 = w1 > 0 && 2 * m + 1 == gl1.y;
                 if (__ballot(z0 || z1)) {
                     lin_d2 v;
                     if (z0) { v.x = q0x; v.y = q0y; s_qlast[t0] = v; }
