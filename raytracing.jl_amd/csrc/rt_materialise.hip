@@ -538,6 +538,9 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
         }
 #endif
         LIN_STAMP(6);
+        // (the epilogue — half pairs, flagged terms, the barrier and the Σℓ check of the unit's tracks — with priority again: a
+        //  workgroup that has stored its records should leave its slots, not wait for issue cycles; C5 −3.4 %, C3 −0.5 %, same box)
+        if (hprio) __builtin_amdgcn_s_setprio(3);
         // ---- the wave's epilogue: half pairs, marked records' fill_volumes terms
         if (__builtin_expect(n_half != 0, 0)) {
             const int ne = n_half < kLinHalfCap ? n_half : kLinHalfCap;
