@@ -1,7 +1,7 @@
 set -e
 cd /root/repo
 export TMPDIR=/tmp
-L=gpurun_out/exp_epilogue_prio.log
+L=gpurun_out/exp_iter_split.log
 : > $L
 timeout -k 10 300 python tools/ab.py compact_debug=0,16,0,16,0,16 >> $L 2>&1
 timeout -k 10 300 python tools/ab.py --mesh bwr_like.msh --nazim 64 --delta 2e-3 compact_debug=0,16,0,16 >> $L 2>&1
