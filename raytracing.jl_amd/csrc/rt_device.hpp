@@ -121,6 +121,8 @@ struct DTracks {
     // in MARCH-SLOT order, for k_materialise (one level of dependent loads less than through perm): the track lines, the record
     // counts (written by the whole-track march beside counts[uid]) and the CSR offsets (k_scan_write, through iperm: uid -> slot)
     const RT_G double *As, *Bs, *Cs, *Ls, *Dxs, *Dys;  // (Ls: the tracks' lengths ℓ; Dxs, Dys: cos ϕ, sin ϕ)
+    const RT_G double *Pxs, *Pys, *Phis;               // start points and angles in march-slot order: the whole-track march reads
+    const RT_G int32_t *Azs;                           // everything a lane starts from by slot — one trip, none behind perm[slot]
     const RT_G int32_t *iperm;
     RT_G int32_t *cnt_slot;
     RT_G int64_t *off_slot;

@@ -315,6 +315,8 @@ struct rt_tracks {
     DevView<int32_t> corder;  // march waves sorted by the uid of their first track (the compaction order of large batches)
     DevView<int32_t> azim, perm;  // perm: march order of all tracks
     DevView<double> As, Bs, Cs, Ls, Dxs, Dys;   // the track lines, lengths and directions (cos ϕ, sin ϕ) in march order (k_materialise)
+    DevView<double> Pxs, Pys, Phis;             // start points and angles in march order (the whole-track march's first loads)
+    DevView<int32_t> Azs;                       // ... and azimuthal indices
     DevView<int32_t> iperm;       // uid -> march slot
     DevBuf<int32_t> cnt_slot;     // record counts / CSR offsets in march-slot order (whole-track two-phase calls)
     DevBuf<int64_t> off_slot;
@@ -436,8 +438,8 @@ void launch_scan(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long lon
 int launch_volumes_pass(hipStream_t s, rt_tracks *t, const int32_t *overflow, int64_t cap);  // fill_volumes over the compact records
 void launch_scale_volumes(hipStream_t s, double *volumes, int32_t n_cells, double n_azim_2);
 void launch_fill_tau(hipStream_t s, rt_tracks *t, int32_t n_groups);
-void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, const double *ell,
-                        const double *cs, const double *sn, double *As, double *Bs, double *Cs, double *Ls, double *Dx, double *Dy, int32_t *iperm);
+void launch_slot_arrays(hipStream_t s, int64_t n, const rt::DTracks &d, double *As, double *Bs, double *Cs, double *Ls, double *Dx, double *Dy,
+                        double *Pxs, double *Pys, double *Phis, int32_t *Azs, int32_t *iperm);
 // rt_march.hip
 int launch_march(int mode, int waves, bool split, bool widek, bool topo, unsigned blocks, size_t smem, hipStream_t s, const rt::DMesh &m,
                  const rt::DTracks &t, const rt::DParams &prm, int32_t *counts, int32_t *status, const int64_t *offsets, const rt::DOut &out,

@@ -230,16 +230,20 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             if (e >= 0) { tgt_el = e; tgt_pj = (int32_t)pj; break; }
         }
     }
-    const double tA = t.A[u], tB = t.B[u], tC = t.C[u];
-    const double phi = t.phi[u];
+    // What a lane starts from.  Whole tracks: by march slot (k_slot_arrays left copies in march order) — every load of the kernel's
+    // first trip is issued at once, none waits for perm[slot]; pieces: by uid (the slot of a piece's wave IS its first uid + lane).
+    const double tA = SPLIT ? t.A[u] : t.As[slot], tB = SPLIT ? t.B[u] : t.Bs[slot], tC = SPLIT ? t.C[u] : t.Cs[slot];
+    const double phi = SPLIT ? t.phi[u] : t.Phis[slot];
+    const double cs_u = SPLIT ? t.cs[u] : t.Dxs[slot], sn_u = SPLIT ? t.sn[u] : t.Dys[slot];
+    const double px_u = SPLIT ? t.px[u] : t.Pxs[slot], py_u = SPLIT ? t.py[u] : t.Pys[slot];
     // advance_step (src/point.jl:43): x + step * Point2D(cos ϕ, sin ϕ)
-    const double sx = prm.tiny_step * t.cs[u];
-    const double sy = prm.tiny_step * t.sn[u];
-    double xpx = t.px[u] + sx, xpy = t.py[u] + sy;  // src/track.jl:114
+    const double sx = prm.tiny_step * cs_u;
+    const double sy = prm.tiny_step * sn_u;
+    double xpx = px_u + sx, xpy = py_u + sy;  // src/track.jl:114
     int64_t base = 0;
     double w = 0.0;
     if (MODE == kFill) base = offsets[u];
-    if (MODE == kFill || FUSE) w = out.delta_s[t.azim[u] - 1];
+    if (MODE == kFill || FUSE) w = out.delta_s[(SPLIT ? t.azim[u] : t.Azs[slot]) - 1];
     int32_t my_chunk = -1;
     RT_G double *row_qx = nullptr, *row_qy = nullptr;  // this lane's slots of row 0 of its current chunk
     RT_G int32_t *row_el = nullptr;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     NextRec nr;
     load_next(mh, -1, nr);
     // per-lane state of the cheap step
-    TopoTrack tt = topo_track(TOPO && m.walk_ok, m.d_vertex, prm.topo_tiny_max, prm.topo_rmax, prm.topo_end_err, prm.tiny_step, t.cs[u], t.sn[u]);
+    TopoTrack tt = topo_track(TOPO && m.walk_ok, m.d_vertex, prm.topo_tiny_max, prm.topo_rmax, prm.topo_end_err, prm.tiny_step, cs_u, sn_u);
     // (wave-uniform constants of the cheap loop in vector registers: the scalar file is the short one — 73 scalar values of the
     //  kernel live in vector lanes, and every use of one inside the loop is a v_readlane)
     if (TOPO) asm volatile("" : "+v"(tt.dv), "+v"(tt.c1), "+v"(tt.c2));
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 atomicAdd(march_ctl() + kCtlRestarts, 1ull);
                 tt.on = false; fl = 0; n_generic = 0; n_exact_tally = 0;
                 i = 0; it = 0; prev_element = -1; wk.T = -1; wk.pred = -1; creep_run = 0; my_chunk = -1; sum_ell = 0.0;
-                xpx = t.px[u] + sx; xpy = t.py[u] + sy;
+                xpx = (SPLIT ? t.px[u] : t.Pxs[slot]) + sx; xpy = (SPLIT ? t.py[u] : t.Pys[slot]) + sy;  // (read again: not kept in registers across the march)
                 continue;
             }
         }
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         }
         counts[u] = i;
         status[u] = st;
-        if (TOPO) { t.cnt_slot[slot] = i; if (FUSE) t.w_slot[slot] = out.delta_s[t.azim[u] - 1]; }  // (k_materialise reads its units' counts and weights in slot order)
+        if (TOPO) { t.cnt_slot[slot] = i; if (FUSE) t.w_slot[slot] = w; }  // (k_materialise reads its units' counts and weights in slot order; w: δs of the track's angle, loaded at the start — two dependent loads here were the tail of every wave, the last one's included)
         {
             // What the wave leaves for the call: its records into the sum of its tile of uids (two-phase calls: the scan then needs no
             // pass over the counts to form the tile sums), and the per-call statistics (rt_last_stats) — records the generic step

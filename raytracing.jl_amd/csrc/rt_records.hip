@@ -736,16 +736,17 @@ __global__ void k_scale_volumes(double *__restrict__ vol, int32_t n_cells, doubl
 }
 
 
-// rt_tracks_create: the line coefficients in march-slot order and the inverse of the march order, from the uploaded arrays
-// (52 B per track that need not cross PCIe).
-__global__ void k_slot_arrays(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ A, const double *__restrict__ B,
-                              const double *__restrict__ C, const double *__restrict__ ell, const double *__restrict__ cs, const double *__restrict__ sn,
-                              double *__restrict__ As, double *__restrict__ Bs, double *__restrict__ Cs, double *__restrict__ Ls,
-                              double *__restrict__ Dx, double *__restrict__ Dy, int32_t *__restrict__ iperm) {
+// rt_tracks_create: what the kernels read per march slot — the lines' coefficients, lengths, directions, start points, angles and
+// azimuthal indices in march-slot order, and the inverse of the march order — from the uploaded arrays (84 B per track that need
+// not cross PCIe).
+__global__ void k_slot_arrays(int64_t n, DTracks t, double *__restrict__ As, double *__restrict__ Bs, double *__restrict__ Cs, double *__restrict__ Ls,
+                              double *__restrict__ Dx, double *__restrict__ Dy, double *__restrict__ Pxs, double *__restrict__ Pys,
+                              double *__restrict__ Phis, int32_t *__restrict__ Azs, int32_t *__restrict__ iperm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int32_t u = perm[i];  // slot i holds track perm[i]
-    As[i] = A[u]; Bs[i] = B[u]; Cs[i] = C[u]; Ls[i] = ell[u]; Dx[i] = cs[u]; Dy[i] = sn[u];
+    const int32_t u = t.perm[i];  // slot i holds track perm[i]
+    As[i] = t.A[u]; Bs[i] = t.B[u]; Cs[i] = t.C[u]; Ls[i] = t.ell[u]; Dx[i] = t.cs[u]; Dy[i] = t.sn[u];
+    Pxs[i] = t.px[u]; Pys[i] = t.py[u]; Phis[i] = t.phi[u]; Azs[i] = t.azim[u];
     iperm[u] = (int32_t)i;
 }
 
@@ -754,10 +755,10 @@ __global__ void k_slot_arrays(int64_t n, const int32_t *__restrict__ perm, const
 // ------------------------------------------------------------------- launchers -------------
 namespace rtx {
 
-void launch_slot_arrays(hipStream_t s, int64_t n, const int32_t *perm, const double *A, const double *B, const double *C, const double *ell,
-                        const double *cs, const double *sn, double *As, double *Bs, double *Cs, double *Ls, double *Dx, double *Dy, int32_t *iperm) {
+void launch_slot_arrays(hipStream_t s, int64_t n, const rt::DTracks &d, double *As, double *Bs, double *Cs, double *Ls, double *Dx, double *Dy,
+                        double *Pxs, double *Pys, double *Phis, int32_t *Azs, int32_t *iperm) {
     if (n > 0)
-        hipLaunchKernelGGL(rt::k_slot_arrays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, perm, A, B, C, ell, cs, sn, As, Bs, Cs, Ls, Dx, Dy, iperm);
+        hipLaunchKernelGGL(rt::k_slot_arrays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d, As, Bs, Cs, Ls, Dx, Dy, Pxs, Pys, Phis, Azs, iperm);
 }
 
 // The six record arrays of a handle, sized for `tot` records, as the kernels see them.

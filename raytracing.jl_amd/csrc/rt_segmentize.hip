@@ -587,10 +587,10 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
         const size_t na = (n + 31) & ~(size_t)31;  // every array starts on a 256-B boundary
         const size_t ncord = (h_corder.size() + 63) & ~(size_t)63;
         // the arena: what goes up — nine double arrays, azim_idx, the march order, the materialise order — and behind it what a small
-        // kernel derives on the device (the lines' coefficients in march-slot order, the inverse of the march order, the lengths, the directions: 52 B per track
-        // that need not cross PCIe)
+        // kernel derives on the device (the lines' coefficients, lengths, directions, start points, angles and azimuthal indices in march-slot order, the inverse
+        // of the march order: 84 B per track that need not cross PCIe)
         const size_t up_bytes = 9 * na * sizeof(double) + 2 * na * sizeof(int32_t) + ncord * sizeof(int32_t);
-        const size_t bytes = up_bytes + 6 * na * sizeof(double) + na * sizeof(int32_t) + 256;
+        const size_t bytes = up_bytes + 9 * na * sizeof(double) + 2 * na * sizeof(int32_t) + 256;
         StagingBlock stage;
         const int slot = staging_acquire(&stage, mesh->device);
         // (a failed upload may leave a copy out of the block in flight: the stream is drained before the block goes back to the pool)
@@ -606,7 +606,8 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
             t->corder.p = h_corder.empty() ? nullptr : t->perm.p + na;
             t->As.p = (double *)(db + up_bytes); t->Bs.p = t->As.p + na; t->Cs.p = t->Bs.p + na; t->Ls.p = t->Cs.p + na;
             t->Dxs.p = t->Ls.p + na; t->Dys.p = t->Dxs.p + na;
-            t->iperm.p = (int32_t *)(t->Dys.p + na);
+            t->Pxs.p = t->Dys.p + na; t->Pys.p = t->Pxs.p + na; t->Phis.p = t->Pys.p + na;
+            t->iperm.p = (int32_t *)(t->Phis.p + na); t->Azs.p = t->iperm.p + na;
         }
         cstamp[2] = cnow();
         if (ok && n > 0) {
@@ -649,7 +650,14 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
                 if (ok && !h_corder.empty())
                     ok = hipMemcpyAsync(t->corder.p, h_corder.data(), h_corder.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess;
             }
-            if (ok) rtx::launch_slot_arrays(s, (int64_t)n, t->perm.p, t->A.p, t->B.p, t->C.p, t->ell.p, t->cs.p, t->sn.p, t->As.p, t->Bs.p, t->Cs.p, t->Ls.p, t->Dxs.p, t->Dys.p, t->iperm.p);
+            if (ok) {
+                rt::DTracks du{};  // (the uploaded arrays, uid order)
+                du.px = rt::as_global(t->px.p); du.py = rt::as_global(t->py.p); du.phi = rt::as_global(t->phi.p); du.cs = rt::as_global(t->cs.p);
+                du.sn = rt::as_global(t->sn.p); du.A = rt::as_global(t->A.p); du.B = rt::as_global(t->B.p); du.C = rt::as_global(t->C.p);
+                du.ell = rt::as_global(t->ell.p); du.azim = rt::as_global(t->azim.p); du.perm = rt::as_global(t->perm.p);
+                du.n = (int64_t)n;
+                rtx::launch_slot_arrays(s, (int64_t)n, du, t->As.p, t->Bs.p, t->Cs.p, t->Ls.p, t->Dxs.p, t->Dys.p, t->Pxs.p, t->Pys.p, t->Phis.p, t->Azs.p, t->iperm.p);
+            }
             ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
             cstamp[4] = cnow();
         }
@@ -678,6 +686,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     d.sn = as_global(t->sn.p); d.A = as_global(t->A.p); d.B = as_global(t->B.p); d.C = as_global(t->C.p);
     d.ell = as_global(t->ell.p); d.azim = as_global(t->azim.p); d.perm = as_global(t->perm.p);
     d.As = as_global(t->As.p); d.Bs = as_global(t->Bs.p); d.Cs = as_global(t->Cs.p); d.Ls = as_global(t->Ls.p); d.Dxs = as_global(t->Dxs.p); d.Dys = as_global(t->Dys.p); d.iperm = as_global(t->iperm.p);
+    d.Pxs = as_global(t->Pxs.p); d.Pys = as_global(t->Pys.p); d.Phis = as_global(t->Phis.p); d.Azs = as_global(t->Azs.p);
     d.cnt_slot = as_global(t->cnt_slot.p); d.off_slot = as_global(t->off_slot.p); d.w_slot = as_global(t->w_slot.p);
     d.n = n_tracks;
     guard.p = nullptr;
