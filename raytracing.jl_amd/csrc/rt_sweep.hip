@@ -82,14 +82,29 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
         // of length 0: τ = 0, 1 − e^{−0} = 0 exactly, Δ = ±0 — its ψ keeps its bits, and one select does for all groups.
         auto segment = [&](const int32_t e, const double ell_row, const bool act, const double (&st)[GP], const double (&qs)[GP]) {
             const double ell = act ? ell_row : 0.0;
-            double wd[GP];
+            double wd[GP], tau[GP];
+            bool thin = true;
 #pragma unroll
             for (int g = 0; g < GP; ++g) {
-                const double tau = st[g] * ell;
-                const double ex = one_minus_exp_neg(tau, poly);  // −expm1(−τ) to within an ulp (rt_device.hpp)
-                const double d = (psi[g] - qs[g]) * ex;
-                psi[g] = psi[g] - d;
-                wd[g] = w * d;
+                tau[g] = st[g] * ell;
+                thin = thin && tau[g] < kThinTau;
+            }
+            // −expm1(−τ) to within an ulp (rt_device.hpp): where every lane's segment is optically thin in every group of the pass —
+            // a wave-uniform branch — by the series alone (10 instructions per group instead of 24)
+            if (__ballot(!thin) == 0 && !(a.debug & 4)) {
+#pragma unroll
+                for (int g = 0; g < GP; ++g) {
+                    const double d = (psi[g] - qs[g]) * one_minus_exp_neg_thin(tau[g], poly);
+                    psi[g] = psi[g] - d;
+                    wd[g] = w * d;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < GP; ++g) {
+                    const double d = (psi[g] - qs[g]) * one_minus_exp_neg(tau[g], poly);
+                    psi[g] = psi[g] - d;
+                    wd[g] = w * d;
+                }
             }
             // Neighbouring lanes are neighbouring parallel tracks: at the same row most of them are in the same cell, and
             // atomics of one wave instruction to one address are served one lane at a time (measured at C3: the tallies were

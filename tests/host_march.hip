@@ -300,6 +300,10 @@ int32_t hostmarch_prep(const double *x, const double *y, int32_t n_nodes, const 
 void hostmarch_one_minus_exp_neg(const double *tau, int64_t n, double *out) {
     for (int64_t i = 0; i < n; ++i) out[i] = rt::one_minus_exp_neg(tau[i]);
 }
+// ... and its form for optically thin segments (tau < rt::kThinTau)
+void hostmarch_one_minus_exp_neg_thin(const double *tau, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = rt::one_minus_exp_neg_thin(tau[i]);
+}
 
 // bf16_up / bf16_value of the preprocessing (the cheap step's four per-record constants are stored as bfloat16 rounded UP).
 void hostmarch_bf16(const double *v, int64_t n, uint16_t *pattern, double *value) {

@@ -40,6 +40,7 @@ def lib():
         L.hostmarch_prep.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip, _ip, _ip, _dp, C.c_char_p, C.c_int32]
         L.hostmarch_bf16.argtypes = [_dp, C.c_int64, C.POINTER(C.c_uint16), _dp]
         L.hostmarch_one_minus_exp_neg.argtypes = [_dp, C.c_int64, _dp]
+        L.hostmarch_one_minus_exp_neg_thin.argtypes = [_dp, C.c_int64, _dp]
         L.hostmarch_topo.restype = C.c_int32
         L.hostmarch_topo.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip] + [_dp] * 6
         _lib = L
@@ -134,9 +135,11 @@ def topo_records(mesh):
     return out
 
 
-def one_minus_exp_neg(tau):
-    """rt::one_minus_exp_neg (rt_device.hpp): the sweep's 1 - exp(-tau), evaluated on the host."""
+def one_minus_exp_neg(tau, thin=False):
+    """rt::one_minus_exp_neg (rt_device.hpp): the sweep's 1 - exp(-tau), evaluated on the host; `thin`: its form for
+    optically thin segments (tau < 1/8: the series without range reduction)."""
     tau = _f(tau)
     out = np.zeros(len(tau))
-    lib().hostmarch_one_minus_exp_neg(tau.ctypes.data_as(_dp), len(tau), out.ctypes.data_as(_dp))
+    f = lib().hostmarch_one_minus_exp_neg_thin if thin else lib().hostmarch_one_minus_exp_neg
+    f(tau.ctypes.data_as(_dp), len(tau), out.ctypes.data_as(_dp))
     return out

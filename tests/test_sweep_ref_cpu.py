@@ -58,6 +58,23 @@ def test_attenuation_factor_is_accurate_to_an_ulp():
     assert got[tau == 0.0][0] == 0.0 and got[-1] == 1.0
 
 
+def test_thin_attenuation_factor_is_accurate_to_an_ulp():
+    """Where every lane's segment is optically thin (τ < 1/8 in every group of the pass) rt_sweep takes the series without range
+    reduction (rt_device.hpp, one_minus_exp_neg_thin): same accuracy on [0, 1/8), and within 2 ulp of the general form there."""
+    import hostmarch as hm
+
+    rng = np.random.default_rng(6)
+    tau = np.concatenate([10.0 ** rng.uniform(-310, -0.91, 200000), rng.uniform(0, 0.125, 300000),
+                          [0.0, 5e-324, 1e-300, 0.0625, np.nextafter(0.125, 0)]])
+    tau = tau[tau < 0.125]
+    got = hm.one_minus_exp_neg(tau, thin=True)
+    ref = -np.expm1(-tau)
+    assert np.all(got >= 0) and np.all(got < 0.1176)
+    assert np.all(np.abs(got - ref) <= 4.5e-16 * ref)
+    assert np.all(np.abs(got - hm.one_minus_exp_neg(tau)) <= 4.5e-16 * ref)
+    assert got[0] >= 0 and hm.one_minus_exp_neg([0.0], thin=True)[0] == 0.0
+
+
 def test_fast_sweep_equals_the_plain_one(rt, traced, oracle_run):
     """sweep_fast (bincount tallies, the active tracks as a prefix of the tracks sorted by length) is what the C4-sized GPU test
     uses: the same numbers as `sweep` up to the order of the tallies' additions."""
