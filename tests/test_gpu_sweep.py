@@ -96,6 +96,36 @@ def test_sweep_matches_sequential_sweep_over_oracle_records(rt, orc, mesh, n_azi
         dt.close(); dm.close()
 
 
+@pytest.mark.parametrize("scale,regime", [(0.02, "thin"), (4.0, "mixed"), (1000.0, "thick")])
+def test_sweep_attenuation_regimes(rt, orc, scale, regime):
+    """rt_sweep takes the series-only attenuation factor on rows whose every lane and group has τ < 1/8 and the general form
+    elsewhere (rt_device.hpp, one_minus_exp_neg_thin / one_minus_exp_neg): cross sections scaled so that every row is thin, rows
+    of both kinds occur, next to no record is thin (some optical lengths beyond 41.5, where the factor is 1) — each against the sequential sweep over the oracle's records, and the default against
+    option "sweep_debug" 4 (the general form everywhere)."""
+    model = rt.DiscreteModelFromFile(rt.data_path("pincell.json"))
+    tg = rt.TrackGenerator(model, 32, 5e-3, bcs=_bcs(rt, "reflective"))
+    rt.trace(tg)
+    om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
+    ref = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, cos_phi=tg.cos_phi, sin_phi=tg.sin_phi,
+                        tiny_step=tg.tiny_step, n_threads=0)
+    G = 5
+    sigma_t, source, weight, psi_in = _problem(rt, tg, G, 11)
+    sigma_t = sigma_t * scale
+    tau = sigma_t[ref["element"] - 1] * ref["ell"][:, None]
+    thin_share = float((tau.max(axis=1) < 0.125).mean())
+    assert {"thin": thin_share == 1.0, "mixed": 0.02 < thin_share < 0.98, "thick": thin_share < 0.02}[regime], thin_share
+    phi1, out1 = sweep_ref.sweep(ref["offsets"], ref["ell"], ref["element"], sigma_t, source, weight, psi_in)
+    res = {}
+    for dbg in (0, 4):
+        dm, dt = _device(rt, tg, 0, sweep_debug=dbg)
+        r = dt.sweep(G, sigma_t, source, weight, psi_in, input="staged")
+        _close(r["phi"], phi1, "phi"); _close(r["psi_out"], out1, "psi_out")
+        res[dbg] = r
+        dt.close(); dm.close()
+    _close(res[0]["phi"], res[4]["phi"], "phi, thin form against the general one")
+    _close(res[0]["psi_out"], res[4]["psi_out"], "psi_out, thin form against the general one")
+
+
 def test_sweep_at_config4_size(rt, orc):
     """BASELINE configs[3] (BWR-like mesh, nφ=64, δ=2e-3: 130,472 tracks, 14.3 M segments): the full batch — 2,039 march waves, the
     BWR-like mesh's two groups of tallies per pass in LDS — swept twice on the device, against the sequential sweep over ALL of
