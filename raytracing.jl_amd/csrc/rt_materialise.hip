@@ -34,6 +34,10 @@
 // The unit's first trip to memory is ONE trip: counts, offsets, the table (lines, lengths, first records: three wave-loads in a
 // (field, track) lane layout) and — for chunks the host reserved, whose ids follow from kernel arguments — the words themselves.
 // Σℓ is not added up: a track's records lie head to tail (see s_qlast).
+// Who issues first: the header (first trip, run groups, transposition) and the epilogue of a workgroup run with a raised issue
+// priority (s_setprio), its store loop with the default one — the latency-bound parts do not queue for issue slots behind the other
+// workgroups' FP64 loops.  The usual unit is one run group (a DPP shift and a ballot establish it: no scalar recurrence), each of
+// the header's wave-loads is taken by another wave, and the transposition is one compare and two LDS writes per word.
 //
 // Measured and set aside (round 5, profiles/r05/exp_materialise_*.log): persistent workgroups that issue the next unit's header in
 // the loop's tail (the in-order counter leaves at most two iterations of distance: the header still arrives late, and the extra
