@@ -181,6 +181,58 @@ struct DSplit {
     int32_t n_vwaves;
 };
 
+// ---- the march in three kernels ("lean" plan, round 6) -----------------------------------------
+// The cheap loop of a lane needs a dozen values; the exact step (walk_step / generic: find_element + intersections) it almost
+// never takes needs 200 registers.  In one kernel the two share a register budget (218 VGPRs, two waves per SIMD, scratch).  The
+// lean plan runs them as three kernels that hand a lane's state through memory (src/track.jl:106-178: what the reference carries
+// between iterations is xp, prev_element and i — here: the record the lane predicts, its last record's code, the signed distances
+// of the entry edge's end points, the tally's positions and the counters):
+//   k_first  = k_march<..., PHASE 1>: start band + every track's first record (generic step) + topo_enter; writes the state
+//   k_cheap  (rt_cheap.hip): ONLY the cheap loop and its tally, four waves per SIMD; a lane whose cheap step refuses (or that has
+//              no certified successor, or whose iteration bound reaches the cap) writes its state, queues its slot and LEAVES
+//   k_serve  = k_march<..., PHASE 2>: a few persistent workgroups that claim queued slots and march those tracks to their end with
+//              the full kernel (exact step, then cheap steps again) — behind k_cheap on its stream, or beside it on a second one.
+// The staged words, the side list, counts / status / tile sums are what the one-kernel march leaves: scan, k_materialise_lin and
+// k_finish do not change.  Results never depend on which kernel decided a record.
+struct DLean {
+    RT_G int32_t *pred, *last, *i, *it, *fl, *word, *prev_el, *wk_last;  // [n_slots] per march slot
+    RT_G double *sp, *sn, *ttP, *ttN, *ttp, *dprev, *lqx, *lqy;           // [n_slots]
+    RT_G int32_t *dump;       // [kChunkRows * 16 + 64] where the lanes of k_cheap that have left store (nobody reads it)
+    RT_G int32_t *queue;      // [n_slots] march slots that need exact steps, in the order they were queued (-1: entry not written yet)
+    RT_G int32_t *qctl;       // [0] queue tail, [1] head, [2] k_cheap workgroups that have ended, [3] k_serve gave up (timeout)
+    int32_t n_cheap_wgs;      // workgroups of the k_cheap launch (k_serve ends when all of them have and the queue is empty)
+    int32_t pad_;
+};
+// k_march's lane flags (see there)
+constexpr uint32_t kFlCheap = 1, kFlUsed = 2, kFlMat = 4, kFlWait = 8, kFlDone = 16, kFlRestart = 32;
+// state word `fl` of a slot: bits 0..5 the lane flags, and
+constexpr int32_t kLnApos = 1 << 8;    // TopoState::apos
+constexpr int32_t kLnFinal = 1 << 9;   // the lane has ended (its counts are written)
+constexpr int32_t kLnExact = 1 << 10;  // queued: exact state (lqx, lqy, prev_el, wk_last) — no cheap step was possible behind the first record
+constexpr int kLeanCtl = 44;           // control-block words 44..47 (as int32: 8 words): the queue's counters (DLean::qctl)
+
+// Chunk j of march wave w for a kernel of the lean plan: the one the host reserved, the one ctab records (k_first cleared the wave's
+// row to -1), or a fresh one from the pool's cursor — by compare-and-swap, because k_serve may run beside k_cheap and a lane it
+// serves stages into its ORIGIN wave's columns.  -2: pool exhausted (the attempt is void, the host grows the pool and re-runs).
+__device__ __forceinline__ int32_t lean_chunk(const RT_K DStage *sk, int64_t w, int j) {
+    RT_G int32_t *e = sk->ctab + w * kMaxChunks + j;
+    if (j < sk->n_regions && w < sk->reg_cap[j]) {
+        const int32_t c = sk->reg_base[j] + (int32_t)w;
+        *e = c;                                   // (rt_sweep reads every chunk of a wave through ctab; same value whoever writes)
+        sk->cowner[c] = (int32_t)(w * kMaxChunks + j);
+        return c;
+    }
+    int32_t c = __hip_atomic_load((int32_t *)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c != -1) return c;
+    RT_G int32_t *cursor = sk->cursor;
+    const int32_t nw = atomicAdd((int32_t *)&cursor[0], 1);
+    if (nw >= sk->pool_chunks) { cursor[1] = 1; return -2; }
+    const int32_t old = atomicCAS((int32_t *)e, -1, nw);
+    if (old == -1) { sk->cowner[nw] = (int32_t)(w * kMaxChunks + j); return nw; }
+    sk->cowner[nw] = -1;  // (lost the race: the chunk stays unused)
+    return old;
+}
+
 // The Σℓ check `isapprox(track.ℓ, sum(ℓ.(segments)); rtol)` (src/track.jl:171) is decided here (and in the CPU checker) with a
 // left-to-right sum; Julia's `sum` reassociates (pairwise blocks, @simd lanes), so its Σℓ can differ by a few ulp·n.  A
 // track whose |ℓ − Σℓ| lies within 64·ulp·n·max(ℓ, Σℓ) of the threshold rtol·max(ℓ, Σℓ) could get the other status there:
@@ -275,6 +327,11 @@ struct rt_mesh {
                            // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
     int async_calls = 0;   // 1: rt_segmentize returns once total, status summary and offsets' scan are known to the host; the
                            // compaction may still be running on the stream (every entry point that touches results waits)
+    int lean = 0;          // the march of a two-phase call in three kernels (DLean): 0 no, 1 k_serve behind k_cheap, 2 beside it (second stream)
+    int serve_blocks = 0;  // workgroups of k_serve (0: 64)
+    int cheap_per_cu = 0;  // experiments: workgroups of k_cheap per CU (0: automatic)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
     int timing = 0;        // 1: record HIP events between the kernels of a call for rt_last_timing (≈4 µs of stream time each)
     bool topo_available = false;
     double topo_tiny_max = 0.0, topo_rmax = 0.0, topo_end_err = 0.0, tally_a = 0.0, tally_b = 0.0;
@@ -367,6 +424,11 @@ struct rt_tracks {
     int64_t n_generic_records = 0;       // rt_last_stats
     bool force_unsplit = false;  // a track reached MAX_ITER segments in split mode: this track set marches whole from now on
     int32_t last_topo = 0;  // 1: the last call marched with cheap steps
+    int32_t last_lean = 0;  // ... in three kernels (the option's value)
+    bool lean_gave_up = false, lean_q_clean = false;
+    int64_t n_lean_queued = 0;
+    DevBuf<int32_t> lean_i;   // DLean: the lanes' state (8 int arrays), the queue, the dump row
+    DevBuf<double> lean_d;    // ... 8 double arrays
     int64_t n_exact_walk_records = 0;  // ... and this many of its records came from exact walk steps
     int32_t last_march_waves = 0, last_split = 0, last_widek = 0;  // which instantiation of the march the last call launched
     std::vector<double> h_delta_s;  // what delta_s on the device currently holds
@@ -443,7 +505,10 @@ void launch_slot_arrays(hipStream_t s, int64_t n, const rt::DTracks &d, double *
 // rt_march.hip
 int launch_march(int mode, int waves, bool split, bool widek, bool topo, unsigned blocks, size_t smem, hipStream_t s, const rt::DMesh &m,
                  const rt::DTracks &t, const rt::DParams &prm, int32_t *counts, int32_t *status, const int64_t *offsets, const rt::DOut &out,
-                 const rt::DStage &stg, unsigned long long *fail_info, const rt::DSplit &sp);
+                 const rt::DStage &stg, unsigned long long *fail_info, const rt::DSplit &sp, int phase = 0, const rt::DLean *lean = nullptr);
+// rt_cheap.hip: the lean plan's cheap-only kernel (waves: 4, 8 or 16 per workgroup, by the size of the LDS copy of `volumes`)
+int launch_cheap(int waves, unsigned blocks, size_t smem, hipStream_t s, const rt::DMesh &m, const rt::DTracks &t, const rt::DParams &prm,
+                 int32_t *counts, int32_t *status, const rt::DOut &out, const rt::DStage &stg, unsigned long long *ctl, const rt::DLean &ln);
 void launch_seed(bool widek, unsigned blocks, hipStream_t s, const rt::DMesh &m, const rt::DTracks &t, const rt::DParams &prm, const rt::DSplit &sp);
 void launch_resolve(unsigned blocks, hipStream_t s, const rt::DTracks &t, const rt::DParams &prm, const rt::DSplit &sp, int32_t *counts,
                     int32_t *status, unsigned long long *fail_info);

@@ -135,7 +135,7 @@ __device__ __forceinline__ unsigned long long rt_tick(double dep) {
 // its hot path).  The struct mirrors k_march's parameter list.
 struct MarchArgsLayout {
     DMesh m; DTracks t; DParams prm; int32_t *counts; int32_t *status; const int64_t *offsets; DOut out; DStage stg;
-    unsigned long long *fail_info; DSplit sp;
+    unsigned long long *fail_info; DSplit sp; DLean ln;
 };
 __device__ __forceinline__ const RT_K DStage *march_stage_args() {
     const RT_K char *ka = (const RT_K char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -158,14 +158,18 @@ __device__ __forceinline__ const RT_K DParams *march_prm_args() {
 // formula, ℓ), which no longer feeds the next iteration: a lane's dependent chain per record is one 32-B record fetch and
 // a dozen instructions, and the next record's fetch is in flight while the certificates and the record are evaluated.
 // The exact step (walk_step / generic) runs only for the lanes whose cheap step refused.
-template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false, bool TOPO = false>
+// PHASE (whole tracks with cheap steps; the lean plan, rt_internal.hpp DLean): 0 the march in one kernel; 1 k_first — start band and
+// every track's first record, then the lane's state goes to memory; 2 k_serve — persistent waves claim queued march slots and
+// march those tracks from their stored state to the end.
+template <int MODE, int WAVES, bool SPLIT, bool WIDEK = false, bool TOPO = false, int PHASE = 0>
 #ifndef RT_TOPO_OCC
 #define RT_TOPO_OCC 0
 #endif
 __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) ? 3 : (TOPO ? RT_TOPO_OCC : 0)) void k_march(DMesh m, DTracks t, DParams prm, int32_t *__restrict__ counts,
                                                       int32_t *__restrict__ status,
                                                       const int64_t *__restrict__ offsets, DOut out, DStage stg,
-                                                      unsigned long long *__restrict__ fail_info, DSplit sp) {
+                                                      unsigned long long *__restrict__ fail_info, DSplit sp, DLean ln) {
+    static_assert(PHASE == 0 || (TOPO && WAVES > 1), "the lean plan: whole tracks, cheap steps, fused fill_volumes");
     // The split plan's tables are used at the start and the end of a piece and when a record of the target's cell comes
     // up — never in the steady march: they are read from the argument segment where they are used (as `stg` is), so
     // that their 17 pointers do not occupy scalar registers across the loop.
@@ -197,8 +201,56 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) hist[c] = 0.0;
         __syncthreads();
     }
+    for (;;) {  // (PHASE 2: one pass per claim of queued slots; else a single pass)
     int64_t wave_id = (int64_t)blockIdx.x * WAVES + wib;  // indexes the wave's chunk table (ctab)
     int64_t slot = wave_id * 64 + lane;
+    if (PHASE == 2) {
+        // ---- claim up to 64 queued march slots (DLean::queue); none left and every k_cheap workgroup over: the wave ends
+        int32_t q_base = 0, q_cnt = 0;
+        if (lane == 0) {
+            RT_G int32_t *qc = ln.qctl;
+            unsigned spins = 0;
+            for (;;) {
+                const int32_t head = __hip_atomic_load((int32_t *)&qc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int32_t tail = __hip_atomic_load((int32_t *)&qc[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (head < tail) {
+                    const int32_t nq = tail - head < 64 ? tail - head : 64;
+                    if (atomicCAS((int32_t *)&qc[1], head, head + nq) == head) { q_base = head; q_cnt = nq; break; }
+                    continue;
+                }
+                if (__hip_atomic_load((int32_t *)&qc[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= ln.n_cheap_wgs) {
+                    // (every push of k_cheap happens before its workgroup's count: one more look at the tail decides)
+                    tail = __hip_atomic_load((int32_t *)&qc[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__hip_atomic_load((int32_t *)&qc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tail) { q_cnt = -1; break; }
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(16);
+                // an exit every wave reaches: k_cheap is on its stream before this kernel is launched, so this never fires — if it
+                // does (≈25 ms without work), the attempt is void and the host marches again with the one-kernel plan
+                if (++spins > 60000u) { qc[3] = 1; q_cnt = -1; break; }
+            }
+        }
+        q_base = __builtin_amdgcn_readfirstlane(q_base); q_cnt = __builtin_amdgcn_readfirstlane(q_cnt);
+        if (q_cnt < 0) break;
+        slot = t.n;
+        if (lane < q_cnt) {
+            int32_t e;
+            unsigned spins = 0;
+            while ((e = __hip_atomic_load((int32_t *)&ln.queue[q_base + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > 4000000u) { ln.qctl[3] = 1; break; }
+            }
+            if (e >= 0) { slot = e; ln.queue[q_base + lane] = -1; }  // (consumed: the queue is all -1 again when the call ends)
+        }
+        wave_id = slot >> 6;
+    }
+    const int lane_o = PHASE == 2 ? (int)(slot & 63) : lane;  // the lane's column in its wave's staging chunks
+    if (PHASE == 1) {
+        // k_first leaves the wave's chunk table clean (-1: no chunk yet; lean_chunk)
+        RT_G int32_t *row = stg.ctab + wave_id * kMaxChunks;
+        if (wave_id * 64 < t.n)
+            for (int c = lane; c < kMaxChunks; c += 64) row[c] = -1;
+    }
     int32_t pk = 0, pP = 1, pw = 0;  // SPLIT: piece index, pieces per track, wave of tracks
     if (SPLIT) {
         const int64_t vidx = (int64_t)blockIdx.x * WAVES + wib;  // position in the dispatch order
@@ -255,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     int st = RT_TRACK_OK;
     double sum_ell = 0.0;
     Walk wk;
-    wk.T = -1; wk.pred = -1;
+    wk.T = -1; wk.pred = -1; wk.last = -1;
     wk.ax = wk.ay = wk.bx = wk.by = wk.cx = wk.cy = 0.0; wk.dT = 1.0;
     // node window of find_element(xp) then find_element(xp, k) as the walk records count it (extras field: 0..14, 15 = never)
     const int kk = prm.k > 2 ? (prm.k < rt::kExtrasNever - 1 ? prm.k : rt::kExtrasNever - 1) : 2;
@@ -276,7 +328,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     // kFlCheap: the lane takes cheap steps; kFlUsed: it has taken some (`it` is then an upper bound of the reference's
     // iterations); kFlMat: the exact step's state has to be rebuilt from `ts.last`; kFlWait: nothing to do until the wave
     // has no cheap lane left (an uncertified last step, a finished track); kFlDone / kFlRestart: see below
-    constexpr uint32_t kFlCheap = 1, kFlUsed = 2, kFlMat = 4, kFlWait = 8, kFlDone = 16, kFlRestart = 32;
+    // (the constants: rt_internal.hpp — k_cheap shares them)
     uint32_t fl = 0;
     // positions along the track line, t(x, y) = B·x − A·y ((B, −A) is the line's direction; general_form normalises the whole
     // (A, B, C), src/intersection.jl:11-18, so t is scaled by ‖(A, B)‖), of the end points of the lane's entry edge (by side, as
@@ -298,14 +350,14 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     int32_t last_word = 0;  // staging word of the lane's last record
     // (the cheap loop stores without a branch: should the pool run out before a lane's first chunk — the attempt is void
     //  then and the host re-runs it — its row pointers must still be addresses inside the pool)
-    if (TOPO) row_el = stg.element + lane;
+    if (TOPO) row_el = stg.element + lane_o;
     const RT_G TopoRec *trec_v = m.trec;
     const RT_G EdgeABC *etab_v = m.etab;
     if (TOPO) asm volatile("" : "+v"(trec_v), "+v"(etab_v));
     // Start band (:125-129 with no segment yet): step by tiny_step until xp leaves the boundary
     // band.  Run as its own loop so that the 64 lanes of the wave, whose bands differ in length
     // (≈1/sin ϕ or 1/|cos ϕ| steps), reach their first locate together.
-    while (!(SPLIT && (seed_pending || piece_dead)) && st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
+    while (PHASE != 2 && !(SPLIT && (seed_pending || piece_dead)) && st == RT_TRACK_OK && inboundary(m, xpx, xpy, prm.tiny_step)) {
         if (++it > cap) { st = RT_TRACK_ITER_CAP; break; }
         xpx = xpx + sx; xpy = xpy + sy;
     }
@@ -316,6 +368,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     // First row of a new chunk for a lane: wave-aggregated allocation among the lanes that are here.
     // chunk_lds[j] caches what the wave already owns.
     auto alloc_chunk = [&](const int j) -> int32_t {
+        if (PHASE == 2) return lean_chunk(march_stage_args(), wave_id, j);  // (the lanes of a k_serve wave come from different waves)
         bool pending = true;
         int32_t mine = -1;
         for (;;) {
@@ -330,9 +383,11 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     RT_G int32_t *cursor = sk->cursor;
                     // a chunk the host reserved (DStage: regions by chunk index; the cursor starts behind them) needs no atomic —
                     // every wave wants its first chunk at the same moment, on its first record: 2,039 atomics on one word
-                    if (!SPLIT && jL < sk->n_regions && wave_id < sk->reg_cap[jL]) c = sk->reg_base[jL] + (int32_t)wave_id;
+                    if (PHASE == 1) c = lean_chunk(sk, wave_id, jL);  // (k_cheap / k_serve look the chunk up in ctab)
+                    else if (!SPLIT && jL < sk->n_regions && wave_id < sk->reg_cap[jL]) c = sk->reg_base[jL] + (int32_t)wave_id;
                     else c = atomicAdd((int32_t *)&cursor[0], 1);
-                    if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
+                    if (PHASE == 1) { }
+                    else if (c >= sk->pool_chunks) { c = -2; cursor[1] = 1; }  // pool exhausted: host grows it and re-runs
                     else {
                         sk->ctab[wave_id * kMaxChunks + jL] = c;
                         sk->cowner[c] = (int32_t)(wave_id * kMaxChunks + jL);
@@ -345,14 +400,40 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         }
         return mine;
     };
+    if (PHASE == 2) {
+        // ---- the state k_first / k_cheap stored for this slot (DLean)
+        const int32_t f = ln.fl[slot];
+        i = ln.i[slot]; it = ln.it[slot]; last_word = ln.word[slot];
+        if (f & kLnExact) {
+            // behind the first record no cheap step was possible: the exact step's own state
+            lqx = ln.lqx[slot]; lqy = ln.lqy[slot];
+            prev_element = ln.prev_el[slot];
+            const int32_t wl = ln.wk_last[slot];
+            if (wl >= 0) {
+                const int32_t cell = (int32_t)((uint32_t)wl / 3u);
+                walk_enter(m, load_tri(load_geo(m.geo), cell), wk, cell, wl - 3 * cell);
+            } else { wk.T = prev_element; wk.pred = -1; }
+            xpx = lqx + sx; xpy = lqy + sy;  // :165
+            fl = 0;
+        } else {
+            // a lane that left k_cheap: its cheap step refused (kFlMat: the exact step's state is rebuilt from the last record's
+            // code), or its iteration bound reached the cap (kFlRestart)
+            fl = (uint32_t)f & (kFlUsed | kFlMat | kFlRestart);
+            ts.last = ln.last[slot]; ts.pred = -1;
+        }
+        if (i > 0) {
+            my_chunk = alloc_chunk((i - 1) >> kChunkLog2);  // (the chunk of the last staged record: a look-up)
+            if (my_chunk >= 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane_o);
+        }
+    }
     // A lane whose track creeps (see below) for more than kCreepLocal tiny steps leaves the march loop and
     // waits for the wave: once every lane is out, all 64 lanes test 64 consecutive creep positions of that
     // track at a time (cooperative creep), then the lane marches on.
     bool creep_escalate = false;
     int creep_run = 0;  // generic tiny steps in a row
     for (;;) {
-    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kIterLimit && !creep_escalate) {  // :119
-        if (TOPO) {
+    while (!(SPLIT && piece_dead) && st == RT_TRACK_OK && i < kIterLimit && !creep_escalate && !(PHASE == 1 && (fl & kFlCheap))) {  // :119
+        if (TOPO && PHASE != 1) {  // (k_first: a lane without a record takes no cheap step)
             // ---- cheap steps: a wave-uniform inner loop that runs while some lane is in cheap mode and no lane is due
             //      for an exact step (lanes whose track has ended, or that wait with an uncertified last step, idle here)
             {
@@ -455,7 +536,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     if (__builtin_expect(commit && rw == 0, 0)) {
                         my_chunk = alloc_chunk((i - 1) >> kChunkLog2);
                         // (pool exhausted: the attempt is void and the host re-runs it; the row pointer stays inside the pool)
-                        if (my_chunk >= 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane);
+                        if (my_chunk >= 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane_o);
                     }
                     last_word = commit ? (g.code + 1) | (inexact ? kWordExactTally : 0) : last_word;
                     row_el[rw * 16] = last_word;
@@ -466,7 +547,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             // walk step's certificates but not the cheap step's: every refusal is an exact pass the other lanes wait for)
             // goes on with exact steps only, i.e. as the march without cheap steps.
             if (__builtin_expect(tt.on && n_cheap_ref >= 16 && 8 * n_cheap_ref > n_cheap_it, 0)) {
-                if (march_prm_args()->topo_force) {  // option "topo" = 2: every record that carries a cheap certificate uses it
+                if (PHASE == 2 || march_prm_args()->topo_force) {  // option "topo" = 2: every record that carries a cheap certificate uses it
+                                                                    // (k_serve: its lanes ARE the refused ones — the rule is about waves of whole batches)
                     n_cheap_ref = 0; n_cheap_it = 0;
                 } else {
                     tt.on = false;
@@ -488,7 +570,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             }
         }
         if (++it > cap) { if (TOPO && (fl & kFlUsed)) continue; st = RT_TRACK_ITER_CAP; break; }
-        if (TOPO && __builtin_expect((fl & kFlMat) != 0, 0)) {
+        if (TOPO && PHASE != 1 && __builtin_expect((fl & kFlMat) != 0, 0)) {
             asm volatile("" ::: "memory");
             fl &= ~kFlMat;
             const int32_t cell = (int32_t)((uint32_t)ts.last / 3u);
@@ -611,7 +693,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                               (unsigned long long)__popcll(act));
             }
             if (m.walk_ok && eq >= 0) walk_enter(m, tri, wk, element, eq);
-            else { wk.T = element; wk.pred = -1; }
+            else { wk.T = element; wk.pred = -1; wk.last = -1; }
         }
         }
         if (SPLIT && !from_seed && element == tgt_el) {  // (tgt_el = -1: no target)
@@ -635,7 +717,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 // line, its exit edge and the previous record — its code; the generic step's record (every track's first one,
                 // refusals) keeps its own end points in the side list.
                 if (my_chunk >= 0) {
-                    if (r == 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane);
+                    if (r == 0) row_el = march_stage_args()->element + stage_slot(my_chunk, 0, lane_o);
                     int32_t word = wk.last + 1;
                     if (__builtin_expect(res != kWalkEmit, 0)) {
                         const RT_K DStage *sk = march_stage_args();
@@ -662,7 +744,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             } else if (my_chunk >= 0) {
                 if (r == 0) {  // per-lane addresses of the chunk's row 0, kept in VGPRs (the staging pointers are
                                // SGPR tuples that do not survive the generic branch unspilled)
-                    const int64_t o0 = stage_slot(my_chunk, 0, lane);
+                    const int64_t o0 = stage_slot(my_chunk, 0, lane_o);
                     const RT_K DStage *sk = march_stage_args();
                     row_qx = sk->qx + o0; row_qy = sk->qy + o0; row_el = sk->element + o0;
                 }
@@ -674,7 +756,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 row_qx[r * 16] = qx; row_qy[r * 16] = qy;
                 row_el[r * 16] = derived ? element + 1 : -(element + 1);
                 if (__builtin_expect(!derived, 0)) {
-                    const int64_t o = stage_slot(my_chunk, r, lane);
+                    const int64_t o = stage_slot(my_chunk, r, lane_o);
                     const RT_K DStage *sk = march_stage_args();
                     sk->px[o] = px; sk->py[o] = py;
                 }
@@ -758,9 +840,33 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             if (st == RT_TRACK_OK && !isapprox_s(t.ell[u], sum_ell, prm.rtol)) st = RT_TRACK_LENGTH_MISMATCH;
             if (sum_check_is_marginal(t.ell[u], sum_ell, prm.rtol, i)) atomicAdd(march_ctl() + kCtlNearRtol, 1ull);
         }
-        counts[u] = i;
-        status[u] = st;
-        if (TOPO) { t.cnt_slot[slot] = i; if (FUSE) t.w_slot[slot] = w; }  // (k_materialise reads its units' counts and weights in slot order; w: δs of the track's angle, loaded at the start — two dependent loads here were the tail of every wave, the last one's included)
+        // PHASE 1 (k_first): the lane marched with exact steps until a cheap step became possible — behind its first record, as a
+        // rule — and goes on in k_cheap (its state: DLean); a lane whose track ended or failed before that ENDS here.  (The exact
+        // state, kLnExact, is for a lane that is to go on in k_serve without a cheap step: not used by this kernel's loop.)
+        bool fin = true;
+        if (PHASE == 1 && st == RT_TRACK_OK && (fl & kFlCheap)) {
+            fin = false;
+            const bool cheap = (fl & kFlCheap) != 0;
+            ln.i[slot] = i; ln.it[slot] = it; ln.word[slot] = last_word;
+            ln.fl[slot] = (int32_t)(fl & (kFlCheap | kFlUsed)) | (ts.apos ? kLnApos : 0) | (cheap ? 0 : kLnExact);
+            if (cheap) {
+                ln.pred[slot] = ts.pred; ln.last[slot] = ts.last; ln.sp[slot] = ts.sp; ln.sn[slot] = ts.sn;
+                ln.ttP[slot] = ttP; ln.ttN[slot] = ttN; ln.ttp[slot] = ttp; ln.dprev[slot] = dprev;
+            } else {
+                ln.lqx[slot] = lqx; ln.lqy[slot] = lqy; ln.prev_el[slot] = prev_element; ln.wk_last[slot] = wk.last;
+            }
+            const unsigned long long qm = __ballot(!cheap);
+            if (!cheap) {  // (k_serve starts behind this kernel: its end publishes the state)
+                const int L = __ffsll((long long)qm) - 1;
+                int32_t b0 = 0;
+                if (lane == L) b0 = atomicAdd((int32_t *)&ln.qctl[0], (int32_t)__popcll(qm));
+                ln.queue[__shfl(b0, L) + (int32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (int32_t)slot;
+            }
+        } else if (PHASE == 1) {
+            ln.fl[slot] = kLnFinal;
+        }
+        if (fin) { counts[u] = i; status[u] = st; }
+        if (TOPO) { if (fin) t.cnt_slot[slot] = i; if (FUSE && PHASE != 2) t.w_slot[slot] = w; }  // (k_materialise reads its units' counts and weights in slot order; w: δs of the track's angle, loaded at the start — two dependent loads here were the tail of every wave, the last one's included)
         {
             // What the wave leaves for the call: its records into the sum of its tile of uids (two-phase calls: the scan then needs no
             // pass over the counts to form the tile sums), and the per-call statistics (rt_last_stats) — records the generic step
@@ -784,11 +890,12 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 RT_G int32_t *line = acc + (size_t)t0 * kTileAccStride;
                 // (a wave's lanes are 64 consecutive uids — one tile — except where the batch's partial last wave of uids was packed
                 //  into the march order)
+                const int32_t i_end = fin ? i : 0;  // (a lane that goes on in another kernel is counted where it ends)
                 if (__ballot(tile != t0) == 0) {
-                    const unsigned long long ws = wave_sum(i);
-                    if (first) atomicAdd((int32_t *)line, (int32_t)ws);
-                } else {
-                    atomicAdd((int32_t *)(acc + (size_t)tile * kTileAccStride), (int32_t)i);
+                    const unsigned long long ws = wave_sum(i_end);
+                    if (first && ws) atomicAdd((int32_t *)line, (int32_t)ws);
+                } else if (i_end) {
+                    atomicAdd((int32_t *)(acc + (size_t)tile * kTileAccStride), (int32_t)i_end);
                 }
                 if (first && ng) atomicAdd((int32_t *)(line + 1), (int32_t)ng);
                 if (first && ne) atomicAdd((int32_t *)(line + 2), (int32_t)ne);
@@ -803,6 +910,8 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         }
     }
     }  // slot < t.n
+    if (PHASE != 2) break;
+    }  // for (;;): k_serve's claims
     if (FUSE) {
         __syncthreads();
         for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) {
@@ -822,14 +931,22 @@ namespace rtx {
 // of `volumes` does not fit and for a wide k; builds with -DRT_EXPERIMENTAL add the two-pass march (count / fill).
 int launch_march(int mode, int waves, bool split, bool widek, bool topo, unsigned blocks, size_t smem, hipStream_t s, const rt::DMesh &m,
                  const rt::DTracks &t, const rt::DParams &prm, int32_t *counts, int32_t *status, const int64_t *offsets, const rt::DOut &out,
-                 const rt::DStage &stg, unsigned long long *fail_info, const rt::DSplit &sp) {
-    auto go = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK, bool TOPO>() -> int {
+                 const rt::DStage &stg, unsigned long long *fail_info, const rt::DSplit &sp, int phase, const rt::DLean *lean) {
+    const rt::DLean ln = lean ? *lean : rt::DLean{};
+    auto go = [&]<int MODE, int WAVES, bool SPLIT, bool WIDEK, bool TOPO, int PHASE = 0>() -> int {
         if (smem > 48 * 1024)
-            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK, TOPO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK, TOPO>), dim3(blocks), dim3(64 * WAVES), smem, s, m, t, prm, counts, status,
-                           offsets, out, stg, fail_info, sp);
+            RT_HIP(hipFuncSetAttribute((const void *)rt::k_march<MODE, WAVES, SPLIT, WIDEK, TOPO, PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((rt::k_march<MODE, WAVES, SPLIT, WIDEK, TOPO, PHASE>), dim3(blocks), dim3(64 * WAVES), smem, s, m, t, prm, counts, status,
+                           offsets, out, stg, fail_info, sp, ln);
         return RT_SUCCESS;
     };
+    if (mode == rt::kStage && phase != 0) {  // the lean plan's k_first (1) / k_serve (2): whole tracks, cheap steps
+        if (!lean || !topo || split || widek) { set_error("k_march: phase %d needs the two-phase whole-track march", phase); return RT_ERR_INVALID; }
+        if (phase == 1 && waves == 4) return go.template operator()<rt::kStage, 4, false, false, true, 1>();
+        if (phase == 1 && waves == 6) return go.template operator()<rt::kStage, 6, false, false, true, 1>();
+        if (phase == 2 && waves == 4) return go.template operator()<rt::kStage, 4, false, false, true, 2>();
+        if (phase == 2 && waves == 6) return go.template operator()<rt::kStage, 6, false, false, true, 2>();
+    }
     if (mode == rt::kStage) {
         if (topo && !split && !widek && waves == 4) return go.template operator()<rt::kStage, 4, false, false, true>();
         if (topo && !split && !widek && waves == 6) return go.template operator()<rt::kStage, 6, false, false, true>();

@@ -171,6 +171,8 @@ void free_mesh(rt_mesh *m) {
     m->x.release(); m->y.release(); m->cn.release(); m->ncp.release(); m->ncd.release();
     m->gstart.release(); m->gnode.release(); m->c3start.release(); m->c3node.release(); m->c3x.release(); m->c3y.release(); m->fan.release(); m->wrec.release(); m->adjr.release(); m->trec.release(); m->etab.release(); m->geo.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    for (hipEvent_t &e : m->side_ev) if (e) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -415,6 +417,11 @@ static rt_mesh *mesh_create_impl(int32_t device, const double *x, const double *
         return nullptr;
     }
     m->stream = m->own_stream;
+    // (the lean plan's k_serve runs beside k_cheap on a second stream; without it, behind k_cheap)
+    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess) m->side_stream = nullptr;
+    for (hipEvent_t &e : m->side_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    if (!m->side_ev[0] || !m->side_ev[1]) { if (m->side_stream) (void)hipStreamDestroy(m->side_stream); m->side_stream = nullptr; }
     if (build_mesh(m, x, y, n_nodes, cell_nodes, n_cells, node_cells_ptrs, node_cells_data, bb) != RT_SUCCESS) return nullptr;
     // development knob: RT_OPTIONS="name=value,name=value" applies rt_set_option at creation
     if (const char *env = getenv("RT_OPTIONS")) {
@@ -481,6 +488,9 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "mat_kernel")) { mesh->mat_kernel = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "march_waves")) { mesh->march_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
+    if (!strcmp(name, "lean")) { mesh->lean = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
+    if (!strcmp(name, "serve_blocks")) { mesh->serve_blocks = (int)value; return RT_SUCCESS; }
+    if (!strcmp(name, "cheap_per_cu")) { mesh->cheap_per_cu = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "timing")) { mesh->timing = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "async")) { mesh->async_calls = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "pool_chunks_hint")) { mesh->pool_chunks_hint = value; return RT_SUCCESS; }
@@ -745,6 +755,9 @@ struct SegmentizeCall {
     bool do_compact = true;   // the call writes the 44-B records
     bool split = false;       // track pieces (DSplit)
     bool topo = false;        // cheap steps: the two-phase march
+    bool lean = false;        // ... in three kernels: k_first, k_cheap, k_serve (DLean)
+    int cheap_waves = 4;      // waves per workgroup of k_cheap
+    rt::DLean dl{};
     int fuse_waves = 4;
     size_t hist_bytes = 0, fuse_smem = 0;
     const int32_t *corder = nullptr;  // compaction order of the whole-track waves
@@ -884,6 +897,16 @@ struct SegmentizeCall {
         topo = m->single_pass && m->topo && m->topo_available && m->d.walk_ok && !split && !widek && n > 0 && fuse && tiny_step > 0 &&
                tiny_step <= m->topo_tiny_max && (m->topo == 2 || 10 * m->n_records_topo >= 9 * m->n_records_walk);
         t->last_topo = topo ? 1 : 0;
+        // The lean plan: the cheap loop in a kernel of its own at four waves per SIMD (16 per CU) — as many workgroups per CU as
+        // LDS copies of `volumes` fit: 4 x 4 waves, 2 x 8 or 1 x 16
+        lean = false;
+        if (topo && m->lean && !t->lean_gave_up) {
+            for (int cw : {4, 8, 16}) {
+                const size_t per = hist_bytes + (size_t)cw * rt::kMaxChunks * sizeof(int32_t);
+                if ((size_t)(16 / cw) * per <= 158 * 1024) { lean = true; cheap_waves = cw; break; }
+            }
+        }
+        t->last_lean = lean ? m->lean : 0;
         if (split) {
             sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
             sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
@@ -933,10 +956,43 @@ struct SegmentizeCall {
     }
 
     int march(int mode, int waves, bool pieces, bool wide, bool cheap, unsigned blocks, size_t smem, const rt::DTracks &tracks,
-              const rt::DStage &stage, const int64_t *offsets = nullptr) {
+              const rt::DStage &stage, const int64_t *offsets = nullptr, int phase = 0, hipStream_t on = nullptr) {
         t->last_march_waves = waves; t->last_split = std::max(t->last_split, pieces ? 1 : 0); t->last_widek = wide ? 1 : 0;
-        return launch_march(mode, waves, pieces, wide, cheap, blocks, smem, s, m->d, tracks, prm, t->counts.p, t->status.p, offsets, out,
-                            stage, d_fail, sp);
+        return launch_march(mode, waves, pieces, wide, cheap, blocks, smem, on ? on : s, m->d, tracks, prm, t->counts.p, t->status.p, offsets, out,
+                            stage, d_fail, sp, phase, phase ? &dl : nullptr);
+    }
+
+    // The lean plan's three kernels (DLean): k_first on the call's stream, then k_cheap — and k_serve behind it on the same stream
+    // ("lean" 1) or beside it on the mesh's second stream ("lean" 2: it starts when k_first has ended and ends when k_cheap has and
+    // the queue is empty; the call's stream waits for it before the scan)
+    int march_lean() {
+        const unsigned blocks1 = (unsigned)((n_waves + fuse_waves - 1) / fuse_waves);
+        if (int rc = march(rt::kStage, fuse_waves, false, false, true, blocks1, fuse_smem, d_whole, stg, nullptr, 1)) return rc;
+        const bool beside = m->lean == 2 && m->side_stream;
+        if (beside) {
+            RT_HIP(hipEventRecord(m->side_ev[0], s));
+            RT_HIP(hipStreamWaitEvent(m->side_stream, m->side_ev[0], 0));
+        }
+        size_t smem_c = hist_bytes + (size_t)cheap_waves * rt::kMaxChunks * sizeof(int32_t);
+        {
+            // A batch of one residency round or less: as many workgroups per CU as it takes to use every CU, not as many as fit —
+            // the dispatcher fills a CU before it moves on, and 510 workgroups at four per CU leave half the chip idle.  (LDS is the
+            // one resource a launch can ask more of than it needs.)
+            const int fit = 16 / cheap_waves;
+            int per_cu = (int)std::min<int64_t>(fit, (dl.n_cheap_wgs + m->n_cus - 1) / std::max(1, m->n_cus));
+            if (m->cheap_per_cu > 0) per_cu = std::min(fit, m->cheap_per_cu);
+            per_cu = std::max(1, per_cu);
+            if (per_cu < fit) smem_c = std::max(smem_c, (size_t)(158 * 1024 / per_cu) & ~(size_t)255);
+            smem_c = std::min<size_t>(smem_c, (size_t)m->lds_per_block);
+        }
+        if (int rc = launch_cheap(cheap_waves, (unsigned)dl.n_cheap_wgs, smem_c, s, m->d, d_whole, prm, t->counts.p, t->status.p, out, stg, d_ctl, dl)) return rc;
+        const unsigned blocks2 = (unsigned)std::max(1, m->serve_blocks > 0 ? m->serve_blocks : 64);
+        if (int rc = march(rt::kStage, fuse_waves, false, false, true, blocks2, fuse_smem, d_whole, stg, nullptr, 2, beside ? m->side_stream : s)) return rc;
+        if (beside) {
+            RT_HIP(hipEventRecord(m->side_ev[1], m->side_stream));
+            RT_HIP(hipStreamWaitEvent(s, m->side_ev[1], 0));
+        }
+        return RT_SUCCESS;
     }
 
     // ---- staged single-pass march: the pool is sized from the Cauchy–Crofton estimate (or from what the previous call needed)
@@ -977,6 +1033,14 @@ struct SegmentizeCall {
             RT_HIP(t->gelement.reserve(slots));
             RT_HIP(t->cowner.reserve((size_t)want));
             t->pool_chunks = want;
+        }
+        if (lean) {
+            const size_t ns = (size_t)n_waves * 64;
+            if (t->lean_i.cap < 9 * ns + 1024) {
+                RT_HIP(t->lean_i.reserve(9 * ns + 1024));
+                RT_HIP(t->lean_d.reserve(8 * ns));
+                t->lean_q_clean = false;
+            }
         }
         if (topo && side_want > t->side_cap) {
             const size_t ne = (size_t)std::min<int64_t>(side_want, 0x7ffffff0);
@@ -1032,6 +1096,23 @@ struct SegmentizeCall {
         RT_HIP(hipMemsetAsync(t->dbg.p, 0, sizeof(unsigned long long) * 4 * std::max<int64_t>(1, n_waves), s));
         stg.dbg = t->dbg.p;
 #endif
+        if (lean) {
+            const size_t ns = (size_t)n_waves * 64;
+            int32_t *ip = t->lean_i.p;
+            double *dp = t->lean_d.p;
+            dl.pred = as_global(ip); dl.last = as_global(ip + ns); dl.i = as_global(ip + 2 * ns); dl.it = as_global(ip + 3 * ns);
+            dl.fl = as_global(ip + 4 * ns); dl.word = as_global(ip + 5 * ns); dl.prev_el = as_global(ip + 6 * ns); dl.wk_last = as_global(ip + 7 * ns);
+            dl.queue = as_global(ip + 8 * ns); dl.dump = as_global(ip + 9 * ns);
+            dl.sp = as_global(dp); dl.sn = as_global(dp + ns); dl.ttP = as_global(dp + 2 * ns); dl.ttN = as_global(dp + 3 * ns);
+            dl.ttp = as_global(dp + 4 * ns); dl.dprev = as_global(dp + 5 * ns); dl.lqx = as_global(dp + 6 * ns); dl.lqy = as_global(dp + 7 * ns);
+            dl.qctl = as_global(reinterpret_cast<int32_t *>(d_ctl + rt::kLeanCtl));
+            dl.n_cheap_wgs = (int32_t)((n_waves + cheap_waves - 1) / cheap_waves);
+            dl.pad_ = 0;
+            if (!t->lean_q_clean || attempt > 0) {  // (k_serve leaves every entry it consumed at -1: clean again after a complete call)
+                RT_HIP(hipMemsetAsync(t->lean_i.p + 8 * ns, 0xff, ns * sizeof(int32_t), s));
+                t->lean_q_clean = true;
+            }
+        }
         stg_pieces = stg;
         d_whole = t->d;
         {
@@ -1074,7 +1155,8 @@ struct SegmentizeCall {
         }
         if (n > 0 && !split) {  // whole tracks
             int rc;
-            if (topo) rc = march(rt::kStage, fuse_waves, false, false, true, (unsigned)((n_waves + fuse_waves - 1) / fuse_waves), fuse_smem, d_whole, stg);
+            if (topo && lean) rc = march_lean();
+            else if (topo) rc = march(rt::kStage, fuse_waves, false, false, true, (unsigned)((n_waves + fuse_waves - 1) / fuse_waves), fuse_smem, d_whole, stg);
             else if (fuse) rc = march(rt::kStage, fuse_waves, false, false, false, (unsigned)((n_waves + fuse_waves - 1) / fuse_waves), fuse_smem, d_whole, stg);
             else rc = march(rt::kStage, 1, false, widek, false, (unsigned)n_waves, one_wave_smem, d_whole, stg);
             if (rc) return rc;
@@ -1123,6 +1205,14 @@ struct SegmentizeCall {
     // What an attempt may leave to repair — outputs that were too small, fused volumes that counted records twice — and whether
     // the call is complete (kDone), runs again with larger pools (kRetry) or with whole tracks (kRestartWhole); < 0: error
     int after_attempt(int attempt) {
+        if (lean && reinterpret_cast<const int32_t *>(h_res + rt::kLeanCtl)[3] != 0) {
+            // k_serve ended without its work (it never saw k_cheap finish): not a result — this handle marches with the one-kernel plan
+            t->lean_gave_up = true; t->lean_q_clean = false; t->marg_clean = false;
+            if (attempt >= 3) { set_error("rt_segmentize: the lean plan's queue was not served"); return RT_ERR_HIP; }
+            RT_HIP(hipStreamSynchronize(s));
+            choose_plan();
+            return kRetry;
+        }
         const bool pools_ok = !cur[1] && !cur[3];
         if (do_compact && pools_ok && total > out.cap) {
             // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
@@ -1173,6 +1263,7 @@ struct SegmentizeCall {
             return kDone;
         }
         t->marg_clean = false;  // (a void attempt may have left entries in the list of tracks to sum exactly)
+        t->lean_q_clean = false;
         if (attempt >= 3) { set_error("staging pool / side list overflow persists (%d chunks, %d entries needed)", cur[0], cur[2]); return RT_ERR_HIP; }
         if (cur[1]) want = (int64_t)cur[0] + cur[0] / 8 + 64;  // the cursor kept counting: this is what the march needs
         if (cur[3]) side_want = (int64_t)cur[2] + cur[2] / 8 + 1024;
@@ -1260,6 +1351,7 @@ struct SegmentizeCall {
         t->n_near_rtol = (int64_t)h_res[rt::kCtlNearRtol];
         t->n_exact_tally = (int64_t)h_res[rt::kCtlExactTally];
         t->n_restarts = m->single_pass ? (int64_t)h_res[rt::kCtlRestarts] : 0;
+        t->n_lean_queued = lean ? (int64_t)reinterpret_cast<const int32_t *>(h_res + rt::kLeanCtl)[0] : 0;
         t->n_failed = (int64_t)fi[0];
         t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
         t->first_failed_status = 0;
@@ -1513,6 +1605,8 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 18) stats[18] = t->n_near_rtol;
     if (n > 19) stats[19] = t->n_restarts;
     if (n > 20) stats[20] = t->last_topo ? t->n_exact_tally : 0;
+    if (n > 21) stats[21] = t->last_lean;      // the lean plan of the last call (0: the march in one kernel)
+    if (n > 22) stats[22] = t->n_lean_queued;  // ... and the lanes k_serve finished
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
         stats[7] = b(t->in_arena) + b(t->cnt_slot) + b(t->off_slot) + b(t->w_slot) +

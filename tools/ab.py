@@ -83,7 +83,7 @@ def run_here(a):
             for x in (off, st, *[recs[k] for k in ("px", "py", "qx", "qy", "ell", "element") if k in recs]): h.update(np.ascontiguousarray(x).tobytes())
             s = dt.stats()
             print(tag, f": {total} segments, {best:.4f} ms/step, march {med('march'):.4f} scan {med('scan'):.4f} compact {med('compact'):.4f} volumes {med('volumes'):.4f} | "
-                  f"records sha {h.hexdigest()[:12]} volumes sum {float(vol.sum()):.15e} cheap {s['cheap_records']} generic {s['generic_records']} from lengths {s['records_tallied_from_lengths']} "
+                  f"records sha {h.hexdigest()[:12]} volumes sum {float(vol.sum()):.15e} cheap {s['cheap_records']} generic {s['generic_records']} from lengths {s['records_tallied_from_lengths']} queued {s.get('lean_queued', 0)} "
                   f"held {s['device_bytes'] / 1e9:.3f} GB", flush=True)
         else:
             G, nc = a.groups, tg.mesh.num_cells
