@@ -20,10 +20,11 @@ every rank (direct sends and receives into the final buffers, ``distributed.Segm
 timed region and always reported beside it (``allgather.ms``, ``segments_per_s_including_allgather``); rank 0 then
 runs the whole problem alone (``single_gpu_same_workload``) so that the speed-up is measured inside one run.
 
-The JSON line also carries ``roofline`` (the record-writing kernel — the one that moves the per-segment bytes: algorithmic
-bytes ÷ HIP-event duration against the 8 TB/s HBM peak; ``pipeline_frac``: the same for the whole step; ``march``: the march's
-own limits — latency / issue — with real bytes by counters; ``traffic`` only when the committed PMC summary was taken from the
-very library that is running), ``latency`` (p50/p95 of single steps), ``e2e`` (the costs of the
+The JSON line also carries ``roofline`` (``definition_version`` 3: the DOMINANT kernel by HIP-event time — the longer of march and
+record kernel: SURVEY §8(d)'s algorithmic bytes per launch ÷ its duration against the 8 TB/s HBM peak; ``record_kernel``: the kernel
+that writes the 44-B records with its own 48 B per segment, whatever its share; ``pipeline_frac``: 45 B per segment ÷ the whole
+step; ``march``: the march's own limits — latency / issue — with real bytes by counters; ``traffic`` only when the committed PMC
+summary was taken from the very library that is running), ``latency`` (p50/p95 of single steps), ``e2e`` (the costs of the
 boundary around the step: mesh preparation, track upload, record download) and, at N=1, ``cpu_baseline`` (the
 oracle — a C port of the reference's algorithm — timed on the host cores of the same box).
 """
@@ -51,7 +52,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-lev
 BYTES_PER_SEGMENT = {"march": 45.0, "compact": 64.0, "scan": 0.0}
 BYTES_PER_SEGMENT_TWO_PHASE = {"march": 45.0, "compact": 48.0, "scan": 0.0}
 STEP_BYTES_PER_SEGMENT = 45.0  # the whole step, by the same definition (what one segmentize! must at least move)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06", "pmc_summary.json")
 
 WORKLOADS = {
     "c3": dict(mesh="pincell.msh", n_azim=128, delta=1e-3, name="BASELINE configs[2]: demo/pincell.msh, nφ=128, δ=1e-3"),
@@ -77,11 +78,11 @@ def pmc_traffic():
     try:
         d = json.load(open(PMC_SUMMARY))
         if d.get("lib_sha256") != lib_sha256():
-            return {}, "profiles/r05/pmc_summary.json was taken from another build of the library"
+            return {}, "profiles/r06/pmc_summary.json was taken from another build of the library"
         global PMC_KERNELS
         PMC_KERNELS = d["kernels"]
         return ({k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in d["kernels"].items()
-                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r05/pmc_summary.json (same library, sha256 match)")
+                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v}, "profiles/r06/pmc_summary.json (same library, sha256 match)")
     except Exception as e:
         return {}, "no PMC summary: %r" % (e,)
 
@@ -94,7 +95,10 @@ def kernel_names(stats):
     cheap = stats.get("cheap_records", 0) > 0  # the TOPO instantiation (cheap steps) ran
     return {"march": "rt::k_march<2, %d, %s, %s, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
                                                            "true" if cheap else "false"),
-            "compact": "rt::k_materialise_lin" if cheap else "rt::k_compact3<%s>" % ("true" if sp else "false"),
+            # (the record kernel by what the call launched — rt_last_stats[23]: a two-phase call falls back to k_materialise for
+            #  arrays of 2^29 records or with option "mat_kernel" 1)
+            "compact": (stats.get("record_kernel") or ("rt::k_materialise_lin" if cheap else "rt::k_compact3")) +
+                       ("<%s>" % ("true" if sp else "false") if (stats.get("record_kernel") or ("" if cheap else "rt::k_compact3")) == "rt::k_compact3" else ""),
             "scan": "rt::k_scan_fused" if cheap else "rt::k_scan_write"}
 
 
@@ -579,8 +583,8 @@ def _main(real_stdout):
                 if rank == 0:
                     ms_step = t_max / args.steps * 1e3
                     per_k = {key: kern[key] / args.steps for key in ("march", "compact")}
-                    dom = "compact"  # (the record-writing kernel: the one that moves the per-segment bytes)
-                    bps_fb = bytes_per_segment(stats)
+                    dom = "march" if per_k["march"] >= per_k["compact"] else "compact"  # (the dominant kernel by HIP-event time)
+                    bps_fb = dict(bytes_per_segment(stats), march=STEP_BYTES_PER_SEGMENT)
                     ach = bps_fb[dom] * local_total / (per_k[dom] * 1e-3) / 1e9 if per_k[dom] > 0 else 0.0
                     fb = {"metric": "segments/sec (whole node)", "value": global_segments * args.steps / t_max, "unit": "segments/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -589,7 +593,7 @@ def _main(real_stdout):
                           "config": {"workload": "%s; FIXED global problem split over %d GPUs (strong scaling)" % (wl["name"], world),
                                      "tracks_global": int(tg.n_total_tracks), "segments_global": int(global_segments),
                                      "failed_tracks": failed_tracks},
-                          "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "roofline": {"definition_version": 3, "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_segment": bps_fb[dom],
                                        "segments_per_launch": int(local_total), "kernel_ms_avg": per_k[dom]},
                           "kernel_ms": {k: v / args.steps for k, v in kern.items()}, "per_rank": per_rank,
@@ -748,7 +752,14 @@ def _main(real_stdout):
         # bytes and VALU issue by counters when the committed PMC passes belong to this library), never priced with bytes it does not move.
         rec_k = next(k for k in per_kernel if k["kernel"] == names["compact"])
         march_k = next(k for k in per_kernel if k["kernel"] == names["march"])
-        achieved = rec_k["achieved_GBs"]
+        # definition_version 3 (round 6): `roofline` is the DOMINANT kernel by HIP-event time again (rounds 1-4; round 5 named the
+        # record kernel whatever its share) — SURVEY §8(d)'s 45 B per segment x the segments of a launch ÷ that kernel's duration when
+        # it is the march (which stages 4 B per segment: `march` says what it is bound by), the record kernel's own 48 B when it is
+        # the record kernel; the record kernel always has its own object, `roofline.record_kernel`.
+        dom_is_march = march_k["ms_avg"] >= rec_k["ms_avg"]
+        dom_k = march_k if dom_is_march else rec_k
+        dom_bps = STEP_BYTES_PER_SEGMENT if dom_is_march else rec_k["bytes_per_segment"]
+        achieved = dom_bps * local_total / (dom_k["ms_avg"] * 1e-3) / 1e9 if dom_k["ms_avg"] > 0 else 0.0
         step_GBs = STEP_BYTES_PER_SEGMENT * global_segments / (ms_per_step * 1e-3) / 1e9
         tr_all = [k["traffic"] for k in per_kernel]
         traffic_ratio = (sum(tr_all) / (STEP_BYTES_PER_SEGMENT * local_total)) if all(t is not None for t in tr_all) else None
@@ -797,11 +808,16 @@ def _main(real_stdout):
                 "library_sha256": lib_sha256(),
             },
             "roofline": {
-                "bound": "hbm", "kernel": rec_k["kernel"],
+                "definition_version": 3,
+                "bound": "hbm", "kernel": dom_k["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": rec_k["traffic"], "traffic_source": traffic_src,
-                "bytes_per_segment": rec_k["bytes_per_segment"], "segments_per_launch": int(local_total),
-                "kernel_ms_avg": rec_k["ms_avg"],
+                "traffic": dom_k["traffic"], "traffic_source": traffic_src,
+                "bytes_per_segment": dom_bps, "segments_per_launch": int(local_total),
+                "kernel_ms_avg": dom_k["ms_avg"],
+                "record_kernel": {"kernel": rec_k["kernel"], "bound": "hbm", "achieved": rec_k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": rec_k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": rec_k["traffic"],
+                                  "bytes_per_segment": rec_k["bytes_per_segment"], "kernel_ms_avg": rec_k["ms_avg"],
+                                  "note": "the kernel that moves SURVEY §8(d)'s bytes: its own 4 B read + 44 B written per segment ÷ its HIP-event time"},
                 "pipeline_frac": step_GBs / (HBM_PEAK_GBS * world),
                 "traffic_over_algorithmic": traffic_ratio,
                 "march": march_report,
@@ -809,9 +825,9 @@ def _main(real_stdout):
                              "bytes_per_segment": STEP_BYTES_PER_SEGMENT, "ms_per_step": ms_per_step,
                              "traffic_over_algorithmic": traffic_ratio,
                              "note": "whole step: algorithmic bytes (45 B/segment) ÷ ms_per_step against the peak of the GPUs in use"},
-                "note": "kernel = the record-writing kernel (the one that moves SURVEY §8(d)'s bytes): bytes_per_segment x segments per "
-                        "launch ÷ its HIP-event time (DESIGN.md §4); pipeline_frac = 45 B/segment ÷ ms_per_step; the march is FP64 "
-                        "traversal bound by its per-track dependent chain, see `march`",
+                "note": "kernel = the longer of march and record kernel by HIP-event time (definition_version 3); the march is priced with "
+                        "SURVEY §8(d)'s 45 B/segment (it stages 4 B/segment and is bound by its per-track dependent chain: see `march`), the record "
+                        "kernel with its own 48 B (`record_kernel`); pipeline_frac = 45 B/segment ÷ ms_per_step",
             },
             "kernels": per_kernel,
             "kernel_ms": {k: v / args.steps for k, v in kern.items()},

@@ -280,6 +280,8 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
  * iteration bound reached the iteration cap; stats[20] cheap records whose fill_volumes term was added from the record's own
  * length by the second kernel of the two-phase march (a short chord or a shallow crossing: the chord from the vertices' distances
  * would not be within 4e-11 of it — DESIGN.md §2).
+ * stats[21] the lean plan of the call's march (option "lean"; 0: one kernel), stats[22] the lanes its k_serve finished; stats[23] the
+ * kernel that wrote the call's records (1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows).
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 

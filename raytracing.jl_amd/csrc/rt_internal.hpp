@@ -425,6 +425,7 @@ struct rt_tracks {
     bool force_unsplit = false;  // a track reached MAX_ITER segments in split mode: this track set marches whole from now on
     int32_t last_topo = 0;  // 1: the last call marched with cheap steps
     int32_t last_lean = 0;  // ... in three kernels (the option's value)
+    int32_t last_record_kernel = 0;  // which kernel wrote the last call's records: 0 none yet, 1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise (rows only)
     bool lean_gave_up = false, lean_q_clean = false;
     int64_t n_lean_queued = 0;
     DevBuf<int32_t> lean_i;   // DLean: the lanes' state (8 int arrays), the queue, the dump row

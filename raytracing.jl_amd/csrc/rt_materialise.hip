@@ -78,6 +78,38 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+// intersection(track.ABC, edge.ABC), src/intersection.jl:127-138, with ONE reciprocal for its two quotients.  The compiler's f64
+// division is v_div_scale x 2, v_rcp, two Newton steps (four FMAs), q0 = n·r, e = fma(−d, q0, n), v_div_fmas (= fma(e, r, q0) when
+// nothing was scaled), v_div_fixup (sign and special values): five of its eleven instructions depend on the denominator alone.
+// With |d|, |n| in [2^-200, 2^200] v_div_scale scales nothing and v_div_fixup changes nothing: the sequence below is then the
+// compiler's, operation for operation — the same bits.  A numerator that is exactly zero (an exit point ON x = 0 or y = 0) gives
+// n·r, which carries the quotient's sign.  `ok` = false: the caller takes the two full divisions (wave-uniformly).
+// Measured (round 6, profiles/r06/exp_shared_reciprocal.log, same box, records hash-identical): C3 0.1216 / 0.1197 / 0.1240 ms without,
+// 0.1236 / 0.1197 / 0.1240 with; C5 1.237 / 1.218 against 1.221 / 1.233 — nothing: the guards that keep it bit-identical (zero
+// numerators, exponent range, the wave-uniform fallback) cost what the two v_rcp_f64 and four v_div_scale_f64 save (44 -> 42
+// instructions of the iteration's ≈450), and the kernel spills (20 B of scratch).  Off; -DRT_LIN_SHARED_RCP=1 builds it.
+#ifndef RT_LIN_SHARED_RCP
+#define RT_LIN_SHARED_RCP 0
+#endif
+__device__ __forceinline__ bool lin_range_ok(double v) {
+    const uint32_t e = ((uint32_t)(__builtin_bit_cast(uint64_t, v) >> 52)) & 0x7ffu;
+    return (e - (1023u - 200u)) <= 400u;
+}
+__device__ __forceinline__ bool edge_exit_point_shared(double tA, double tB, double tC, double eA, double eB, double eC, double &qx, double &qy) {
+    const double a = tB * eA;
+    const double b = eB * tA;
+    const double det = a - b;
+    const double nx = tC * eB - eC * tB, ny = tA * eC - eA * tC;
+    double r = __builtin_amdgcn_rcp(det);
+    r = __builtin_fma(r, __builtin_fma(-det, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-det, r, 1.0), r);
+    const double x0 = nx * r, y0 = ny * r;
+    const double x1 = __builtin_fma(__builtin_fma(-det, x0, nx), r, x0), y1 = __builtin_fma(__builtin_fma(-det, y0, ny), r, y0);
+    qx = nx == 0.0 ? x0 : x1;
+    qy = ny == 0.0 ? y0 : y1;
+    return lin_range_ok(det) && (nx == 0.0 || lin_range_ok(nx)) && (ny == 0.0 || lin_range_ok(ny));
+}
+
 typedef double __attribute__((ext_vector_type(2))) lin_d2;
 typedef int32_t __attribute__((ext_vector_type(2))) lin_i2;
 typedef int32_t __attribute__((ext_vector_type(4))) lin_i4;
@@ -357,8 +389,20 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             const lin_i2 gl0 = *(const lin_i2 *)&s_trk[t0].goff, gl1 = *(const lin_i2 *)&s_trk[t1].goff;  // (goff, last)
             const int32_t g0 = gl0.x, g1 = gl1.x;
             double q0x, q0y, q1x, q1y;
+#if RT_LIN_SHARED_RCP
+            {
+                const bool ok0 = edge_exit_point_shared(ab0.x, ab0.y, c0, pre.e0A, pre.e0B, pre.e0C, q0x, q0y);
+                const bool ok1 = edge_exit_point_shared(ab1.x, ab1.y, c1, pre.e1A, pre.e1B, pre.e1C, q1x, q1y);
+                // (a word of 0 — no record — gathers entry 0 against whatever line: only lanes WITH a record count)
+                if (__builtin_expect(__ballot((w0 > 0 && !ok0) || (w1 > 0 && !ok1)) != 0, 0)) {
+                    edge_exit_point(ab0.x, ab0.y, c0, pre.e0A, pre.e0B, pre.e0C, q0x, q0y);
+                    edge_exit_point(ab1.x, ab1.y, c1, pre.e1A, pre.e1B, pre.e1C, q1x, q1y);
+                }
+            }
+#else
             edge_exit_point(ab0.x, ab0.y, c0, pre.e0A, pre.e0B, pre.e0C, q0x, q0y);  // src/intersection.jl:127-138
             edge_exit_point(ab1.x, ab1.y, c1, pre.e1A, pre.e1B, pre.e1C, q1x, q1y);
+#endif
             int32_t cell0 = (int32_t)((uint32_t)(w0 > 0 ? (w0 & kWordCode) - 1 : 0) / 3u) + 1;
             int32_t cell1 = (int32_t)((uint32_t)(w1 > 0 ? (w1 & kWordCode) - 1 : 0) / 3u) + 1;
             // records that keep their own end points (the generic step's): every track's first one from the table, the others

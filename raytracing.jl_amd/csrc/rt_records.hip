@@ -799,8 +799,10 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
     // (k_materialise_lin addresses the result arrays through 32-bit buffer offsets: arrays below 4 GB, i.e. 2^29 records)
     if (records && !rows && m->mat_kernel != 1 && out.cap < ((int64_t)1 << 29) - 64 && c.stg.side_cap > 0) {
         launch_materialise_lin(c.d_whole, t->status.p, c.stg, out, a, s, m->n_cus, 0);
+        if (tally) t->last_record_kernel = 3;
         return RT_SUCCESS;
     }
+    if (tally) t->last_record_kernel = rows && !records ? 4 : 2;
     if (records && rows)
         hipLaunchKernelGGL((rt::k_materialise<true, true>), dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
                            (const int64_t *)t->offsets.p, c.stg, out, a);
@@ -829,6 +831,7 @@ void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_r
 void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s) {
     const rt_tracks::CompactPlan &c = t->cplan;
     if (c.codes) { (void)launch_materialise(t, out, s, true, false, false, nullptr); return; }
+    t->last_record_kernel = 1;
     if (t->n > 0 && !c.split_all && c.n_whole_waves > 0)
         hipLaunchKernelGGL(rt::k_compact3<false>, dim3(4u * (unsigned)c.n_whole_waves), dim3(256), 0, s, c.d_whole,
                            (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p, c.stg, out, c.sp, c.corder);

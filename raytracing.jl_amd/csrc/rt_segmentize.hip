@@ -870,6 +870,7 @@ struct SegmentizeCall {
         t->sw_ell_valid = false;
         t->cplan = rt_tracks::CompactPlan{};
         t->last_split = 0;
+        t->last_record_kernel = 0;
         return RT_SUCCESS;
     }
 
@@ -1607,6 +1608,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 20) stats[20] = t->last_topo ? t->n_exact_tally : 0;
     if (n > 21) stats[21] = t->last_lean;      // the lean plan of the last call (0: the march in one kernel)
     if (n > 22) stats[22] = t->n_lean_queued;  // ... and the lanes k_serve finished
+    if (n > 23) stats[23] = t->last_record_kernel;  // 1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows only
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
         stats[7] = b(t->in_arena) + b(t->cnt_slot) + b(t->off_slot) + b(t->w_slot) +
