@@ -959,6 +959,49 @@ RT_HD __forceinline__ TopoTrack topo_track(bool mesh_on, double d_vertex, double
     return tt;
 }
 
+// ------------------------------------------------------------------ the Σℓ check -
+// The Σℓ check `isapprox(track.ℓ, sum(ℓ.(segments)); rtol)` (src/track.jl:171) is decided here (and in the CPU checker) with a
+// left-to-right sum; Julia's `sum` reassociates (pairwise blocks, @simd lanes), so its Σℓ can differ by a few ulp·n.  A
+// track whose |ℓ − Σℓ| lies within 64·ulp·n·max(ℓ, Σℓ) of the threshold rtol·max(ℓ, Σℓ) could get the other status there:
+// such tracks are counted (rt_last_stats) so that a caller knows when this cannot be pinned.
+// `abs_band`: an absolute widening of the band (the Σℓ chain below: n · a few ulp of the largest coordinate).
+RT_HD __forceinline__ bool sum_check_is_marginal(double ell, double sum, double rtol, int n, double band = 64.0, double abs_band = 0.0) {
+    const double big = fabs(ell) > fabs(sum) ? fabs(ell) : fabs(sum);
+    return fabs(fabs(ell - sum) - rtol * big) <= band * 1.1102230246251565e-16 * (double)(n > 1 ? n : 1) * big + abs_band;
+}
+
+// Σℓ of a track WITHOUT adding up its records (k_materialise_lin, round 5): the records of a track lie head to tail on its line —
+// p of a record IS the q before it, bit for bit — so Σ‖p_i − q_i‖ = ‖p_0 − q_0‖ + (q_last − q_0)·d, d = (cos ϕ, sin ϕ) the march's
+// direction, up to the roundings of n norms and their sum.  Only a record that keeps its OWN p (a generic step's, behind tiny steps)
+// breaks the chain; `chain_gap_term` is what such a record i contributes to the correction `gap` that `chain_sum` subtracts:
+//   * the signed gap (p_i − b_i)·d-wise in front of it (b_i = the exit point of the record before; a record that begins BEHIND that
+//     point — cells that overlap within the locate's tolerance — counts negative: its overlap is IN Σℓ),
+//   * and minus twice its own length if its two points are in the wrong order along d (order_intersection_points compares x
+//     coordinates, src/intersection.jl:151-159, which near ϕ = π/2 are equal to the last bit): such a record walks backwards, the
+//     projection subtracts its length where Σℓ adds it.
+// `chain_status` decides like the kernel: 2 = inside the band in which a sum in another order (or this chain's own error: the
+// exit points lie off the line by a few ulp of the coordinates, which a near-zero-length record turns into a first-order term —
+// `coord_max`) could decide the other way: k_finish sums those left to right; 1 = LENGTH_MISMATCH for sure; 0 = OK for sure.
+// Host twin: tests/host_march.hip drives these on the checker's records (tests/test_sum_chain_cpu.py, tools/fuzz_cpu.py).
+RT_HD __forceinline__ double chain_gap_term(double px, double py, double qx, double qy, double ell, double bx, double by, double dx, double dy) {
+    const double g = norm2(px - bx, py - by);
+    double acc = (px - bx) * dx + (py - by) * dy < 0.0 ? -g : g;
+    if ((qx - px) * dx + (qy - py) * dy < 0.0) acc -= 2.0 * ell;
+    return acc;
+}
+RT_HD __forceinline__ double chain_sum(double fpx, double fpy, double fqx, double fqy, double lqx, double lqy, double dx, double dy, double gap, int cnt) {
+    double S = cnt > 0 ? norm2(fpx - fqx, fpy - fqy) : 0.0;
+    if (cnt > 1) S += ((lqx - fqx) * dx + (lqy - fqy) * dy) - gap;
+    return S;
+}
+constexpr double kChainBands = 96.0;      // any-order sum against the left-to-right one: n·2^-53·Σ each; 96 hold the statistic's 64
+constexpr double kChainCoordUlps = 64.0;  // ... + n · this many ulp of the largest coordinate
+RT_HD __forceinline__ int chain_status(double L, double S, double rtol, int cnt, double coord_max) {
+    const double abs_band = kChainCoordUlps * 2.220446049250313e-16 * coord_max * (double)(cnt > 1 ? cnt : 1);
+    if (sum_check_is_marginal(L, S, rtol, cnt, kChainBands, abs_band)) return 2;
+    return isapprox_s(L, S, rtol) ? 0 : 1;  // src/track.jl:171-175
+}
+
 // --------------------------------------------------------------------- transport sweep -
 // 1 − e^{−τ} for τ >= 0 (rt_sweep: the attenuation factor of a segment), accurate to a few ulp over the whole range —
 // also where e^{−τ} ≈ 1 and 1 − e^{−τ} would cancel.  The device library's expm1 serves every argument (overflow,

@@ -233,14 +233,7 @@ __device__ __forceinline__ int32_t lean_chunk(const RT_K DStage *sk, int64_t w, 
     return old;
 }
 
-// The Σℓ check `isapprox(track.ℓ, sum(ℓ.(segments)); rtol)` (src/track.jl:171) is decided here (and in the CPU checker) with a
-// left-to-right sum; Julia's `sum` reassociates (pairwise blocks, @simd lanes), so its Σℓ can differ by a few ulp·n.  A
-// track whose |ℓ − Σℓ| lies within 64·ulp·n·max(ℓ, Σℓ) of the threshold rtol·max(ℓ, Σℓ) could get the other status there:
-// such tracks are counted (rt_last_stats) so that a caller knows when this cannot be pinned.
-__device__ __forceinline__ bool sum_check_is_marginal(double ell, double sum, double rtol, int n, double band = 64.0) {
-    const double big = fabs(ell) > fabs(sum) ? fabs(ell) : fabs(sum);
-    return fabs(fabs(ell - sum) - rtol * big) <= band * 1.1102230246251565e-16 * (double)(n > 1 ? n : 1) * big;
-}
+// (sum_check_is_marginal and the Σℓ chain of k_materialise_lin: rt_device.hpp — host and device)
 
 constexpr int kC3Pitch = kChunkRows + 4;  // doubles per track in a tile: slot 0 = carry, slots 1..32 = rows
 
@@ -251,6 +244,7 @@ struct DMat {
     const RT_G int32_t *corder;   // large batches: march waves in the order of their output addresses (as k_compact3)
     int64_t n_units;              // 4 per march wave
     double rtol;
+    double coord_max;             // largest |coordinate| of the mesh's bounding box (the Σℓ chain's absolute band)
     int32_t tally;                // 1: Σℓ + status (the call's first pass over the codes); 0: records / rows only
     int32_t force_exact;          // tests: every track takes k_finish's left-to-right sum
     int32_t marg_cap;

@@ -467,17 +467,11 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 if (a.tally && (gap0 || gap1)) {
                     const double d0x = s_trk[t0].g2[1], d0y = s_trk[t0].g2[2], d1x = s_trk[t1].g2[1], d1y = s_trk[t1].g2[2];
                     if (gap0) {
-                        const double g = norm2(p0x - b0x, p0y - b0y);
-                        double acc = (p0x - b0x) * d0x + (p0y - b0y) * d0y < 0.0 ? -g : g;
-                        if ((q0x - p0x) * d0x + (q0y - p0y) * d0y < 0.0) acc -= 2.0 * l0;
-                        atomicAdd(&s_gap[t0], acc);
+                        atomicAdd(&s_gap[t0], chain_gap_term(p0x, p0y, q0x, q0y, l0, b0x, b0y, d0x, d0y));
                         if (2 * m == gl0.y) { lin_d2 v; v.x = q0x; v.y = q0y; s_qlast[t0] = v; }  // ... and the chain's end, if it is the last record
                     }
                     if (gap1) {
-                        const double g = norm2(p1x - b1x, p1y - b1y);
-                        double acc = (p1x - b1x) * d1x + (p1y - b1y) * d1y < 0.0 ? -g : g;
-                        if ((q1x - p1x) * d1x + (q1y - p1y) * d1y < 0.0) acc -= 2.0 * l1;
-                        atomicAdd(&s_gap[t1], acc);
+                        atomicAdd(&s_gap[t1], chain_gap_term(p1x, p1y, q1x, q1y, l1, b1x, b1y, d1x, d1y));
                         if (2 * m + 1 == gl1.y) { lin_d2 v; v.x = q1x; v.y = q1y; s_qlast[t1] = v; }
                     }
                 }
@@ -616,14 +610,15 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             const double fx = s_trk[tl].g1[1], fy = s_trk[tl].g1[2], gx = s_trk[tl].g1[3], gy = s_trk[tl].g2[0];
             const lin_d2 ql = s_qlast[tl];
             // (the chain as a PROJECTION on the march direction: a last record that walks backwards may end behind the first one's q)
-            double S = cnt > 0 ? norm2(fx - gx, fy - gy) : 0.0;
-            if (cnt > 1) S += ((ql.x - gx) * s_trk[tl].g2[1] + (ql.y - gy) * s_trk[tl].g2[2]) - s_gap[tl];
+            const double S = chain_sum(fx, fy, gx, gy, ql.x, ql.y, s_trk[tl].g2[1], s_trk[tl].g2[2], s_gap[tl], cnt);
             const double L = s_trk[tl].g0[3];
-            // any-order sum against the left-to-right one: within cnt·2⁻⁵³·Σ; 96 bands hold the statistic's 64 (k_finish)
-            if (a.force_exact || sum_check_is_marginal(L, S, a.rtol, cnt, 96.0)) {
+            // (rt_device.hpp, chain_status: inside the band of what a sum in another order — or the chain's own error — could decide
+            //  differently, k_finish sums left to right)
+            const int cs = chain_status(L, S, a.rtol, cnt, a.coord_max);
+            if (a.force_exact || cs == 2) {
                 const int32_t e = atomicAdd((int32_t *)&a.marg[0], 1);
                 if (e < a.marg_cap) a.marg[1 + e] = (int32_t)slot;  // (marg_cap = every march slot: cannot overflow)
-            } else if (!isapprox_s(L, S, a.rtol)) {  // src/track.jl:171-175
+            } else if (cs == 1) {  // src/track.jl:171-175
                 const int32_t u = t.perm[slot];
                 if (status[u] == RT_TRACK_OK) {
                     status[u] = RT_TRACK_LENGTH_MISMATCH;

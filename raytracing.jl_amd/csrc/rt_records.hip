@@ -784,6 +784,7 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
     a.etab = m->d.etab; a.corder = as_global(c.corder);
     a.etab_bytes = (int32_t)(uint32_t)std::min<uint64_t>((uint64_t)3 * (uint64_t)m->n_cells * sizeof(rt::EdgeABC), 0xffffffffull);
     a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.tally = tally ? 1 : 0;
+    a.coord_max = std::max(std::max(fabs(m->d.bx0), fabs(m->d.bx1)), std::max(fabs(m->d.by0), fabs(m->d.by1)));
     a.force_exact = m->test_exact_sums; a.ctl = d_ctl; a.vacc = as_global(t->vacc.p);
     if (tally) {
         RT_HIP(t->marg.reserve((size_t)c.n_whole_waves * 64 + 1));

@@ -23,7 +23,7 @@
 
 namespace {
 
-struct Rec { double px, py, qx, qy, ell; int32_t element; };
+struct Rec { double px, py, qx, qy, ell; int32_t element; int32_t own; };  // own: a generic step's record (it keeps its own p)
 
 struct Result {
     std::vector<int64_t> offsets;
@@ -115,7 +115,7 @@ restart:
                 edge_exit_point(tA, tB, tC, e->A, e->B, e->C, qx, qy);
                 px = lqx; py = lqy;
                 ell = norm2(px - qx, py - qy);
-                out.push_back({px, py, qx, qy, ell, code / 3 + 1});
+                out.push_back({px, py, qx, qy, ell, code / 3 + 1, 0});
                 sum_ell += ell;
                 lqx = qx; lqy = qy;
                 ++i; it += kub; ++cnt[5];
@@ -172,7 +172,7 @@ restart:
         } else {
             ++cnt[0];
         }
-        out.push_back({px, py, qx, qy, ell, element + 1});
+        out.push_back({px, py, qx, qy, ell, element + 1, res == kWalkGeneric ? 1 : 0});
         sum_ell += ell;
         lqx = qx; lqy = qy;
         xpx = qx + sx; xpy = qy + sy;
@@ -273,6 +273,33 @@ void hostmarch_fetch(int64_t *offsets, int32_t *status, double *px, double *py, 
         px[i] = r.px; py[i] = r.py; qx[i] = r.qx; qy[i] = r.qy; ell[i] = r.ell; element[i] = r.element;
     }
     memcpy(stats, g_res.stats, sizeof(g_res.stats));
+}
+
+// The Σℓ check of k_materialise_lin on the records of the last hostmarch_run: per track, the chain (rt_device.hpp chain_gap_term /
+// chain_sum / chain_status — the very functions the kernel calls) over its records in march order, the gaps added left to right.
+// status_chain[u]: 0 OK, 1 LENGTH_MISMATCH, 2 inside the band (k_finish sums left to right); S_chain[u]: the chain's Σℓ;
+// S_exact[u]: the left-to-right sum of the records' lengths (what src/track.jl:171 compares, and what k_finish forms).
+void hostmarch_chain(int64_t n_tracks, const double *cs, const double *sn, const double *ell, double rtol, double coord_max,
+                     int32_t *status_chain, double *S_chain, double *S_exact) {
+    for (int64_t u = 0; u < n_tracks; ++u) {
+        const int64_t o = g_res.offsets[u], cnt = g_res.offsets[u + 1] - o;
+        double gap = 0.0, sum = 0.0;
+        for (int64_t i = 0; i < cnt; ++i) {
+            const Rec &r = g_res.recs[(size_t)(o + i)];
+            sum += r.ell;
+            if (i > 0 && r.own) {
+                const Rec &b = g_res.recs[(size_t)(o + i - 1)];
+                gap += rt::chain_gap_term(r.px, r.py, r.qx, r.qy, r.ell, b.qx, b.qy, cs[u], sn[u]);
+            }
+        }
+        double S = 0.0;
+        if (cnt > 0) {
+            const Rec &f = g_res.recs[(size_t)o], &l = g_res.recs[(size_t)(o + cnt - 1)];
+            S = rt::chain_sum(f.px, f.py, f.qx, f.qy, l.qx, l.qy, cs[u], sn[u], gap, (int)cnt);
+        }
+        S_chain[u] = S; S_exact[u] = sum;
+        status_chain[u] = rt::chain_status(ell[u], S, rtol, (int)cnt, coord_max);
+    }
 }
 
 // Host-only view of the preprocessing (no march): the per-record certificate fields, for tests.

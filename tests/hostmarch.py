@@ -41,6 +41,7 @@ def lib():
         L.hostmarch_bf16.argtypes = [_dp, C.c_int64, C.POINTER(C.c_uint16), _dp]
         L.hostmarch_one_minus_exp_neg.argtypes = [_dp, C.c_int64, _dp]
         L.hostmarch_one_minus_exp_neg_thin.argtypes = [_dp, C.c_int64, _dp]
+        L.hostmarch_chain.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _dp, _dp]
         L.hostmarch_topo.restype = C.c_int32
         L.hostmarch_topo.argtypes = [_dp, _dp, C.c_int32, _ip, C.c_int32, _dp, _ip] + [_dp] * 6
         _lib = L
@@ -143,3 +144,43 @@ def one_minus_exp_neg(tau, thin=False):
     f = lib().hostmarch_one_minus_exp_neg_thin if thin else lib().hostmarch_one_minus_exp_neg
     f(tau.ctypes.data_as(_dp), len(tau), out.ctypes.data_as(_dp))
     return out
+
+
+def chain(tg, rtol=None):
+    """The Σℓ check of ``k_materialise_lin`` (rt_device.hpp ``chain_*``) on the records of the LAST ``run(tg)``: per track the
+    chain's status (0 OK, 1 LENGTH_MISMATCH, 2 inside the band that k_finish decides with its left-to-right sum), the chain's Σℓ
+    and the left-to-right Σℓ of the records."""
+    n = len(tg.ell)
+    st = np.zeros(n, np.int32)
+    S, E = np.zeros(n), np.zeros(n)
+    cs, sn, ell = _f(tg.cos_phi), _f(tg.sin_phi), _f(tg.ell)
+    p = lambda a, t: a.ctypes.data_as(t)
+    lib().hostmarch_chain(n, p(cs, _dp), p(sn, _dp), p(ell, _dp), float(rtol if rtol is not None else 1.4901161193847656e-8),
+                          float(np.max(np.abs(tg.mesh.bb))), p(st, _ip), p(S, _dp), p(E, _dp))
+    return st, S, E
+
+
+def chain_check(tg, rtols=None):
+    """Does the chain decide as the reference's check (src/track.jl:171: isapprox(ℓ, Σℓ; rtol) on the LEFT-TO-RIGHT sum of the
+    records' lengths) wherever it decides at all?  Run on the records of the last ``run(tg)``: at the default rtol, at three fixed
+    ones, and at tolerances put next to this problem's own tracks — for up to eight tracks whose |ℓ − Σℓ| / max(ℓ, Σℓ) is real
+    (above 1e-11: a skipped sliver, an overlap), that ratio times (1 ± 1e-7): the track just fails / just passes.  Returns
+    (tracks decided wrongly, tracks left to the exact sum, decisions made, tracks left to the exact sum at the default rtol)."""
+    L = _f(tg.ell)
+    wrong = marginal = decided = 0
+    st, S, E = chain(tg)
+    marg_default = int(np.count_nonzero(st == 2))
+    big = np.maximum(np.abs(L), np.abs(E))
+    ratio = np.abs(L - E) / np.where(big > 0, big, 1.0)
+    if rtols is None:
+        real = np.sort(ratio[ratio > 1e-11])
+        pick = real[np.linspace(0, len(real) - 1, min(8, len(real))).astype(int)] if len(real) else []
+        rtols = [1.4901161193847656e-8, 1e-6, 1e-10, 1e-13] + [float(v) * f for v in pick for f in (1 - 1e-7, 1 + 1e-7)]
+    for rtol in rtols:
+        st, S, E = chain(tg, rtol)
+        ref_fail = ~((L == E) | (np.abs(L - E) <= rtol * big))
+        dec = st != 2
+        wrong += int(np.count_nonzero(dec & ((st == 1) != ref_fail)))
+        marginal += int(np.count_nonzero(~dec))
+        decided += int(np.count_nonzero(dec))
+    return wrong, marginal, decided, marg_default

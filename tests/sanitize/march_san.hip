@@ -35,7 +35,7 @@ int64_t orc_fetch(void *mv, double *px, double *py, double *qx, double *qy, doub
 }
 
 int main(int argc, char **argv) {
-    long long segs = 0, walk = 0, cheap = 0;
+    long long segs = 0, walk = 0, cheap = 0, chain_dec = 0, chain_marg = 0;
     int bad = 0, n_mesh = 0;
     for (int a = 1; a < argc; ++a) {
         rt_msh *M = rt_msh_load(argv[a]);
@@ -74,6 +74,20 @@ int main(int argc, char **argv) {
                 if (w == 0) walk += g_res.stats[0];
                 if (w == 2) cheap += g_res.stats[5];
             }
+            {   // the Σℓ chain of k_materialise_lin (rt_device.hpp chain_*) on the cheap-step march's records, against the
+                // left-to-right check, wherever it decides (tests/test_sum_chain_cpu.py has the tuned tolerances)
+                std::vector<int32_t> cst(n);
+                std::vector<double> cS(n), cE(n);
+                const double cmax = std::max(std::max(fabs(bb[0]), fabs(bb[2])), std::max(fabs(bb[1]), fabs(bb[3])));
+                for (const double rtol : {1.4901161193847656e-8, 1e-6, 1e-11}) {
+                    hostmarch_chain(n, D[5].data(), D[6].data(), D[7].data(), rtol, cmax, cst.data(), cS.data(), cE.data());
+                    for (int64_t u = 0; u < n; ++u) {
+                        if (cst[u] == 2) { ++chain_marg; continue; }
+                        ++chain_dec;
+                        if ((cst[u] == 1) == rt::isapprox_s(D[7][u], cE[u], rtol)) { ++bad; printf("CHAIN MISMATCH %s track %lld rtol %g\n", argv[a], (long long)u, rtol); }
+                    }
+                }
+            }
             void *orc = orc_mesh_create(x.data(), y.data(), nn, cells.data(), nc, ptrs.data(), data.data(), bb);
             std::vector<int64_t> ooff(n + 1);
             std::vector<int32_t> ost(n);
@@ -96,7 +110,8 @@ int main(int argc, char **argv) {
             segs += tot;
         }
     }
-    printf("march_san: %d meshes, %lld segments (%lld by the walk step, %lld by cheap steps), exact walk steps == walk off == cheap steps == checker: %s\n",
-           n_mesh, segs, walk, cheap, bad ? "MISMATCH" : "yes");
+    printf("march_san: %d meshes, %lld segments (%lld by the walk step, %lld by cheap steps), exact walk steps == walk off == cheap steps == checker: %s; "
+           "Σℓ chain: %lld decisions equal the left-to-right check's, %lld left to the exact sum\n",
+           n_mesh, segs, walk, cheap, bad ? "MISMATCH" : "yes", chain_dec, chain_marg);
     return bad ? 1 : 0;
 }

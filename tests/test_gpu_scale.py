@@ -182,6 +182,15 @@ def test_bwr_config5_full_size_properties(rt):
     rel = (ell_sum - tell).abs() / tell
     assert float(rel[ok].max().item()) <= rt.RTOL_DEFAULT * (1 + 1e-9)  # exactly the reference's criterion
     assert float(rel.max().item()) < 1e-3  # the failing ones miss a sliver, not a cell
+    # ... in BOTH directions: isapprox(ℓ, Σℓ; rtol) is |ℓ − Σℓ| <= rtol·max(|ℓ|, |Σℓ|) (src/track.jl:171) — every track marked OK
+    # satisfies it, and every track marked LENGTH_MISMATCH really violates it (1e-9: this sum's order is not the kernel's)
+    big = torch.maximum(tell.abs(), ell_sum.abs())
+    ratio = (ell_sum - tell).abs() / big
+    assert float(ratio[ok].max().item()) <= rt.RTOL_DEFAULT * (1 + 1e-9)
+    if n_bad:
+        assert float(ratio[~ok].min().item()) > rt.RTOL_DEFAULT * (1 - 1e-9), "a track marked LENGTH_MISMATCH passes the reference's check"
+    print("config 5: the Σℓ status holds in both directions; smallest ratio of a failing track / rtol =",
+          float(ratio[~ok].min().item()) / rt.RTOL_DEFAULT if n_bad else None)
 
     # first / last segment ends at the track's p / q (test/runtests.jl:30-35)
     first = off[:-1]

@@ -103,13 +103,19 @@ def run(seed):
         if not ok:
             bad.append(walk)
         res[walk] = r
+    # the Σℓ chain of k_materialise_lin (rt_device.hpp chain_*: the functions the kernel calls) on the records of the cheap-step
+    # march just made — with the flags of the records that keep their own p —, against the left-to-right check, at the default
+    # rtol and at tolerances tuned to this problem's own tracks
+    cw, cm, cd, _cm0 = hm.chain_check(tg)
+    if cw:
+        bad.append("chain")
     s, info = res[True]["stats"], res[True]["info"]
     line = ("seed %d %-11s tiny %.0e cells %5d nφ %4d k %2d tracks %6d segs %8d failing %5d | records walkable %5d/%5d eps≤%.1e fragile %d degenerate %d | "
-            "walk emits %8d skips %6d generic emits %7d refused %6d | cheap steps: emits %8d refused %5d restarts %d%s" %
+            "walk emits %8d skips %6d generic emits %7d refused %6d | cheap steps: emits %8d refused %5d restarts %d | Σℓ chain: %d decisions, %d left to the exact sum, %d wrong%s" %
             (seed, kind, tg.tiny_step, model.num_cells, n_azim, k, tg.n_total_tracks, ref["total"], int(np.count_nonzero(ref["status"])),
              int(info["records_walk"]), int(info["records"]), info["eps_max"], int(info["cells_fragile"]), int(info["cells_degenerate"]),
              s["walk_emits"], s["walk_skips"], s["generic_emits"], s["refused"], res["topo"]["stats"]["cheap_emits"],
-             res["topo"]["stats"]["cheap_refused"], res["topo"]["stats"]["cheap_restarts"], ("  MISMATCH walk=%s" % bad) if bad else ""))
+             res["topo"]["stats"]["cheap_refused"], res["topo"]["stats"]["cheap_restarts"], cd, cm, cw, ("  MISMATCH walk=%s" % bad) if bad else ""))
     return seed, bool(bad), line, s["walk_emits"], ref["total"], res["topo"]["stats"]["cheap_emits"], kind
 
 
