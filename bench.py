@@ -279,8 +279,13 @@ def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
     # "compact": the CSR records (ℓ, cell) as a caller with the reference's layout holds them; "staged": a call that wrote no records
     # ("compact" = 0: k_materialise leaves (ℓ, cell) rows in the march's slot order instead); "auto": the default input after an
     # ordinary call — the rows are built from the staged words once per segmentation (`first_sweep_ms` includes that)
-    for key, compact, name in (("compact", 1, "compact"), ("staged", 0, "staged"), ("auto", 1, "auto")):
+    # (round 6: the compact input is swept as rows too — "compact": as the library serves it by default, the staging's rows while the
+    #  handle has them; "compact_rows_from_records": rows transposed once per segmentation from the CSR records themselves, what a
+    #  handle without whole-track staging gets; "compact_in_place": the records where they lie, round 5's path)
+    for key, compact, name, rows in (("compact", 1, "compact", 1), ("compact_rows_from_records", 1, "compact", 2), ("compact_in_place", 1, "compact", 0),
+                                     ("staged", 0, "staged", 1), ("auto", 1, "auto", 1)):
         dmesh.set_option("compact", compact)
+        dmesh.set_option("sweep_rows", rows)
         seg()
         r = dt.sweep(G, sig, src, None, None, input=name, fetch=False)
         ms = min(dt.sweep(G, input=name, fetch=False)["ms"] for _ in range(5))
@@ -302,9 +307,10 @@ def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
         dt.wait()
         b2b_ms = (time.perf_counter() - t0) / 10 * 1e3
         dmesh.set_option("async", 0)
-        out[key] = {"input": r["input"], "sweep_ms": ms, "sweeps_back_to_back_ms": b2b_ms, "first_sweep_ms": r["ms"], "passes": r["passes"], "groups_per_pass": r["groups_per_pass"], "bytes_per_segment": 2.0 * r["passes"] * row_bytes,
+        out[key] = {"input": r["input"], "rows": r.get("rows"), "sweep_ms": ms, "sweeps_back_to_back_ms": b2b_ms, "first_sweep_ms": r["ms"], "passes": r["passes"], "groups_per_pass": r["groups_per_pass"], "bytes_per_segment": 2.0 * r["passes"] * row_bytes,
                      "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "segment_group_updates_per_s": total * 2.0 * G / (ms * 1e-3),
                      "ms_per_step_segmentize_plus_sweep": step_ms}
+    dmesh.set_option("sweep_rows", 1)
     dmesh.set_option("compact", 0)
     t0 = time.perf_counter()
     for _ in range(steps):

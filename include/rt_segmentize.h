@@ -230,7 +230,10 @@ int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
  *   track_weight        [n_tracks] w[u]; NULL: the previous call's, or δs[azim_idx[u]] — the weight fill_volumes gives a
  *                       segment (src/trackgenerator.jl:379-382) — if none was ever given
  *   psi_in              [2][n_tracks][G] incoming boundary flux; NULL: what the previous sweep handed on (0 at first)
- *   input               1: the compact CSR records (ℓ and element, 12 B per segment and direction, uncoalesced); 2: rows in the
+ *   input               1: the compact CSR records (ℓ and element — the reference's layout).  Round 6: they are swept as coalesced
+ *                       (ℓ, cell) ROWS too — the staging's while the handle has them, else rows transposed ONCE per segmentation from
+ *                       the records (rt_sweep_rows_kind = 2); rt_set_option "sweep_rows" 0: where they lie (12 B per segment and
+ *                       direction, a wave-load touches 64 lines: 2.4x slower); 2: rows in the
  *                       march's staging layout, coalesced — (ℓ, cell) rows, 12 B, which a two-phase call with "compact" 0 writes
  *                       instead of the records and which the first sweep after any other two-phase call makes from the staged
  *                       words (once per segmentation); after a call with exact steps only: its (q, cell) rows, 20 B, ℓ = ‖p − q‖
@@ -249,6 +252,9 @@ int32_t rt_sweep(rt_tracks *tracks, int32_t n_groups, const double *sigma_t, con
                  const double *track_weight, const double *psi_in, int32_t input, double *ms);
 int32_t rt_sweep_fetch(rt_tracks *tracks, double *phi, double *psi_out, double *psi_next);
 int32_t rt_sweep_info(rt_tracks *tracks, void **ptrs_dev, int32_t *info);
+/* How the last rt_sweep read its records: 0 where they lie (compact records, or the exact march's 20-B staging rows on their first
+ * pass), 1 (ℓ, cell) rows in the staging's layout, 2 (ℓ, cell) rows made from the compact records; < 0: RT_ERR_*. */
+int32_t rt_sweep_rows_kind(rt_tracks *tracks);
 /* The device copy of the cross sections as rt_sweep reads them: [n_cells * n_groups][2] doubles = {sigma_t, source / sigma_t}
  * (0 for the second where sigma_t = 0).  A solver that updates its source on the device writes the second components there —
  * ordered against rt_mesh_get_stream — and calls rt_sweep with sigma_t = source = NULL ("those of the previous call"): no

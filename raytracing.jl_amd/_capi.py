@@ -20,7 +20,7 @@ SYMBOLS = (
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks", "rt_wait",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_pinned", "rt_fetch_volumes", "rt_device_pointers",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
-    "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_sweep_xs_pointer", "rt_multi_link_rates",
+    "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_sweep_rows_kind", "rt_sweep_xs_pointer", "rt_multi_link_rates",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
     "rt_multi_failed_tracks", "rt_multi_fetch_offsets", "rt_multi_fetch_segments", "rt_multi_fetch_volumes", "rt_multi_allgather",
     "rt_trace_counts", "rt_trace", "rt_msh_load", "rt_msh_sizes", "rt_msh_fetch", "rt_msh_free",
@@ -148,6 +148,8 @@ def lib():
         L.rt_sweep_xs_pointer.restype = C.c_int32
         L.rt_sweep_xs_pointer.argtypes = [_vp, C.POINTER(_vp)]
         L.rt_sweep_info.restype = C.c_int32
+        L.rt_sweep_rows_kind.restype = C.c_int32
+        L.rt_sweep_rows_kind.argtypes = [_vp]
         L.rt_sweep_info.argtypes = [_vp, C.POINTER(_vp), _ip]
         L.rt_multi_link_rates.restype = C.c_int32
         L.rt_multi_link_rates.argtypes = [_vp, _dp]
@@ -436,7 +438,8 @@ class DeviceTracks:
         _check(lib().rt_sweep(self._h, G, stp, qp, wp, pip, self.SWEEP_INPUT[input], C.byref(ms)))
         info = (C.c_int32 * 4)()
         _check(lib().rt_sweep_info(self._h, None, info))
-        out = dict(ms=ms.value, input={1: "compact", 2: "staged"}[int(info[0])], groups_per_pass=int(info[1]), passes=int(info[2]))
+        out = dict(ms=ms.value, input={1: "compact", 2: "staged"}[int(info[0])], groups_per_pass=int(info[1]), passes=int(info[2]),
+                   rows={0: None, 1: "staging", 2: "from compact"}.get(int(lib().rt_sweep_rows_kind(self._h))))
         if fetch:
             out["phi"] = np.empty((self.dmesh.n_cells, G)); out["psi_out"] = np.empty((2, self.n, G)); out["psi_next"] = np.empty((2, self.n, G))
             _check(lib().rt_sweep_fetch(self._h, *[out[k].ctypes.data_as(_dp) for k in ("phi", "psi_out", "psi_next")]))

@@ -312,6 +312,7 @@ struct rt_mesh {
     int n_cus = 256;
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
+    int sweep_rows = 1; // rt_sweep over the compact records: as (ℓ, cell) rows (the staging's, or made once from the records); 0: where they lie
     int sweep_ell = 1;  // rt_sweep over staged rows: keep ℓ of every row from the first pass for the later ones (0: every pass derives it)
     int sweep_debug = 0, compact_debug = 0;
     int mat_kernel = 0;      // records of a two-phase call: 0 k_materialise_lin (output order, 16-B stores), 1 k_materialise (chunk tiles; A/B)
@@ -453,8 +454,10 @@ struct rt_tracks {
     DevBuf<double> sw_ell;      // ℓ of every staged row (slot-indexed like the staging pool), left by the first staged pass after a call
     bool sw_ell_valid = false;  // ... of the last rt_segmentize
     DevBuf<int32_t> sw_cell;    // codes: cell + 1 of every staged row, beside sw_ell (k_materialise<.., ROWS>)
+    DevBuf<int32_t> sw_ctab, sw_plan;  // rows made from the COMPACT records (rt_sweep.hip ensure_rows_from_compact): their own chunk table
+    bool sw_rowsc_valid = false;       // ... sw_ell / sw_cell hold those rows for the last rt_segmentize
     bool sw_links = false, sw_has_w = false, sw_has_xs = false, sw_done = false;
-    int32_t sw_groups = 0, sw_last_input = 0, sw_last_gp = 0, sw_last_passes = 0;
+    int32_t sw_groups = 0, sw_last_input = 0, sw_last_gp = 0, sw_last_passes = 0, sw_last_rows = 0;
     int64_t refusals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // cheap-step refusals of the last call by certificate term
     int64_t n_near_rtol = 0, n_restarts = 0, n_exact_tally = 0;
     int64_t n_failed = 0, first_failed_uid = 0;
@@ -485,6 +488,7 @@ void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_r
 void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s);
 int ensure_compacted(rt_tracks *t);
 int ensure_rows(rt_tracks *t);
+int ensure_rows_from_compact(rt_tracks *t);  // rt_sweep.hip
 void launch_prologue(hipStream_t s, unsigned long long *ctl, double *volumes, int32_t n_cells, int32_t first_chunk, int32_t side_first);
 // the exclusive scan of the counts (two kernels); see k_scan_tile_sums / k_scan_write for the optional pointers
 void launch_scan_fused(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, const int32_t *tile_acc, int32_t *tile_acc_next,

@@ -863,6 +863,7 @@ int ensure_rows(rt_tracks *t) {
     if (int rc = launch_materialise(t, out, t->mesh->stream, false, true, false, nullptr)) return rc;
     RT_HIP(hipGetLastError());
     t->sw_ell_valid = true;
+    t->sw_rowsc_valid = false;  // (the same buffers)
     return RT_SUCCESS;
 }
 

@@ -482,6 +482,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "compact")) { mesh->compact = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_ell")) { mesh->sweep_ell = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "sweep_rows")) { mesh->sweep_rows = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "compact_debug")) { mesh->compact_debug = (int)value; return RT_SUCCESS; }
@@ -868,6 +869,7 @@ struct SegmentizeCall {
         out.dbg = m->compact_debug;
         t->compacted = false;
         t->sw_ell_valid = false;
+        t->sw_rowsc_valid = false;
         t->cplan = rt_tracks::CompactPlan{};
         t->last_split = 0;
         t->last_record_kernel = 0;

@@ -289,7 +289,107 @@ __global__ __launch_bounds__(256) void k_sweep_link(const int32_t *__restrict__ 
     const int32_t sc = src_of[slot];  // source track * 2 + source direction, -1: none
     psi_in[i] = sc < 0 ? 0.0 : psi_out[((int64_t)(sc & 1) * n + (sc >> 1)) * G + g];
 }
+// ---- (ℓ, cell) rows from the COMPACT records (round 6) --------------------------------------------------------------
+// The sweep's fast input is the coalesced one: rows of a march wave, lane = track (k_sweep<true, ..., ELLROWS>).  A handle whose
+// call left no whole-track staging (tracks marched in pieces: C1, C2), or a caller that names the compact CSR records — the
+// reference's own layout, `for segment in track.segments: ℓ, element` (README.md:127-135) — used to sweep those records where they
+// lie: one lane walks one track's run, a wave-load touches 64 lines (0.60 ms and 1.39 GB per sweep at C3 / 7 groups against 0.25 ms
+// over rows).  Now the first sweep after a segmentation transposes the compact (ℓ, cell) into rows ONCE — a chunk table of its own:
+// wave w gets ⌈max count / 32⌉ chunks in a row, `k_rows_plan` — and every sweep reads the rows.
+__global__ __launch_bounds__(256) void k_rows_count(const int32_t *__restrict__ counts, const int32_t *__restrict__ perm, int64_t n, int32_t n_waves,
+                                                    int32_t *__restrict__ nch) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const int64_t slot = w * 64 + (threadIdx.x & 63);
+    int32_t mc = slot < n ? counts[perm[slot]] : 0;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t v = __shfl_xor(mc, o, 64);
+        mc = v > mc ? v : mc;
+    }
+    if ((threadIdx.x & 63) == 0) nch[w] = (mc + kChunkRows - 1) >> kChunkLog2;
+}
+// one workgroup: exclusive scan of the waves' chunk counts -> first[w]; total[0] = chunks in all
+__global__ __launch_bounds__(1024) void k_rows_plan(const int32_t *__restrict__ nch, int32_t n_waves, int32_t *__restrict__ first, int32_t *__restrict__ total) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int32_t base = 0; base < n_waves; base += 1024) {
+        const int32_t i = base + (int32_t)threadIdx.x;
+        const int32_t v = i < n_waves ? nch[i] : 0;
+        int32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        if (i < n_waves) first[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+// one four-wave workgroup per march wave: lane = track, wave k of the workgroup takes the rows r ≡ k (mod 4)
+__global__ __launch_bounds__(256) void k_rows_fill(const int32_t *__restrict__ counts, const int64_t *__restrict__ offsets, const int32_t *__restrict__ perm,
+                                                   int64_t n, const double *__restrict__ ell, const int32_t *__restrict__ element,
+                                                   const int32_t *__restrict__ first, const int32_t *__restrict__ nch, int32_t *__restrict__ ctab,
+                                                   double *__restrict__ ell_rows, int32_t *__restrict__ cell_rows) {
+    const int64_t w = blockIdx.x;
+    const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6;
+    const int64_t slot = w * 64 + lane;
+    const bool have = slot < n;
+    const int32_t u = have ? perm[slot] : 0;
+    const int32_t cnt = have ? counts[u] : 0;
+    const int64_t off = have ? offsets[u] : 0;
+    const int32_t c0 = first[w], nc = nch[w];
+    for (int j = threadIdx.x; j < nc; j += 256) ctab[w * kMaxChunks + j] = c0 + j;
+    const int maxr = nc << kChunkLog2;
+    for (int r = kw; r < maxr; r += 4) {
+        if (r < cnt) {
+            const int64_t sl = stage_slot(c0 + (r >> kChunkLog2), r & (kChunkRows - 1), lane);
+            ell_rows[sl] = ell[off + r];
+            cell_rows[sl] = element[off + r];
+        }
+    }
+}
+
 }  // namespace rt
+
+namespace rtx {
+// The rows of the last segmentation from its compact records (see k_rows_fill): built once, `sw_rowsc_valid`.
+int ensure_rows_from_compact(rt_tracks *t) {
+    if (t->sw_rowsc_valid) return RT_SUCCESS;
+    if (int rc = ensure_compacted(t)) return rc;
+    hipStream_t s = t->mesh->stream;
+    const int64_t n = t->n;
+    const int32_t n_waves = (int32_t)((n + 63) / 64);
+    if (n_waves == 0) { t->sw_rowsc_valid = true; return RT_SUCCESS; }
+    RT_HIP(t->sw_plan.reserve(2 * (size_t)n_waves + 8));
+    RT_HIP(t->sw_ctab.reserve((size_t)n_waves * rt::kMaxChunks));
+    int32_t *nch = t->sw_plan.p, *first = nch + n_waves, *total = first + n_waves;
+    hipLaunchKernelGGL(rt::k_rows_count, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, s, (const int32_t *)t->counts.p, (const int32_t *)t->perm.p, n, n_waves, nch);
+    hipLaunchKernelGGL(rt::k_rows_plan, dim3(1), dim3(1024), 0, s, (const int32_t *)nch, n_waves, first, total);
+    int32_t h_total = 0;
+    RT_HIP(hipMemcpyAsync(&h_total, total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RT_HIP(hipStreamSynchronize(s));
+    const size_t slots = (size_t)std::max(1, h_total) * rt::kChunkRows * 64;
+    RT_HIP(t->sw_ell.reserve(slots)); RT_HIP(t->sw_cell.reserve(slots));
+    t->sw_ell_valid = false;  // (the buffers now hold rows in THIS chunk table's layout, not the staging pool's)
+    hipLaunchKernelGGL(rt::k_rows_fill, dim3((unsigned)n_waves), dim3(256), 0, s, (const int32_t *)t->counts.p, (const int64_t *)t->offsets.p,
+                       (const int32_t *)t->perm.p, n, (const double *)t->sell.p, (const int32_t *)t->element.p, (const int32_t *)first, (const int32_t *)nch,
+                       t->sw_ctab.p, t->sw_ell.p, t->sw_cell.p);
+    RT_HIP(hipGetLastError());
+    t->sw_rowsc_valid = true;
+    return RT_SUCCESS;
+}
+}  // namespace rtx
+
+
 
 using namespace rtx;
 
@@ -369,9 +469,19 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     // which records: the march's staging rows (whole-track single-pass calls leave them behind) or the compact CSR arrays
     const bool staged_ok = t->cplan.staged && !t->cplan.split && t->cplan.n_whole_waves == (n + 63) / 64;
     if (input == 2 && !staged_ok) { set_error("rt_sweep: the last rt_segmentize left no whole-track staging rows (track pieces or two-pass mode)"); return RT_ERR_INVALID; }
-    const bool staged = input == 2 || (input == 0 && staged_ok);
+    bool staged = input == 2 || (input == 0 && staged_ok);
+    // The compact records asked for (or all there is: tracks marched in pieces): swept as ROWS all the same (option "sweep_rows",
+    // on by default) — the staging's, while the handle still has them; else rows made once from the compact records
+    // (ensure_rows_from_compact).  "sweep_rows" 0: the records where they lie (k_sweep<false, ...>; A/B and tests).
+    bool rows_compact = false;
+    if (!staged && m->sweep_rows) {
+        if (staged_ok && m->sweep_rows != 2) staged = true;  // ("sweep_rows" 2, tests / A/B: always from the compact records)
+        else rows_compact = true;
+    }
     if (!staged)
         if (int rc = ensure_compacted(t)) return rc;
+    if (rows_compact)
+        if (int rc = ensure_rows_from_compact(t)) return rc;
     using rt::as_global;
     rt::DSweep a{};
     a.stg = t->cplan.stg;
@@ -400,7 +510,11 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     // like the rows; every later pass — of this sweep and of all following sweeps over the same segmentation — reads (ℓ, cell)
     // rows instead (12 B instead of 20, no square root, no entry point).  Option "sweep_ell" = 0 switches this off.
     bool ell_rows = false;
-    if (staged && t->cplan.codes) {
+    if (rows_compact) {
+        a.stg = rt::DStage{};
+        a.stg.ctab = as_global(t->sw_ctab.p); a.stg.element = as_global(t->sw_cell.p);
+        ell_rows = true;
+    } else if (staged && t->cplan.codes) {
         // a two-phase call staged codes: the sweep reads (ℓ, cell) rows, which the call itself left ("compact" = 0) or which
         // k_materialise writes now, once per segmentation
         if (int rc = ensure_rows(t)) return rc;
@@ -424,7 +538,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
         if (m->sweep_waves == 4 || m->sweep_waves == 8 || m->sweep_waves == 16) W = m->sweep_waves;
         const unsigned blocks = (unsigned)((2 * (int64_t)a.n_waves + W - 1) / W);
         a.g0 = g0; a.ng = GP;
-        if (STAGED && ell_rows && t->sw_ell_valid) {
+        if (STAGED && ell_rows && (t->sw_ell_valid || rows_compact)) {
             if constexpr (STAGED) {
                 if (smem > 48 * 1024)
                     RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<true, GP, LDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -434,7 +548,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
             if (smem > 48 * 1024)
                 RT_HIP(hipFuncSetAttribute((const void *)rt::k_sweep<STAGED, GP, LDS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((rt::k_sweep<STAGED, GP, LDS, false>), dim3(blocks), dim3(64 * W), smem, s, a);
-            if (STAGED && ell_rows) t->sw_ell_valid = true;  // (the forward waves of this pass have written every row's ℓ)
+            if (STAGED && ell_rows) { t->sw_ell_valid = true; t->sw_rowsc_valid = false; }  // (the forward waves of this pass have written every row's ℓ)
         }
         ++passes;
         return RT_SUCCESS;
@@ -454,7 +568,7 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
     };
     if (n > 0) {
         int rc;
-        if (staged) rc = a.use_lds ? launch_all.template operator()<true, true>() : launch_all.template operator()<true, false>();
+        if (staged || rows_compact) rc = a.use_lds ? launch_all.template operator()<true, true>() : launch_all.template operator()<true, false>();
         else rc = a.use_lds ? launch_all.template operator()<false, true>() : launch_all.template operator()<false, false>();
         if (rc) return rc;
         const int64_t nl = 2 * n * G;
@@ -473,7 +587,9 @@ static int32_t sweep_impl(rt_tracks *t, int32_t G, const double *sigma_t, const 
         t->in_flight = false;  // (the sweep waited for the stream)
     }
     t->sw_done = true;
-    t->sw_last_input = staged ? 2 : 1; t->sw_last_gp = a.use_lds ? gp : 0; t->sw_last_passes = passes;
+    // (what the caller's records were: 1 the compact CSR records — named, or all there is —, 2 the staging; and how they were read)
+    t->sw_last_input = (input == 1 || rows_compact || !staged) ? 1 : 2;
+    t->sw_last_rows = rows_compact ? 2 : (staged && ell_rows ? 1 : 0); t->sw_last_gp = a.use_lds ? gp : 0; t->sw_last_passes = passes;
     return RT_SUCCESS;
 }
 
@@ -516,6 +632,12 @@ int32_t rt_sweep_info(rt_tracks *t, void **ptrs_dev, int32_t *info) {
     if (ptrs_dev) { ptrs_dev[0] = t->sw_phi.p; ptrs_dev[1] = t->sw_psi_out.p; ptrs_dev[2] = t->sw_psi_in.p; }
     if (info) { info[0] = t->sw_last_input; info[1] = t->sw_last_gp; info[2] = t->sw_last_passes; info[3] = t->sw_groups; }
     return RT_SUCCESS;
+}
+
+int32_t rt_sweep_rows_kind(rt_tracks *t) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (!t->sw_done) { set_error("rt_sweep has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    return t->sw_last_rows;
 }
 
 int32_t rt_sweep_xs_pointer(rt_tracks *t, void **xs_dev) {
