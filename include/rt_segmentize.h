@@ -178,6 +178,23 @@ int32_t rt_fetch_segments_pinned(rt_tracks *tracks, void **host_ptrs);
 int32_t rt_fetch_pinned(rt_tracks *tracks, void **host_ptrs);
 
 /*
+ * The same eight arrays in a host block that the LIBRARY owns (round 6).  One segmentize! ends with track.segments on the host
+ * (src/trackgenerator.jl:357-369), and into fresh host memory that copy is bound by page faults whose cost depends on the state of
+ * the box's huge pages.  rt_result_alloc maps an anonymous block aligned to 2 MB — seg_offsets[n_tracks + 1], status[n_tracks] and six
+ * record arrays of the estimated record count (n_records_hint <= 0: the Cauchy–Crofton estimate from sum_ell = Σ track.ℓ) —, asks for
+ * transparent huge pages BEFORE its first touch and returns at once: threads of the library fault the block in, in address order, in the
+ * background (a unit whose 2-MB fault stalls switches what is still to come to 4-KB pages).  Call it BEFORE rt_tracks_create /
+ * rt_segmentize: the upload and the kernels then run beside the page faults.  rt_result_fetch copies offsets, status and records of the
+ * last rt_segmentize into the block behind that front (a block that turns out too small is replaced) and returns the eight host pointers
+ * (host_ptrs[8], order as rt_fetch_pinned) and the record count; they stay valid until rt_result_free — independent of the track
+ * handle's lifetime: a Julia host wraps them with unsafe_wrap(Array, ptr, n; own = false) and frees the block in a finalizer.
+ */
+typedef struct rt_result rt_result;
+rt_result *rt_result_alloc(rt_mesh *mesh, int64_t n_tracks, double sum_ell, int64_t n_records_hint);
+int32_t rt_result_fetch(rt_tracks *tracks, rt_result *result, void **host_ptrs, int64_t *total);
+void rt_result_free(rt_result *result);
+
+/*
  * Device-resident results for consumers that stay on the GPU (RCCL all-gather of shards,
  * a device-side transport sweep).  ptrs_dev[9] receives, in this order: seg_offsets (i64),
  * status (i32), px, py, qx, qy, ell (f64), element (i32), volumes (f64).  The pointers stay

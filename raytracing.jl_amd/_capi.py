@@ -19,6 +19,7 @@ SYMBOLS = (
     "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_info", "rt_last_stats", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks", "rt_wait",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_pinned", "rt_fetch_volumes", "rt_device_pointers",
+    "rt_result_alloc", "rt_result_fetch", "rt_result_free",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
     "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_sweep_rows_kind", "rt_sweep_xs_pointer", "rt_multi_link_rates",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_segmentize", "rt_multi_shards", "rt_multi_shard",
@@ -147,6 +148,11 @@ def lib():
         L.rt_sweep_fetch.argtypes = [_vp, _dp, _dp, _dp]
         L.rt_sweep_xs_pointer.restype = C.c_int32
         L.rt_sweep_xs_pointer.argtypes = [_vp, C.POINTER(_vp)]
+        L.rt_result_alloc.restype = _vp
+        L.rt_result_alloc.argtypes = [_vp, C.c_int64, C.c_double, C.c_int64]
+        L.rt_result_fetch.restype = C.c_int32
+        L.rt_result_fetch.argtypes = [_vp, _vp, C.POINTER(_vp), _lp]
+        L.rt_result_free.argtypes = [_vp]
         L.rt_sweep_info.restype = C.c_int32
         L.rt_sweep_rows_kind.restype = C.c_int32
         L.rt_sweep_rows_kind.argtypes = [_vp]
@@ -264,12 +270,39 @@ class DeviceMesh:
         self._hook = C.CFUNCTYPE(None, C.c_void_p)(lambda _user: fn())  # keep the thunk alive
         _check(lib().rt_mesh_set_enqueue_hook(self._h, C.cast(self._hook, C.c_void_p), None))
 
+    def result_alloc(self, n_tracks: int, sum_ell: float, n_records_hint: int = 0) -> "ResultBlock":
+        """``rt_result_alloc``: a host block for the results of a track set of ``n_tracks`` tracks with Σℓ = ``sum_ell`` — returns at
+        once, the library faults the block in in the background.  Call it before ``DeviceTracks`` / ``segmentize``."""
+        h = lib().rt_result_alloc(self._h, int(n_tracks), float(sum_ell), int(n_records_hint))
+        if not h:
+            raise RtError(f"rt_result_alloc: {last_error()}")
+        return ResultBlock(h)
+
     def set_option(self, name: str, value: int):
         _check(lib().rt_set_option(self._h, name.encode(), int(value)))
 
     def close(self):
         if getattr(self, "_h", None):
             lib().rt_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ResultBlock:
+    """``rt_result``: a host block owned by the library (2-MB aligned anonymous memory, huge pages asked for before its first touch,
+    faulted in by the library's threads in the background) for everything a fetch returns — see ``include/rt_segmentize.h``."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_result_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -322,6 +355,28 @@ class DeviceTracks:
         st = np.zeros(max(self.n, 1), np.int32)
         _check(lib().rt_fetch_offsets(self._h, off.ctypes.data_as(_lp), st.ctypes.data_as(_ip)))
         return off, st[: self.n]
+
+    def fetch_result(self, block):
+        """``rt_result_fetch``: offsets, status and the six record arrays of the last ``segmentize`` in the host block ``block``
+        (``DeviceMesh.result_alloc``, best called BEFORE this handle was created: the block is faulted in in the background).  Returns
+        (offsets, status, records dict) as numpy arrays over the block's memory; they keep the block alive."""
+        ptrs = (_vp * 8)()
+        tot = C.c_int64(0)
+        _check(lib().rt_result_fetch(self._h, block._h, ptrs, C.byref(tot)))
+        n = int(tot.value)
+
+        def view(addr, ctype, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype)
+            raw = (ctype * count).from_address(addr)
+            raw._rt_block = block  # (the arrays' base: the block lives as long as any of them)
+            return np.ctypeslib.as_array(raw)
+
+        off = view(ptrs[0], C.c_int64, self.n + 1, np.int64)
+        st = view(ptrs[1], C.c_int32, self.n, np.int32)
+        seg = {k: view(ptrs[2 + i], C.c_double if i < 5 else C.c_int32, n, np.float64 if i < 5 else np.int32)
+               for i, k in enumerate(("px", "py", "qx", "qy", "ell", "element"))}
+        return off, st, seg
 
     def fetch_segments_pinned(self):
         """The records in page-locked host buffers owned by this handle (``rt_fetch_segments_pinned``): numpy

@@ -5,6 +5,8 @@
 // callers replaced by memcpy.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -216,6 +218,141 @@ inline void hint_huge_pages(char *dst, size_t bytes) {
     const uintptr_t page = 4096;
     const uintptr_t a = ((uintptr_t)dst + page - 1) & ~(page - 1), b = ((uintptr_t)dst + bytes) & ~(page - 1);
     if (b > a) (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
+#else
+    (void)dst; (void)bytes;
+#endif
+}
+
+// ---- a host block owned by the library for everything a fetch returns (rt_result_alloc, round 6) -----------------------------
+// One call of segmentize! ends with its records on the host (src/trackgenerator.jl:357-369: `t.tracks_by_uid[i].segments`), and at the
+// headline configuration 98 % of such a call is the copy into 410 MB of FRESH host memory: 7.3 ms of PCIe — and 2-19 ms more of page
+// faults, by the state of the box's huge pages (a destination the caller allocated can only be hinted at: rounds 4-5).  Here the
+// library owns the destination: an anonymous mapping aligned to 2 MB, transparent huge pages asked for BEFORE its first touch, and
+// faulted in by threads of its own in the BACKGROUND, in address order, while the caller uploads its tracks and the kernels run —
+// the fetch then copies behind the front of what is already there.  Where a 2-MB fault stalls (memory that must be compacted first)
+// the unit is re-advised to 4-KB pages and faulted by 512 small faults instead: independent of the box's state.
+struct ResultBlock {
+    static constexpr size_t kUnit = (size_t)2 << 20;
+    char *map = nullptr; size_t map_bytes = 0;   // the mapping as mmap returned it
+    char *base = nullptr; size_t bytes = 0;      // its 2-MB aligned part: the eight arrays
+    size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // seg_offsets (i64), status (i32), px, py, qx, qy, ell (f64), element (i32)
+    int64_t n_tracks = 0, cap_records = 0;
+    std::vector<std::thread> th;
+    std::vector<unsigned char> done;             // per 2-MB unit: faulted in
+    std::mutex m;
+    std::condition_variable cv;
+    size_t front_units = 0, next_unit = 0, n_units = 0;
+    bool stop = false;
+    long small_units = 0;                        // units that fell back to 4-KB pages
+    double stall_ms = 2.0;                       // a 2-MB unit whose first touch takes longer than this is a stall
+    ~ResultBlock() { release(); }
+    static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+    bool map_for(int64_t n_tracks_, int64_t cap_records_, bool huge) {
+#if defined(__linux__)
+        release();
+        n_tracks = n_tracks_; cap_records = cap_records_;
+        const size_t nt = (size_t)std::max<int64_t>(n_tracks, 0), nr = (size_t)std::max<int64_t>(cap_records, 1);
+        const size_t len[8] = {8 * (nt + 1), 4 * std::max<size_t>(nt, 1), 8 * nr, 8 * nr, 8 * nr, 8 * nr, 8 * nr, 4 * nr};
+        size_t o = 0;
+        for (int a = 0; a < 8; ++a) { off[a] = o; o = up(o + len[a], a < 2 ? 4096 : kUnit); }  // (every record array starts a 2-MB unit)
+        bytes = up(o, kUnit);
+        map_bytes = bytes + kUnit;
+        void *p = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) { map = nullptr; map_bytes = bytes = 0; return false; }
+        map = (char *)p;
+        base = (char *)up((size_t)(uintptr_t)map, kUnit);
+#if defined(MADV_HUGEPAGE)
+        if (huge) (void)madvise(base, bytes, MADV_HUGEPAGE);
+#endif
+        n_units = bytes / kUnit;
+        done.assign(n_units, 0);
+        front_units = next_unit = 0; stop = false; small_units = 0;
+        return true;
+#else
+        (void)n_tracks_; (void)cap_records_; (void)huge;
+        return false;
+#endif
+    }
+    // one unit: its first byte — a 2-MB fault where the kernel has a huge page at hand; if that took long (compaction), or no huge
+    // page came, the other 511 pages by small faults
+    void fault_unit(size_t u) {
+        volatile char *p = (volatile char *)(base + u * kUnit);
+        const auto t0 = std::chrono::steady_clock::now();
+        p[0] = 0;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#if defined(__linux__) && defined(MADV_NOHUGEPAGE)
+        if (ms > stall_ms) {
+            // (the fault had to wait for a huge page: the units still to come take 4-KB pages — many small faults in parallel beat a
+            //  few that each wait for compaction)
+            std::lock_guard<std::mutex> lk(m);
+            if (u + 1 < n_units) (void)madvise(base + (u + 1) * kUnit, (n_units - u - 1) * kUnit, MADV_NOHUGEPAGE);
+            ++small_units;
+        }
+#else
+        (void)ms;
+#endif
+        for (size_t o = 4096; o < kUnit; o += 4096) p[o] = 0;  // (already present behind a huge page: 511 stores)
+    }
+    void worker() {
+        for (;;) {
+            size_t u;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (stop || next_unit >= n_units) return;
+                u = next_unit++;
+            }
+            fault_unit(u);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                done[u] = 1;
+                while (front_units < n_units && done[front_units]) ++front_units;
+            }
+            cv.notify_all();
+        }
+    }
+    void prefault_start(unsigned n_threads) {
+        if (!base) return;
+        n_threads = std::max(1u, std::min(n_threads, 16u));
+        // (ONE thread is started here — ≈30 µs of the caller's time —, it starts the others and works itself)
+        try {
+            th.emplace_back([this, n_threads] {
+                std::vector<std::thread> more;
+                for (unsigned k = 1; k < n_threads; ++k) {
+                    try { more.emplace_back([this] { worker(); }); } catch (...) { break; }
+                }
+                worker();
+                for (auto &t : more) t.join();
+            });
+        } catch (...) {
+            worker();  // (no thread to be had: here)
+        }
+    }
+    // until [0, upto) of the block is faulted in (the fetch copies behind this front)
+    void wait_front(size_t upto) {
+        const size_t need = std::min(n_units, (upto + kUnit - 1) / kUnit);
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return front_units >= need; });
+    }
+    void join() {
+        for (auto &t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
+    void release() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        join();
+#if defined(__linux__)
+        if (map) (void)munmap(map, map_bytes);
+#endif
+        map = base = nullptr; map_bytes = bytes = 0; n_units = 0; done.clear();
+    }
+    template <typename T> T *array(int a) const { return reinterpret_cast<T *>(base + off[a]); }
+};
+
+inline void unhint_huge_pages(char *dst, size_t bytes) {
+#if defined(__linux__) && defined(MADV_NOHUGEPAGE)
+    const uintptr_t page = 4096;
+    const uintptr_t a = ((uintptr_t)dst + page - 1) & ~(page - 1), b = ((uintptr_t)dst + bytes) & ~(page - 1);
+    if (dst && b > a) (void)madvise((void *)a, b - a, MADV_NOHUGEPAGE);
 #else
     (void)dst; (void)bytes;
 #endif

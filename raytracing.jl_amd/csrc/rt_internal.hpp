@@ -312,6 +312,7 @@ struct rt_mesh {
     int n_cus = 256;
     int lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     int sweep_gp = 0, sweep_waves = 0;  // rt_sweep: groups per pass / waves per workgroup (0: automatic)
+    int fetch_hugepages = 1;  // rt_fetch_* into the caller's arrays: ask for transparent huge pages on the destination (once per array)
     int sweep_rows = 1; // rt_sweep over the compact records: as (ℓ, cell) rows (the staging's, or made once from the records); 0: where they lie
     int sweep_ell = 1;  // rt_sweep over staged rows: keep ℓ of every row from the first pass for the later ones (0: every pass derives it)
     int sweep_debug = 0, compact_debug = 0;

@@ -278,7 +278,8 @@ void staging_release(int slot) {
 // page faults of a fresh destination in parallel).  A plain hipMemcpy into pageable memory runs at a third of the link's rate (C3's
 // 410 MB of records: 25-42 ms, C5's 5 GB: 330-600 ms), and page-locking the whole result first (rt_fetch_pinned's first call) costs
 // as much.  dst[a] == NULL: skipped.
-static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, void *const *dst, const size_t *bytes) {
+static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, void *const *dst, const size_t *bytes,
+                           rthostpar::ResultBlock *blk = nullptr) {
     hipStream_t s = t->mesh->stream;
     StagingBlock stage;
     const int slot = staging_acquire(&stage, t->mesh->device);
@@ -291,28 +292,44 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
         return RT_SUCCESS;
     }
     const size_t half = kStageBytes / 2;
-    static const bool huge_hint = getenv("RT_FETCH_NO_HUGEPAGE_HINT") == nullptr;  // (development: A/B)
-    struct Piece { char *d; size_t bytes; int h; };
-    Piece prev{nullptr, 0, 0};
+    // A destination the CALLER allocated (blk == nullptr) is usually fresh: the copying threads take its page faults.  Transparent
+    // huge pages are asked for once per array (option "fetch_hugepages", default on: a no-op behind numpy, −40 % behind an allocator
+    // that does not ask) — and taken back for what is still to come when a piece's copy stalls (below 2 GB/s: 2-MB faults that wait
+    // for compaction; 4-KB faults in parallel are then the faster way).  A block of the library's own (blk) is faulted in by its
+    // threads, in address order: a piece is copied once the front has passed it.
+    const bool huge_hint = !blk && t->mesh->fetch_hugepages != 0;
+    bool huge_stalled = false;
+    struct Piece { char *d; size_t bytes; int h; char *rest; size_t rest_bytes; };
+    Piece prev{nullptr, 0, 0, nullptr, 0};
     auto drain = [&](const Piece &pc) -> int {  // the piece has arrived in its half: into place
         if (!pc.d) return RT_SUCCESS;
         RT_HIP(hipEventSynchronize(stage.ev[pc.h]));
         const char *hb = (const char *)stage.p + (size_t)pc.h * half;
+        if (blk) blk->wait_front((size_t)(pc.d + pc.bytes - blk->base));
+        const auto t0 = std::chrono::steady_clock::now();
         rthostpar::copy_into_place(pc.d, hb, pc.bytes);
+        if (huge_hint && !huge_stalled && pc.bytes >= ((size_t)4 << 20)) {
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if ((double)pc.bytes / sec < 2.0e9) {
+                huge_stalled = true;
+                rthostpar::unhint_huge_pages(pc.rest, pc.rest_bytes);
+            }
+        }
         return RT_SUCCESS;
     };
     int k = 0;
     for (int a = 0; a < n_arrays; ++a) {
         if (!dst[a]) continue;
+        if (huge_hint && !huge_stalled) rthostpar::hint_huge_pages((char *)dst[a], bytes[a]);  // (one madvise per destination array)
         for (size_t o = 0; o < bytes[a]; o += half, ++k) {
             const size_t nbp = std::min(half, bytes[a] - o);
             const int h = k & 1;
             // (half h was drained two pieces ago: `prev` is the piece in the OTHER half)
             RT_HIP(hipMemcpyAsync((char *)stage.p + (size_t)h * half, (const char *)src[a] + o, nbp, hipMemcpyDeviceToHost, s));
             RT_HIP(hipEventRecord(stage.ev[h], s));
-            if (huge_hint) rthostpar::hint_huge_pages((char *)dst[a] + o, nbp);  // (while the piece is in flight)
             if (int rc = drain(prev)) return rc;
-            prev = Piece{(char *)dst[a] + o, nbp, h};
+            if (huge_stalled && huge_hint) rthostpar::unhint_huge_pages((char *)dst[a] + o, bytes[a] - o);  // (a later array of a stalled fetch)
+            prev = Piece{(char *)dst[a] + o, nbp, h, (char *)dst[a] + o + nbp, bytes[a] - o - nbp};
         }
     }
     const int rc = drain(prev);
@@ -482,6 +499,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "compact")) { mesh->compact = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_gp")) { mesh->sweep_gp = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_ell")) { mesh->sweep_ell = value != 0; return RT_SUCCESS; }
+    if (!strcmp(name, "fetch_hugepages")) { mesh->fetch_hugepages = value != 0; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_rows")) { mesh->sweep_rows = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "sweep_waves")) { mesh->sweep_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "sweep_debug")) { mesh->sweep_debug = (int)value; return RT_SUCCESS; }
@@ -535,6 +553,7 @@ static rt_tracks *tracks_create_impl(rt_mesh *mesh, int64_t n_tracks, const doub
     rthostpar::plan_march_order(ell, n, mesh->sort_mode, mesh->kappa, mesh->test_reserved_pct, rt::kStaticRegions, rt::kChunkRows, plan);
     std::vector<int32_t> &perm = plan.perm;
     std::vector<int32_t> &h_corder = plan.corder;
+    static_assert(rt::kStaticRegions <= (int)(sizeof(plan.reg_cap) / sizeof(plan.reg_cap[0])), "MarchPlan::reg_cap holds every region");
     for (int j = 0; j < rt::kStaticRegions; ++j) t->reg_cap[j] = plan.reg_cap[j];
     {
         // Σℓ in a fixed order (blocks of 4096 tracks, added in block order) whatever the number of threads; range of azim_idx
@@ -1432,6 +1451,52 @@ int32_t rt_fetch_offsets(rt_tracks *t, int64_t *seg_offsets, int32_t *status) {
     void *dst[2] = {seg_offsets, t->n ? status : nullptr};
     const size_t bytes[2] = {sizeof(int64_t) * (size_t)(t->n + 1), sizeof(int32_t) * (size_t)t->n};
     return fetch_pipelined(t, 2, src, dst, bytes);
+}
+
+// ---- a host block owned by the library for everything a fetch returns (rt_hostpar.hpp, ResultBlock)
+struct rt_result {
+    rthostpar::ResultBlock b;
+    int64_t total = 0;
+};
+
+rt_result *rt_result_alloc(rt_mesh *mesh, int64_t n_tracks, double sum_ell, int64_t n_records_hint) {
+    if (!mesh || n_tracks < 0) { set_error("rt_result_alloc: bad arguments"); return nullptr; }
+    // the Cauchy–Crofton estimate of the record count (as the staging pool's): κ·Σℓ + a few per track
+    const int64_t est = n_records_hint > 0 ? n_records_hint : (int64_t)(1.08 * mesh->kappa * std::max(sum_ell, 0.0)) + 2 * n_tracks + 4096;
+    rt_result *r = new (std::nothrow) rt_result();
+    if (!r || !r->b.map_for(n_tracks, est, mesh->fetch_hugepages != 0)) {
+        set_error("rt_result_alloc: no memory for %lld records", (long long)est);
+        delete r;
+        return nullptr;
+    }
+    r->b.prefault_start(std::min(12u, std::max(2u, std::thread::hardware_concurrency() / 2)));  // (in the background: returns at once)
+    return r;
+}
+
+void rt_result_free(rt_result *r) { delete r; }
+
+int32_t rt_result_fetch(rt_tracks *t, rt_result *r, void **host_ptrs, int64_t *total) {
+    if (!t || !r) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
+    RT_HIP(hipSetDevice(t->mesh->device));
+    if (int rc = ensure_compacted(t)) return rc;
+    if (r->b.n_tracks != t->n || r->b.cap_records < t->total) {
+        // the estimate was short (or the block belongs to another track set): a block of the right size, faulted in here
+        if (!r->b.map_for(t->n, t->total + t->total / 64 + 64, t->mesh->fetch_hugepages != 0)) { set_error("rt_result_fetch: no memory"); return RT_ERR_INVALID; }
+        r->b.prefault_start(std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    }
+    rthostpar::ResultBlock &b = r->b;
+    const void *src[8] = {t->offsets.p, t->status.p, t->spx.p, t->spy.p, t->sqx.p, t->sqy.p, t->sell.p, t->element.p};
+    void *dst[8];
+    for (int a = 0; a < 8; ++a) dst[a] = b.base + b.off[a];
+    const size_t nt = (size_t)t->n, nr = (size_t)t->total;
+    const size_t bytes[8] = {8 * (nt + 1), 4 * nt, 8 * nr, 8 * nr, 8 * nr, 8 * nr, 8 * nr, 4 * nr};
+    if (int rc = fetch_pipelined(t, 8, src, dst, bytes, &b)) return rc;
+    r->total = t->total;
+    if (host_ptrs) for (int a = 0; a < 8; ++a) host_ptrs[a] = dst[a];
+    if (total) *total = t->total;
+    return RT_SUCCESS;
 }
 
 int32_t rt_fetch_segments(rt_tracks *t, double *px, double *py, double *qx, double *qy, double *ell,

@@ -46,7 +46,10 @@ def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, dev
     """``segmentize!(t; k=5, rtol=√eps)``.  ``fetch=False`` leaves the results on the device
     (``t.device_tracks.device_pointers()``) for consumers that stay on the GPU; ``fetch="pinned"``
     returns views of page-locked buffers owned by ``t.device_tracks`` (PCIe rate, no page faults;
-    valid until the next ``segmentize`` of ``t``) instead of fresh arrays.  ``walk=False``
+    valid until the next ``segmentize`` of ``t``) instead of fresh arrays; ``fetch=True`` (default) returns arrays over a host block
+    that the library owns and faults in in the background while the tracks are uploaded and the kernels run
+    (``rt_result_alloc``, round 6: what makes one call independent of the box's huge-page state; the arrays keep the block
+    alive); ``fetch="fresh"``: numpy arrays allocated here, filled by ``rt_fetch_*`` (rounds 4-5).  ``walk=False``
     disables the certified walk step of the device march (every iteration then runs the
     literal locate + intersect step); results are identical either way.  ``check=False`` does
     not raise for failed tracks (the reference would have thrown at the first one) and leaves
@@ -61,6 +64,8 @@ def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, dev
     old = getattr(t, "device_tracks", None)
     if old is not None:
         old.close()
+    # (the destination first: its pages are faulted in beside the upload and the kernels)
+    blk = dm.result_alloc(len(t.ell), float(np.sum(t.ell))) if fetch is True else None
     dt = _capi.DeviceTracks(dm, t.px, t.py, t.phi, t.cos_phi, t.sin_phi, t.A, t.B, t.C, t.ell, t.azim_idx)
     t.device_tracks = dt
     aq = t.azimuthal_quadrature
@@ -71,6 +76,8 @@ def segmentize(t: TrackGenerator, *, k: int = 5, rtol: float = RTOL_DEFAULT, dev
     if fetch:
         if fetch == "pinned":
             off, t.track_status, s = dt.fetch_pinned()
+        elif blk is not None:
+            off, t.track_status, s = dt.fetch_result(blk)
         else:
             off, t.track_status = dt.fetch_offsets()
             s = dt.fetch_segments()

@@ -190,8 +190,44 @@ static void test_fetch(size_t bytes, size_t block_bytes, std::mt19937 &rng) {
     free(dst);
 }
 
+// The library-owned result block (rt_result_alloc): mapped, faulted in by its background threads in address order, a "fetch" that
+// copies behind the front (as fetch_pipelined does: wait_front, then the team's copy_into_place), a block replaced by a larger one
+// while its threads still run, a block released while they run.
+static void fail(const char *what) { fprintf(stderr, "hostpar_san: %s\n", what); ++g_fail; }
+static void test_result_block(int64_t n_tracks, int64_t n_records, bool huge) {
+    rthostpar::ResultBlock b;
+    if (!b.map_for(n_tracks, n_records, huge)) { fail("result block: map_for"); return; }
+    b.stall_ms = 0.05;  // (exercise the 4-KB fallback's madvise on some units)
+    b.prefault_start(4);
+    const size_t len[8] = {8 * (size_t)(n_tracks + 1), 4 * (size_t)n_tracks, 8 * (size_t)n_records, 8 * (size_t)n_records, 8 * (size_t)n_records,
+                           8 * (size_t)n_records, 8 * (size_t)n_records, 4 * (size_t)n_records};
+    std::vector<char> src((size_t)3 << 20);
+    for (size_t i = 0; i < src.size(); ++i) src[i] = (char)(i * 131u + 7u);
+    for (int a = 0; a < 8; ++a) {
+        char *dst = b.base + b.off[a];
+        if (a + 1 < 8 && b.off[a] + len[a] > b.off[a + 1]) fail("result block: arrays overlap");
+        for (size_t o = 0; o < len[a]; o += src.size()) {
+            const size_t nb = std::min(src.size(), len[a] - o);
+            b.wait_front((size_t)(dst + o + nb - b.base));
+            rthostpar::copy_into_place(dst + o, src.data(), nb);
+        }
+    }
+    for (int a = 0; a < 8; ++a)
+        for (size_t o = 0; o < len[a]; o += 4099)
+            if (b.base[b.off[a] + o] != src[o % src.size()]) { fail("result block: a copied byte was overwritten by the faulting threads"); break; }
+    // a larger block while the threads of the first may still be running, then release while running
+    if (!b.map_for(n_tracks, 2 * n_records + 1, huge)) { fail("result block: second map_for"); return; }
+    b.prefault_start(3);
+    b.wait_front(b.bytes / 2);
+    b.release();
+    if (b.base) fail("result block: release");
+}
+
 int main() {
     std::mt19937 rng(20261004);
+    test_result_block(1000, 300000, true);
+    test_result_block(1, 1, false);
+    test_result_block(130456, 1200000, true);
     test_par_ranges();
     for (size_t n : {(size_t)1, (size_t)63, (size_t)64, (size_t)130456, (size_t)300000, (size_t)65 * 4200 + 17})
         for (int mode = 0; mode < 3; ++mode) test_plan(n, mode, rng);
@@ -207,6 +243,6 @@ int main() {
         for (int c = 0; c < 4; ++c) th.emplace_back([c] { std::mt19937 r2(77 + c); test_upload(90000 + 1000 * (size_t)c, 2u << 20, r2); test_fetch((5u << 20) + c, 1u << 20, r2); });
         for (auto &t : th) t.join();
     }
-    printf("hostpar_san: %s\n", g_fail ? "FAILED" : "par_ranges, march plans (18 sets x 3 modes), uploads (image / ranges / concurrent), fetch drains: ok");
+    printf("hostpar_san: %s\n", g_fail ? "FAILED" : "par_ranges, march plans (18 sets x 3 modes), uploads (image / ranges / concurrent), fetch drains, result blocks: ok");
     return g_fail ? 1 : 0;
 }
