@@ -132,6 +132,7 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
     # ---- the mesh handle (src/mesh.jl:10-31 flattened to the SoA arrays rt_mesh_create takes) is cached per mesh
     hm = mesh_handle(t.mesh, device)
     ht = C_NULL
+    hr = C_NULL     # rt_result: the host block the library owns for this call's results (round 6)
     views = nothing
     try
         # ---- per-track inputs in uid order (src/track.jl:42-54); cos/sin by the host libm,
@@ -144,6 +145,11 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
         C = Float64[tr.ABC[3] for tr in tracks]
         ℓ = Float64[tr.ℓ for tr in tracks]
         azim = Int32[tr.azim_idx for tr in tracks]
+        # ---- the destination FIRST (eager rebuild without page-locking): a block the library maps, asks huge pages for and faults in
+        #      on threads of its own from here on — beside the upload and the kernels below (rt_result_alloc returns at once)
+        if !pinned
+            hr = ccall((:rt_result_alloc, LIB), Ptr{Cvoid}, (Ptr{Cvoid}, Int64, Float64, Int64), hm, n, sum(ℓ), 0)
+        end
         ht = ccall((:rt_tracks_create, LIB), Ptr{Cvoid},
                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
@@ -178,6 +184,17 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
             spx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total); spy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total)
             sqx = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[6]), total)
             sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[7]), total); sel = unsafe_wrap(Array, Ptr{Int32}(hp[8]), total)
+        elseif hr != C_NULL
+            # offsets, status and the six record arrays into the library's block, copied behind the front of its page faults;
+            # unsafe_wrap(own = false): Julia never frees the memory — rt_result_free does, in the `finally` below, after the
+            # Segments have been built from it
+            hp = Vector{Ptr{Cvoid}}(undef, 8); tot = Ref{Int64}(0)
+            rc = ccall((:rt_result_fetch, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ref{Int64}), ht, hr, hp, tot)
+            rc != 0 && error("rt_result_fetch: " * lasterror())
+            offs = unsafe_wrap(Array, Ptr{Int64}(hp[1]), n + 1; own=false)
+            spx = unsafe_wrap(Array, Ptr{Float64}(hp[3]), total; own=false); spy = unsafe_wrap(Array, Ptr{Float64}(hp[4]), total; own=false)
+            sqx = unsafe_wrap(Array, Ptr{Float64}(hp[5]), total; own=false); sqy = unsafe_wrap(Array, Ptr{Float64}(hp[6]), total; own=false)
+            sℓ = unsafe_wrap(Array, Ptr{Float64}(hp[7]), total; own=false); sel = unsafe_wrap(Array, Ptr{Int32}(hp[8]), total; own=false)
         else
             offs = Vector{Int64}(undef, n + 1)
             spx = Vector{Float64}(undef, total); spy = similar(spx); sqx = similar(spx); sqy = similar(spx); sℓ = similar(spx)
@@ -211,6 +228,7 @@ function segmentize_amd!(t::TrackGenerator{Float64}; k::Int=5, rtol::Real=Base.r
         materialize && ccall((:rt_fetch_volumes, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), ht, t.volumes)
     finally
         ht != C_NULL && ccall((:rt_tracks_destroy, LIB), Cvoid, (Ptr{Cvoid},), ht)
+        hr != C_NULL && ccall((:rt_result_free, LIB), Cvoid, (Ptr{Cvoid},), hr)   # (the eager rebuild has copied everything out)
     end
     return materialize ? t : (t, views)
 end
