@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
     LOAD(rt_abi_version) LOAD(rt_last_error) LOAD(rt_status_message) LOAD(rt_device_count)
     LOAD(rt_mesh_create) LOAD(rt_mesh_destroy) LOAD(rt_mesh_info) LOAD(rt_tracks_create) LOAD(rt_tracks_destroy)
     LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_pinned) LOAD(rt_fetch_volumes)
+    LOAD(rt_result_alloc) LOAD(rt_result_fetch) LOAD(rt_result_free)
     LOAD(rt_multi_create) LOAD(rt_multi_destroy) LOAD(rt_multi_segmentize) LOAD(rt_multi_failed_tracks) LOAD(rt_multi_fetch_offsets)
     LOAD(rt_multi_fetch_segments) LOAD(rt_multi_fetch_volumes) LOAD(rt_multi_shards)
     LOAD(rt_sweep_set_links) LOAD(rt_sweep) LOAD(rt_sweep_fetch) LOAD(rt_sweep_info)
@@ -123,6 +124,11 @@ int main(int argc, char **argv) {
     char note[128];
     p_rt_mesh_info(hm, info, RT_MESH_INFO_COUNT, note, sizeof note);
     walk_enabled = (int32_t)info[RT_MESH_INFO_WALK_ENABLED];
+    /* the destination first (round 6): a host block of the library's, faulted in in the background from here on */
+    double sum_ell = 0.0;
+    for (int64_t u = 0; u < n; ++u) sum_ell += ell[u];
+    rt_result *hr = p_rt_result_alloc(hm, n, sum_ell, 0);
+    if (!hr) { fprintf(stderr, "rt_result_alloc: %s\n", p_rt_last_error()); return 1; }
     ht = p_rt_tracks_create(hm, n, px, py, phi, cs, sn, A, B, C, ell, azim);
     if (!ht) { fprintf(stderr, "rt_tracks_create: %s\n", p_rt_last_error()); return 1; }
     total = p_rt_segmentize(ht, 1e-8, 5, rtol, delta_s, n2);
@@ -138,6 +144,15 @@ int main(int argc, char **argv) {
         return 1;
     }
     for (int a = 0; a < 6; ++a) hp[a] = hp8[2 + a];
+    {   /* ... and the library's own host block holds the same bytes (what the shim's eager rebuild reads) */
+        void *hb8[8];
+        int64_t tot2 = -1;
+        if (p_rt_result_fetch(ht, hr, hb8, &tot2)) { fprintf(stderr, "rt_result_fetch: %s\n", p_rt_last_error()); return 1; }
+        int same = tot2 == total && !memcmp(offs, hb8[0], sizeof(int64_t) * ((size_t)n + 1)) && !memcmp(status, hb8[1], sizeof(int32_t) * (size_t)n);
+        for (int a = 0; a < 6 && same; ++a) same = !memcmp(hp8[2 + a], hb8[2 + a], (size_t)total * (a < 5 ? sizeof(double) : sizeof(int32_t)));
+        if (!same) { fprintf(stderr, "rt_result_fetch: the block differs from rt_fetch_pinned\n"); return 1; }
+        p_rt_result_free(hr);
+    }
     if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
     /* ---- a consumer that stays on the device: one transport sweep over the cyclic tracks with the linking rt_trace produced
      *      (next_track_fwd / next_track_bwd, dir_next_track_*, bc_*: src/trackgenerator.jl:231-348), two groups */
