@@ -974,8 +974,8 @@ RT_HD __forceinline__ bool sum_check_is_marginal(double ell, double sum, double 
 // p of a record IS the q before it, bit for bit — so Σ‖p_i − q_i‖ = ‖p_0 − q_0‖ + (q_last − q_0)·d, d = (cos ϕ, sin ϕ) the march's
 // direction, up to the roundings of n norms and their sum.  Only a record that keeps its OWN p (a generic step's, behind tiny steps)
 // breaks the chain; `chain_gap_term` is what such a record i contributes to the correction `gap` that `chain_sum` subtracts:
-//   * the signed gap (p_i − b_i)·d-wise in front of it (b_i = the exit point of the record before; a record that begins BEHIND that
-//     point — cells that overlap within the locate's tolerance — counts negative: its overlap is IN Σℓ),
+//   * the gap in front of it, (p_i − b_i)·d (b_i = the exit point of the record before; a record that begins BEHIND that point —
+//     cells that overlap within the locate's tolerance — counts negative: its overlap is IN Σℓ),
 //   * and minus twice its own length if its two points are in the wrong order along d (order_intersection_points compares x
 //     coordinates, src/intersection.jl:151-159, which near ϕ = π/2 are equal to the last bit): such a record walks backwards, the
 //     projection subtracts its length where Σℓ adds it.
@@ -984,8 +984,12 @@ RT_HD __forceinline__ bool sum_check_is_marginal(double ell, double sum, double 
 // `coord_max`) could decide the other way: k_finish sums those left to right; 1 = LENGTH_MISMATCH for sure; 0 = OK for sure.
 // Host twin: tests/host_march.hip drives these on the checker's records (tests/test_sum_chain_cpu.py, tools/fuzz_cpu.py).
 RT_HD __forceinline__ double chain_gap_term(double px, double py, double qx, double qy, double ell, double bx, double by, double dx, double dy) {
-    const double g = norm2(px - bx, py - by);
-    double acc = (px - bx) * dx + (py - by) * dy < 0.0 ? -g : g;
+    // The gap's PROJECTION on d, not its length: the span (q_last − q_first)·d that chain_sum starts from contains exactly this
+    // projection.  (Round 5 took ±‖p − b‖.  The two differ when the gap is not along the line: the exit points of a SHALLOW crossing
+    // — an edge within 1e-7 … 1e-3 rad of the track — lie off the line by u·R / sin, 1e-10 on a mesh 13 units from the origin, and a gap
+    // of 4.5e-10 between two such points was 1.5e-11 longer than its projection: outside the band, found by the host twin of this
+    // function at a tolerance tuned to the track, tools/fuzz_cpu.py seed 710227.)
+    double acc = (px - bx) * dx + (py - by) * dy;
     if ((qx - px) * dx + (qy - py) * dy < 0.0) acc -= 2.0 * ell;
     return acc;
 }

@@ -25,6 +25,16 @@ def _problems(rt):
         tg = rt.TrackGenerator(model, 16, 0.004)
         rt.trace(tg)
         yield "mesh %d" % seed, tg
+    # the case that found the round-5 chain's error (tools/fuzz_cpu.py seed 710227, class `aligned`: lattice rows within 1e-7 … 3e-3 rad
+    # of a track direction, 11 units from the origin): a gap between two exit points of SHALLOW crossings is not along the line — its
+    # length exceeded its projection by 1.5e-11, and at a tolerance next to that track's |ℓ − Σℓ| the chain decided the other way
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_cpu
+    kind, model, n_azim, delta, k = fuzz_cpu.case(710227)
+    tg = rt.TrackGenerator(model, n_azim, delta)
+    rt.trace(tg)
+    yield "fuzz seed 710227 (%s)" % kind, tg
     # tracks of more than 256 records (the kernel's rounds): a fine lattice crossed lengthwise
     model = meshgen.lattice_model(rt, 6, 200, 4, jitter=0.2, w=4.0, h=0.1)
     tg = rt.TrackGenerator(model, 4, 0.01)
