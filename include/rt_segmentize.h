@@ -261,7 +261,9 @@ int32_t rt_fetch_tau(rt_tracks *tracks, double *tau);
  * rt_sweep_fetch copies out (any may be NULL) phi[n_cells * G], psi_out[2][n_tracks][G] (the flux every traversal ended with)
  * and psi_next[2][n_tracks][G] (the boundary flux of the next sweep).  rt_sweep_info: the device pointers of those three
  * (ptrs_dev[3], may be NULL) and info[4] = {input used (1 / 2), groups per pass (0: global atomics), passes, n_groups}.
- * Results agree with a sequential evaluation to rounding: device expm1 and the order of the tallies' additions differ.
+ * Results agree with a sequential evaluation to rounding: device expm1 and the order of the tallies' additions differ — and the
+ * attenuation factor of an optically thin segment takes one of two forms (2 ulp apart) by what the other 63 lanes of its wave hold, so
+ * the fluxes are not bitwise invariant across march orders / shardings of one problem (rt_set_option "sweep_debug" 4: one form always).
  */
 int32_t rt_sweep_set_links(rt_tracks *tracks, const int64_t *next_fwd, const int64_t *next_bwd, const int8_t *dir_fwd,
                            const int8_t *dir_bwd, const int8_t *bc_fwd, const int8_t *bc_bwd);

@@ -231,9 +231,11 @@ bool staging_new_block(StagingBlock &b, int device) {
 // and its own preprocessing and upload take longer than that — so that the first rt_tracks_create does not wait for it.
 struct StagingPrefetch {
     std::thread th;
-    std::once_flag once, joined;
+    std::once_flag once;
+    std::mutex join_m;  // (wait() before start() must not use up the join: the thread started later would never be joined)
     void start(int device) {
         std::call_once(once, [&] {
+            std::lock_guard<std::mutex> lk(join_m);
             try {
                 th = std::thread([device] {
                     StagingBlock b;
@@ -247,7 +249,10 @@ struct StagingPrefetch {
         });
     }
     // (rt_multi_create reaches this from several host threads at once: the join happens once, the others wait for it)
-    void wait() { std::call_once(joined, [&] { if (th.joinable()) th.join(); }); }
+    void wait() {
+        std::lock_guard<std::mutex> lk(join_m);
+        if (th.joinable()) th.join();
+    }
     ~StagingPrefetch() { wait(); }
 } g_staging_prefetch;
 int staging_acquire(StagingBlock *out, int device) {

@@ -91,6 +91,9 @@ __global__ __launch_bounds__(1024) void k_sweep(DSweep a) {
             }
             // −expm1(−τ) to within an ulp (rt_device.hpp): where every lane's segment is optically thin in every group of the pass —
             // a wave-uniform branch — by the series alone (10 instructions per group instead of 24)
+            // (The choice is per WAVE-row: a segment takes the series when the other 63 lanes' segments are thin too, else the general
+            //  form — the two agree to 2 ulp, so ψ_out is NOT bitwise invariant across march orders, sort modes or shardings of the
+            //  same problem; the tests compare at 1e-12.  "sweep_debug" 4 = the general form everywhere: the reproducible mode.)
             if (__ballot(!thin) == 0 && !(a.debug & 4)) {
 #pragma unroll
                 for (int g = 0; g < GP; ++g) {
