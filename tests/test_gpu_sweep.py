@@ -80,10 +80,14 @@ def test_sweep_matches_sequential_sweep_over_oracle_records(rt, orc, mesh, n_azi
         assert not nxt1.any()
     # (a batch this small is marched in pieces by default: the staging rows of a compacting call are whole tracks only with
     #  "split" = 0; "compact" = 0 marches whole tracks by itself)
-    for compact, inp, opts in ((1, "compact", {}), (0, "staged", {}), (1, "staged", {"split": 0}), (0, "compact", {})):
+    # (round 6: the compact records are swept as (ℓ, cell) rows — made once from the records themselves when the call left no
+    #  whole-track staging, "rows from compact", or the staging's; "sweep_rows" 0 = the records where they lie, 2 = always from the records)
+    for compact, inp, opts, rows in ((1, "compact", {}, "from compact"), (0, "staged", {}, "staging"), (1, "staged", {"split": 0}, "staging"),
+                                     (0, "compact", {}, "staging"), (1, "compact", {"sweep_rows": 0}, None),
+                                     (1, "compact", {"sweep_rows": 2, "split": 0}, "from compact"), (0, "compact", {"sweep_rows": 0}, None)):
         dm, dt = _device(rt, tg, compact, **opts)
         r = dt.sweep(G, sigma_t, source, weight, psi_in, input=inp)
-        assert r["input"] == inp
+        assert r["input"] == inp and r["rows"] == rows, (r["input"], r["rows"], inp, rows, opts)
         e = [_close(r["phi"], phi1, "phi"), _close(r["psi_out"], out1, "psi_out"), _close(r["psi_next"], nxt1, "psi_next")]
         r2 = dt.sweep(G)  # everything from the device: cross sections, weights, the boundary flux handed on
         e += [_close(r2["phi"], phi2, "phi, 2nd sweep"), _close(r2["psi_out"], out2, "psi_out, 2nd sweep")]
