@@ -93,8 +93,9 @@ def kernel_names(stats):
     w = stats["march_waves"]
     sp = stats["split"] == 1
     cheap = stats.get("cheap_records", 0) > 0  # the TOPO instantiation (cheap steps) ran
-    return {"march": "rt::k_march<2, %d, %s, %s, %s>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
-                                                           "true" if cheap else "false"),
+    # (the template's last argument: the lean plan's phase — 0 = the march in one kernel, what the default options run)
+    return {"march": "rt::k_march<2, %d, %s, %s, %s, 0>" % (w, "true" if sp else "false", "true" if stats["wide_k"] else "false",
+                                                              "true" if cheap else "false"),
             # (the record kernel by what the call launched — rt_last_stats[23]: a two-phase call falls back to k_materialise for
             #  arrays of 2^29 records or with option "mat_kernel" 1)
             "compact": (stats.get("record_kernel") or ("rt::k_materialise_lin" if cheap else "rt::k_compact3")) +
