@@ -206,6 +206,27 @@ void rt_result_free(rt_result *result);
 int32_t rt_device_pointers(rt_tracks *tracks, void **ptrs_dev);
 
 /*
+ * Records in COMPLETION order (round 6; rt_set_option(mesh, "record_order", 1 | 2)).  The reference keeps a Vector{Segment} per
+ * track (track.segments, src/track.jl:18) and no order between tracks; a call under this option leaves every track's records
+ * contiguous and in march order, as always, but the TRACKS in the order in which the march's workgroups ended: a workgroup that has
+ * finished its tracks takes their span of the six arrays from an atomic cursor, and the record-writing kernel runs beside the rest
+ * of the march instead of behind it (C3: -20 % per step).  What describes the layout is the per-track table
+ *   seg_begin[n_tracks]   first record of track u        seg_count[n_tracks]   its number of records
+ * rt_record_order: 1 if the handle's records currently lie in completion order, 0 if in CSR order (uid order).
+ * rt_device_table: ptrs_dev[10] = seg_begin (i64), seg_count (i32), status (i32), px, py, qx, qy, ell (f64), element (i32),
+ *   volumes (f64) — valid in either order, never rewrites anything (in CSR order seg_begin is seg_offsets).
+ * rt_fetch_table / rt_fetch_records: the table and the six arrays as they lie on the device, to the host.
+ * Every other entry point that hands out records (rt_fetch_offsets / _segments / _pinned, rt_result_fetch, rt_device_pointers,
+ * rt_fill_tau, rt_sweep over the compact records, rt_multi_*) promises the CSR layout: on a handle in completion order it first
+ * rewrites the records in uid order — once, by the record kernel's second run over the staged words (0.12 ms at C3) — and the
+ * handle is in CSR order from then on.
+ */
+int32_t rt_record_order(rt_tracks *tracks);
+int32_t rt_device_table(rt_tracks *tracks, void **ptrs_dev);
+int32_t rt_fetch_table(rt_tracks *tracks, int64_t *seg_begin, int32_t *seg_count, int32_t *status);
+int32_t rt_fetch_records(rt_tracks *tracks, double *px, double *py, double *qx, double *qy, double *ell, int32_t *element);
+
+/*
  * A consumer of the device-resident records (the reference's consumption pattern is
  * "for track in tg.tracks_by_uid, for segment in track.segments: segment.ℓ, segment.element", README.md:127-135, and
  * Segment.τ is its "storage for transport-related data (e.g., optical thickness)", src/segment.jl:14,28): for every
@@ -306,7 +327,8 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
  * length by the second kernel of the two-phase march (a short chord or a shallow crossing: the chord from the vertices' distances
  * would not be within 4e-11 of it — DESIGN.md §2).
  * stats[21] the lean plan of the call's march (option "lean"; 0: one kernel), stats[22] the lanes its k_serve finished; stats[23] the
- * kernel that wrote the call's records (1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows).
+ * kernel that wrote the call's records (1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows);
+ * stats[24] 1 if the call wrote its records beside the march, in completion order (option "record_order").
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 

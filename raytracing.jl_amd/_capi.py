@@ -19,6 +19,7 @@ SYMBOLS = (
     "rt_mesh_create", "rt_mesh_destroy", "rt_mesh_info", "rt_last_stats", "rt_mesh_set_stream", "rt_mesh_get_stream", "rt_mesh_set_enqueue_hook",
     "rt_tracks_create", "rt_tracks_destroy", "rt_segmentize", "rt_failed_tracks", "rt_wait",
     "rt_fetch_offsets", "rt_fetch_segments", "rt_fetch_segments_pinned", "rt_fetch_pinned", "rt_fetch_volumes", "rt_device_pointers",
+    "rt_record_order", "rt_device_table", "rt_fetch_table", "rt_fetch_records",
     "rt_result_alloc", "rt_result_fetch", "rt_result_free",
     "rt_last_timing", "rt_set_option", "rt_fill_tau", "rt_fetch_tau",
     "rt_sweep_set_links", "rt_sweep", "rt_sweep_fetch", "rt_sweep_info", "rt_sweep_rows_kind", "rt_sweep_xs_pointer", "rt_multi_link_rates",
@@ -130,6 +131,14 @@ def lib():
     L.rt_fetch_volumes.argtypes = [_vp, _dp]
     L.rt_device_pointers.restype = C.c_int32
     L.rt_device_pointers.argtypes = [_vp, C.POINTER(_vp)]
+    L.rt_record_order.restype = C.c_int32
+    L.rt_record_order.argtypes = [_vp]
+    L.rt_device_table.restype = C.c_int32
+    L.rt_device_table.argtypes = [_vp, C.POINTER(_vp)]
+    L.rt_fetch_table.restype = C.c_int32
+    L.rt_fetch_table.argtypes = [_vp, _lp, _ip, _ip]
+    L.rt_fetch_records.restype = C.c_int32
+    L.rt_fetch_records.argtypes = [_vp, _dp, _dp, _dp, _dp, _dp, _ip]
     L.rt_last_timing.restype = C.c_int32
     L.rt_last_timing.argtypes = [_vp, _dp, C.c_int32]
     L.rt_set_option.restype = C.c_int32
@@ -439,6 +448,40 @@ class DeviceTracks:
         names = ("offsets", "status", "px", "py", "qx", "qy", "ell", "element", "volumes")
         return {k: (arr[i] or 0) for i, k in enumerate(names)}
 
+    # ---- records in completion order (mesh option "record_order"): the per-track table
+    def record_order(self) -> int:
+        """``rt_record_order``: 1 if the handle's records lie in completion order (tracks in the order in which the march's
+        workgroups ended; every track's records contiguous), 0 if in CSR order (uid order)."""
+        rc = lib().rt_record_order(self._h)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def device_table(self):
+        """``rt_device_table``: device addresses of seg_begin, seg_count, status, px, py, qx, qy, ell, element, volumes — in
+        whichever order the records lie; nothing is rewritten."""
+        arr = (_vp * 10)()
+        _check(lib().rt_device_table(self._h, arr))
+        names = ("seg_begin", "seg_count", "status", "px", "py", "qx", "qy", "ell", "element", "volumes")
+        return {k: (arr[i] or 0) for i, k in enumerate(names)}
+
+    def fetch_table(self):
+        """``rt_fetch_table``: (seg_begin, seg_count, status) — track u's records are [seg_begin[u], seg_begin[u] + seg_count[u])
+        of the arrays ``fetch_records`` returns."""
+        n = max(self.n, 1)
+        beg, cnt, st = np.zeros(n, np.int64), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        _check(lib().rt_fetch_table(self._h, beg.ctypes.data_as(_lp), cnt.ctypes.data_as(_ip), st.ctypes.data_as(_ip)))
+        return beg[: self.n], cnt[: self.n], st[: self.n]
+
+    def fetch_records(self):
+        """``rt_fetch_records``: the six record arrays as they lie on the device (see ``fetch_table``)."""
+        n = self.total
+        out = {k: np.empty(n, np.float64) for k in ("px", "py", "qx", "qy", "ell")}
+        out["element"] = np.empty(n, np.int32)
+        _check(lib().rt_fetch_records(self._h, *[out[k].ctypes.data_as(_dp) for k in ("px", "py", "qx", "qy", "ell")],
+                                      out["element"].ctypes.data_as(_ip)))
+        return out
+
     def fill_tau(self, sigma_t, fetch=True):
         """``rt_fill_tau``: τ[s, g] = Σt[element[s], g]·ℓ[s] on the device (``Segment.τ``, src/segment.jl:14,28).  ``sigma_t``:
         [n_cells, n_groups].  Returns (τ as a [total, n_groups] host array or None, device pointer, kernel ms)."""
@@ -517,13 +560,13 @@ class DeviceTracks:
 
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
-        v = (C.c_int64 * 24)()
-        _check(lib().rt_last_stats(self._h, v, 24))
+        v = (C.c_int64 * 25)()
+        _check(lib().rt_last_stats(self._h, v, 25))
         return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
                     chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]), device_bytes=int(v[7]),
                     cheap_records=int(v[8]), cheap_refusals={k: int(v[9 + i]) for i, k in enumerate(self.REFUSAL_TERMS)},
                     tracks_near_rtol=int(v[18]), tracks_restarted=int(v[19]), records_tallied_from_lengths=int(v[20]),
-                    lean=int(v[21]), lean_queued=int(v[22]),
+                    lean=int(v[21]), lean_queued=int(v[22]), completion_order=int(v[24]),
                     record_kernel={0: None, 1: "rt::k_compact3", 2: "rt::k_materialise<true, false>", 3: "rt::k_materialise_lin",
                                    4: "rt::k_materialise<false, true>"}.get(int(v[23])))
 

@@ -131,6 +131,15 @@ struct DStage {
     RT_G double *s_px, *s_py, *s_qx, *s_qy;
     RT_G int32_t *s_el;     // cell + 1
     int32_t side_cap, side_static;
+    // Records in COMPLETION order (round 6; option "record_order"): cq non-null — a march workgroup that has
+    // ended takes the span of its tracks' records from the cursor in the control block (word kCtlCq), writes its tracks' offsets
+    // (off_slot by march slot, tab_off by uid), releases and appends its index to this queue; the record kernel runs BESIDE the
+    // march on a second stream and its workgroups take the units of the k-th march workgroup to finish.
+    RT_G unsigned long long *cq;       // [cq_blocks] (epoch << 32) | march workgroup; entries of earlier calls carry older epochs
+    RT_G int64_t *tab_off;             // [n] first record of every track, uid order
+    unsigned long long *cq_started;    // pinned host memory, [8]: the grid's last eight workgroups store the epoch when they start
+    uint32_t cq_epoch;
+    int32_t cq_blocks;
 #ifdef RT_TIMING
     unsigned long long *dbg;  // [n_waves][4] development: cycles, wave iterations, generic iterations, emits of the first lane
 #endif
@@ -152,6 +161,8 @@ constexpr int kCtlRefusal = 32;   // 32..40: cheap-step refusals by certificate 
 constexpr int kCtlRestarts = 41;  // tracks marched again with exact steps after cheap steps (their fused volumes were counted twice)
 constexpr int kCtlExactTally = 43;  // cheap records whose fill_volumes term k_materialise adds from the record's own length
 constexpr int kCtlNearRtol = 42;  // tracks whose Σℓ check (src/track.jl:171) sits within summation-order noise of its threshold
+constexpr int kCtlCq = 48;        // 48: records handed out to march workgroups (the completion-order cursor), 49: workgroups in the
+                                  // completion queue, 50: the record kernel beside the march gave up waiting (the attempt is void)
 constexpr int kCtlDeferred = 27;      // k_finish: tracks whose exact Σℓ it could not form (their records lie beyond the arrays' capacity)
 // generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
 // C3 — a lane that escalates waits for the rest of its wave — 8..32 equal)
@@ -248,6 +259,10 @@ struct DMat {
     int32_t tally;                // 1: Σℓ + status (the call's first pass over the codes); 0: records / rows only
     int32_t force_exact;          // tests: every track takes k_finish's left-to-right sum
     int32_t marg_cap;
+    // QUEUE (records in completion order, beside the march): workgroup b takes unit b mod (4 q_waves) of the (b / (4 q_waves))-th
+    // march workgroup in the completion queue (DStage::cq)
+    int32_t q_waves;              // waves per march workgroup
+    int32_t n_waves;              // march waves of the batch
     RT_G int32_t *marg;           // [0] count, [1 ...] march slots of the tracks k_finish has to sum exactly
     RT_G double *ell_rows;        // ROWS
     RT_G int32_t *cell_rows;
@@ -323,6 +338,8 @@ struct rt_mesh {
                            // refused often does not hand back to exact steps (tests and fuzzing: every cheap certificate is exercised)
     int async_calls = 0;   // 1: rt_segmentize returns once total, status summary and offsets' scan are known to the host; the
                            // compaction may still be running on the stream (every entry point that touches results waits)
+    int record_order = 0;  // 0: the records in CSR order (uid order); 1: in completion order when the plan allows it and every march
+                           // workgroup is resident at once (the record kernel then runs beside the march); 2: whenever the plan allows
     int lean = 0;          // the march of a two-phase call in three kernels (DLean): 0 no, 1 k_serve behind k_cheap, 2 beside it (second stream)
     int serve_blocks = 0;  // workgroups of k_serve (0: 64)
     int cheap_per_cu = 0;  // experiments: workgroups of k_cheap per CU (0: automatic)
@@ -444,9 +461,20 @@ struct rt_tracks {
         int64_t n_whole_waves = 0;
         bool split = false, split_all = false, staged = false;  // staged: the last call left staged rows (single-pass mode)
         bool codes = false;   // ... as one word per record (k_march<TOPO>): k_materialise turns them into records / (ℓ, cell) rows
+        int march_waves = 4;  // waves per workgroup of the whole-track march
         double rtol = 0.0;
     } cplan;
-    bool compacted = false;  // the six record arrays hold the last call's records
+    bool compacted = false;  // the six record arrays hold the last call's records in CSR order (uid order)
+    // Records in COMPLETION order (option "record_order"): the six arrays hold the last call's records, every track's contiguous,
+    // at tab_off[uid] (off_slot[march slot]) — the order in which the march's workgroups ended.  rt_device_table hands out the
+    // table; every entry point that promises the CSR layout goes through ensure_compacted, which rewrites them once.
+    bool completion_order = false;
+    bool completion_gave_up = false;   // the record kernel beside the march once waited in vain: this handle stays with CSR order
+    DevBuf<int64_t> tab_off;           // [n]
+    DevBuf<unsigned long long> cq;     // [march workgroups] the completion queue (DStage::cq)
+    unsigned long long *cq_started = nullptr;  // pinned, [8]
+    unsigned long long cq_epoch_last = 0;
+    int32_t last_completion = 0;       // rt_last_stats: the last call wrote its records beside the march
     bool in_flight = false;  // option "async": the last rt_segmentize returned while its compaction was still on the stream
     unsigned long long call_seq = 0;  // sequence number the scan writes behind its host copy of the control block
     // rt_sweep: the gather map of the cyclic linking, per-track weights, cross sections, boundary fluxes, tallies
@@ -480,12 +508,13 @@ int upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s) {
 }
 // rt_records.hip
 int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out);
-int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl);
+int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl, bool queue = false);
+bool lin_kernel_serves(const rt_tracks *t, const rt::DOut &out);  // k_materialise_lin can write this call's records
 // rt_materialise.hip
 void launch_materialise_lin(const rt::DTracks &d, int32_t *status, const rt::DStage &stg, const rt::DOut &out, const rt::DMat &a, hipStream_t s,
-                            int n_cus, int units_per_wg);
+                            int n_cus, bool queue = false);
 void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_rows, bool scale_volumes, double n_azim_2,
-                   unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq);
+                   unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq, bool completion_order = false);
 void launch_compaction(rt_tracks *t, const rt::DOut &out, hipStream_t s);
 int ensure_compacted(rt_tracks *t);
 int ensure_rows(rt_tracks *t);
@@ -493,7 +522,7 @@ int ensure_rows_from_compact(rt_tracks *t);  // rt_sweep.hip
 void launch_prologue(hipStream_t s, unsigned long long *ctl, double *volumes, int32_t n_cells, int32_t first_chunk, int32_t side_first);
 // the exclusive scan of the counts (two kernels); see k_scan_tile_sums / k_scan_write for the optional pointers
 void launch_scan_fused(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, const int32_t *tile_acc, int32_t *tile_acc_next,
-                       unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next);
+                       unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next, bool write_slots = true);
 void launch_scan(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, unsigned long long *host_copy,
                  unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next, unsigned long long seq,
                  double *scale_volumes, double n_azim_2, bool slot_order);

@@ -199,8 +199,15 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         for (int c = lane; c < kMaxChunks; c += 64) chunk_lds[c] = -1;
         if (FUSE)
             for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) hist[c] = 0.0;
+        // Records in completion order (DStage::cq): the host launches the record kernel BESIDE this one only when the grid's last
+        // workgroups have started — workgroups are dealt to the XCDs in turn and every XCD starts its share in order, so the last
+        // eight starting means that every workgroup has its slots (or, a batch of several residency rounds, that the last round has
+        // begun): the record kernel's waiting workgroups can then never keep a march workgroup off the chip.
+        if (TOPO && PHASE == 0 && FUSE && sk->cq && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x)
+            __hip_atomic_store(sk->cq_started + (gridDim.x - 1 - blockIdx.x), (unsigned long long)sk->cq_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
     }
+    int32_t end_cnt = 0, end_u = -1;  // (completion order: what the lane's track left — read behind the march, where the workgroup takes its span)
     for (;;) {  // (PHASE 2: one pass per claim of queued slots; else a single pass)
     int64_t wave_id = (int64_t)blockIdx.x * WAVES + wib;  // indexes the wave's chunk table (ctab)
     int64_t slot = wave_id * 64 + lane;
@@ -866,6 +873,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
             ln.fl[slot] = kLnFinal;
         }
         if (fin) { counts[u] = i; status[u] = st; }
+        if (TOPO && PHASE == 0) { end_cnt = i; end_u = u; }
         if (TOPO) { if (fin) t.cnt_slot[slot] = i; if (FUSE && PHASE != 2) t.w_slot[slot] = w; }  // (k_materialise reads its units' counts and weights in slot order; w: δs of the track's angle, loaded at the start — two dependent loads here were the tail of every wave, the last one's included)
         {
             // What the wave leaves for the call: its records into the sum of its tile of uids (two-phase calls: the scan then needs no
@@ -914,6 +922,51 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
     }  // for (;;): k_serve's claims
     if (FUSE) {
         __syncthreads();
+        if (TOPO && PHASE == 0) {
+            const RT_K DStage *sk = march_stage_args();
+            if (sk->cq) {
+                // ---- records in completion order: the workgroup's tracks, in march-slot order, take one span of the result arrays from
+                //      the cursor (north_star: "appended via a warp-aggregated atomic cursor" — here aggregated over the workgroup: one
+                //      returning atomic per 64 * WAVES tracks, at the workgroup's end, not 2,039 at the same moment); every track's offset
+                //      goes to off_slot (k_materialise_lin reads its units by slot) and to tab_off (the per-track table, uid order).
+                lds_i32 *own = (lds_i32 *)(march_smem + (size_t)m.n_cells * sizeof(double)) + wib * kMaxChunks;  // (every wave is behind its march: the chunk cache is free)
+                int32_t incl = end_cnt;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int32_t v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                if (lane == 63) own[0] = incl;
+                __syncthreads();
+                lds_i32 *w0 = (lds_i32 *)(march_smem + (size_t)m.n_cells * sizeof(double));
+                if (threadIdx.x == 0) {
+                    unsigned long long tot = 0;
+                    for (int w2 = 0; w2 < WAVES; ++w2) tot += (unsigned long long)(uint32_t)w0[w2 * kMaxChunks];
+                    const unsigned long long b0 = atomicAdd(march_ctl() + kCtlCq, tot);
+                    w0[1] = (int32_t)(uint32_t)b0; w0[2] = (int32_t)(uint32_t)(b0 >> 32);
+                }
+                __syncthreads();
+                int64_t off = (int64_t)(((unsigned long long)(uint32_t)w0[2] << 32) | (unsigned long long)(uint32_t)w0[1]);
+                for (int w2 = 0; w2 < WAVES; ++w2)
+                    if (w2 < wib) off += (int64_t)(uint32_t)w0[w2 * kMaxChunks];
+                off += (int64_t)(incl - end_cnt);
+                if (end_u >= 0) {
+                    sk->tab_off[end_u] = off;
+                    t.off_slot[((int64_t)blockIdx.x * WAVES + wib) * 64 + lane] = off;
+                }
+                // publish: every wave's stores (words, side list, counts, status, offsets) drained, then ONE agent-scope release —
+                // the write-back of this XCD's L2 — and the queue entry by an agent-scope store (cdna guide, guideline 16: plain
+                // payload, release, flag; the inline wait keeps the flag behind the write-back whatever the compiler knows of vmcnt)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long k = atomicAdd(march_ctl() + kCtlCq + 1, 1ull);
+                    if (k < (unsigned long long)sk->cq_blocks)
+                        __hip_atomic_store(sk->cq + k, ((unsigned long long)sk->cq_epoch << 32) | (unsigned long long)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         for (int c = threadIdx.x; c < m.n_cells; c += 64 * WAVES) {
             const double v = hist[c];
             if (v != 0.0) unsafeAtomicAdd((double *)&out.volumes[c], v);

@@ -138,6 +138,15 @@ constexpr int kWaitVm0 = 0x0F70;  // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt a
 #define RT_LIN_OCC 4
 #endif
 
+// QUEUE (round 6, records in COMPLETION order): the kernel runs BESIDE the march, on a second stream.  Workgroup b does not know
+// its unit when it starts: it takes unit b mod (4 W) of the (b / (4 W))-th march workgroup to FINISH (DStage::cq; W waves per march
+// workgroup), which has by then taken its span of the result arrays from the cursor and written its tracks' offsets — off_slot is
+// then not the CSR offset but the track's place in completion order, and everything below is unchanged: the 64 W tracks of a march
+// workgroup are one run of records, every unit the usual single run group.  One lane polls the queue entry (relaxed agent-scope
+// loads, s_sleep between them), then ONE agent-scope acquire, a wait, the workgroup's barrier — and plain loads (cdna guide,
+// guideline 16).  A workgroup that waits far beyond any march (~0.3 s), or that sees another one's give-up flag, sets the flag in
+// the control block and leaves: the attempt is void, the host marches again in CSR order.
+template <bool QUEUE>
 __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, int32_t *__restrict__ status, DStage stg, DOut out, DMat a) {
     __shared__ __attribute__((aligned(16))) int32_t s_meta[kLinCap];   // the round's words in output order (0: no record)
     __shared__ __attribute__((aligned(16))) uint8_t s_tmap[kLinCap];   // ... and which of the 16 tracks each belongs to
@@ -153,13 +162,46 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     __shared__ LinHalf s_half[4][kLinHalfCap];   // per wave: half pairs for the epilogue
     __shared__ double s_fval[4][kLinFlagCap];    // per wave: fill_volumes terms of marked records (value, cell) for the epilogue
     __shared__ int32_t s_fcell[4][kLinFlagCap];
-    if (stg.cursor[1] != 0 || stg.cursor[3] != 0) return;  // pool / side list overflow: this attempt is void
+    __shared__ int32_t s_qblock;
+    if (!QUEUE && (stg.cursor[1] != 0 || stg.cursor[3] != 0)) return;  // pool / side list overflow: this attempt is void
     // A workgroup's header phase (first trip to memory, run groups, transposition, up to the barrier behind it) issues with priority
     // over the other workgroups' store loops: its few instructions no longer queue behind four waves of FP64 work per SIMD, its
     // loads leave sooner and the unit reaches its own loop sooner — record kernel −4 % at C3, −6.5 % at C4, −5 % at C5, same box
     // (profiles/r05/exp_issue_priority.log; priority kept until the loop or until behind the first gathers: 1-2 % less; the march
     // does not respond to priorities).  A/B: option "compact_debug" 8 switches it off.
     const bool hprio = !(out.dbg & 8);
+    int64_t q_unit = 0;
+    if (QUEUE) {
+        const int per = 4 * a.q_waves;
+        const int64_t e = (int64_t)blockIdx.x / per;
+        const int r = (int)((int64_t)blockIdx.x - e * per);
+        if (threadIdx.x == 0) {
+            int32_t mb = -1;
+            unsigned long long *gave_up = a.ctl + kCtlCq + 2;
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned long long v = __hip_atomic_load(stg.cq + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 32) == stg.cq_epoch) { mb = (int32_t)(uint32_t)v; break; }
+                // an exit every workgroup reaches: the host launches this kernel when the march's last workgroups have started, and
+                // every march workgroup that ends appends itself — this fires only if the march never publishes (its argument guard)
+                if ((spins & 63u) == 63u && __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > 300000u) { __hip_atomic_store(gave_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_qblock = mb;
+        }
+        __syncthreads();
+        const int32_t mb = s_qblock;
+        if (mb < 0) return;
+        const int64_t wq = (int64_t)mb * a.q_waves + (r >> 2);
+        if (wq >= a.n_waves) return;  // (the batch's last march workgroup may hold fewer waves)
+        q_unit = 4 * wq + (r & 3);
+        // pool / side list overflow — flagged by a lane of the march workgroup itself before it published (vector loads behind the
+        // acquire: handed-off words stay off the scalar path)
+        if (__hip_atomic_load(&stg.cursor[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+            __hip_atomic_load(&stg.cursor[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    }
     if (hprio) __builtin_amdgcn_s_setprio(3);
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (kw in a scalar register: uniform loops)
     const int tl = lane & 15, rr = lane >> 4;  // transposition: track tl, rows 4 i + rr of a chunk
@@ -167,7 +209,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     LIN_STAMP(0);
 #endif
-    const int64_t unit = blockIdx.x;  // (a unit on the XCD whose march workgroup staged its words was tried: no difference — the words come from the
+    const int64_t unit = QUEUE ? q_unit : (int64_t)blockIdx.x;  // (a unit on the XCD whose march workgroup staged its words was tried: no difference — the words come from the
                                       //  memory-side cache either way, profiles/r05/exp_materialise_variants.log)
     if (unit >= a.n_units) return;
     // the result arrays as buffer resources (raw, no stride, bounds = the arrays' capacity; the host takes this kernel only for
@@ -183,7 +225,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     const bool nostore = (out.dbg & 1) != 0;
     // the exit edges' general forms: gathered through a buffer resource too (32-bit offsets: 3 n_cells < 2^27 entries of 32 B)
     const __amdgpu_buffer_rsrc_t r_etab = __builtin_amdgcn_make_buffer_rsrc((void *)a.etab, 0, a.etab_bytes, kBufWord3);
-    const int32_t w = __builtin_amdgcn_readfirstlane((int32_t)(a.corder ? a.corder[unit >> 2] : (int32_t)(unit >> 2)));
+    const int32_t w = __builtin_amdgcn_readfirstlane((int32_t)((!QUEUE && a.corder) ? a.corder[unit >> 2] : (int32_t)(unit >> 2)));
     const int q = (int)(unit & 3);
     const int64_t slot0 = (int64_t)w * 64 + 16 * q;
     const int64_t slot = slot0 + tl;
@@ -195,7 +237,8 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     auto chunk_id = [&](const int j) -> int32_t {
         const int js = __builtin_amdgcn_readfirstlane(j);
         if (js < stg.n_regions && w < stg.reg_cap[js]) return stg.reg_base[js] + w;
-        return __builtin_amdgcn_readfirstlane(ctab[js]);
+        // (QUEUE: the table entry was written by the march beside this kernel — an agent-scope vector load, never the scalar path)
+        return __builtin_amdgcn_readfirstlane(QUEUE ? __hip_atomic_load(&ctab[js], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ctab[js]);
     };
     // ---- the unit's first trip to memory, all of it at once: counts and offsets; the words of the wave's two chunks of the first
     // round, if the host reserved them (their ids follow from (w, j) and kernel arguments — whether or not the unit turns out to
@@ -636,7 +679,7 @@ namespace rtx {
 
 // The launch of k_materialise_lin for the plan of the last two-phase call (records only; rows for rt_sweep: k_materialise).
 void launch_materialise_lin(const rt::DTracks &d, int32_t *status, const rt::DStage &stg, const rt::DOut &out, const rt::DMat &a_in, hipStream_t s,
-                            int /*n_cus*/, int /*units_per_wg*/) {
+                            int /*n_cus*/, bool queue) {
     rt::DMat a = a_in;
     const unsigned blocks = (unsigned)a.n_units;
 #ifdef RT_LIN_TIMING
@@ -648,7 +691,13 @@ void launch_materialise_lin(const rt::DTracks &d, int32_t *status, const rt::DSt
     (void)hipMemsetAsync(dbg, 0, need * sizeof(unsigned long long), s);
     a.dbg = dbg;
 #endif
-    hipLaunchKernelGGL(rt::k_materialise_lin, dim3(blocks), dim3(256), 0, s, d, status, stg, out, a);
+    if (queue) {
+        // one workgroup per unit of every march workgroup (the last one's missing waves leave at once)
+        const unsigned qblocks = (unsigned)stg.cq_blocks * 4u * (unsigned)a.q_waves;
+        hipLaunchKernelGGL(rt::k_materialise_lin<true>, dim3(qblocks), dim3(256), 0, s, d, status, stg, out, a);
+    } else {
+        hipLaunchKernelGGL(rt::k_materialise_lin<false>, dim3(blocks), dim3(256), 0, s, d, status, stg, out, a);
+    }
 #ifdef RT_LIN_TIMING
     static int calls = 0;
     if (++calls % 16 == 0) {

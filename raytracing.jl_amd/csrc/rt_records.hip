@@ -395,7 +395,8 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(DTracks t, const int3
                                                            DStage stg, const double *__restrict__ ell_rows, double rtol, int32_t *__restrict__ marg,
                                                            double *__restrict__ volumes, double *__restrict__ vacc, int32_t n_cells, double n_azim_2,
                                                            unsigned long long *__restrict__ ctl, unsigned long long *__restrict__ host_copy,
-                                                           unsigned long long seq) {
+                                                           unsigned long long seq, const int64_t *__restrict__ off_by_slot) {
+    // (off_by_slot: the records lie in completion order — a track's first record is off_slot[march slot], not the CSR offset)
     const bool void_attempt = stg.cursor[1] != 0 || stg.cursor[3] != 0;
     // volumes ./= n_azim_2 (src/trackgenerator.jl:386): the march accumulated into `vacc` (k_materialise added the terms of the
     // records the march left to it), which is read, scaled into `volumes` and left ZERO for the next call's march
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(DTracks t, const int3
             if (slot < 0) continue;  // done by an earlier pass
             const int32_t u = t.perm[slot];
             const int32_t cnt = counts[u];
-            const int64_t off = offsets[u];
+            const int64_t off = off_by_slot ? off_by_slot[slot] : offsets[u];
             double S = 0.0;
             if (ell_rows) {
                 const RT_G int32_t *ctab = stg.ctab + (int64_t)(slot >> 6) * kMaxChunks;
@@ -655,6 +656,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_fused(const int32_t *__rest
     if (ctl_next && threadIdx.x < kCtlWords) ctl_next[threadIdx.x] = ctl_reset_word(threadIdx.x, first_chunk_next, side_first_next);
 }
 
+// Records in completion order -> CSR order on demand (ensure_compacted): the CSR offsets in march-slot order, for the record
+// kernel's second run.
+__global__ __launch_bounds__(256) void k_offsets_to_slots(const int64_t *__restrict__ offsets, const int32_t *__restrict__ iperm, int64_t n,
+                                                          int64_t *__restrict__ off_slot) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n) off_slot[iperm[u]] = offsets[u];
+}
+
 // fill_volumes (src/trackgenerator.jl:371-386) as its own pass over the compact records: each
 // workgroup owns a contiguous range of tracks (hence a contiguous range of segments, read
 // coalesced), accumulates δs[azim]·ℓ into an LDS-private copy of `volumes` with LDS atomics and
@@ -773,14 +782,20 @@ int reserve_records(rt_tracks *t, int64_t tot, rt::DOut &out) {
     return RT_SUCCESS;
 }
 
+// (k_materialise_lin addresses the result arrays through 32-bit buffer offsets: arrays below 4 GB, i.e. 2^29 records)
+bool lin_kernel_serves(const rt_tracks *t, const rt::DOut &out) {
+    return t->mesh->mat_kernel != 1 && out.cap < ((int64_t)1 << 29) - 64 && t->cplan.stg.side_cap > 0;
+}
+
 // Codes -> records and / or (ℓ, cell) rows (k_materialise) for the plan of the last two-phase call.  tally: the call's first
 // pass over the codes — Σℓ and status (k_finish completes them).
-int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl) {
+int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool records, bool rows, bool tally, unsigned long long *d_ctl, bool queue) {
     using rt::as_global;
     rt_mesh *m = t->mesh;
     const rt_tracks::CompactPlan &c = t->cplan;
     if (t->n <= 0 || c.n_whole_waves <= 0) return RT_SUCCESS;
     rt::DMat a{};
+    a.q_waves = c.march_waves; a.n_waves = (int32_t)std::min<int64_t>(c.n_whole_waves, 0x7fffffff);
     a.etab = m->d.etab; a.corder = as_global(c.corder);
     a.etab_bytes = (int32_t)(uint32_t)std::min<uint64_t>((uint64_t)3 * (uint64_t)m->n_cells * sizeof(rt::EdgeABC), 0xffffffffull);
     a.n_units = 4 * c.n_whole_waves; a.rtol = c.rtol; a.tally = tally ? 1 : 0;
@@ -797,12 +812,12 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
         a.ell_rows = as_global(t->sw_ell.p); a.cell_rows = as_global(t->sw_cell.p);
     }
     const unsigned blocks = (unsigned)a.n_units;
-    // (k_materialise_lin addresses the result arrays through 32-bit buffer offsets: arrays below 4 GB, i.e. 2^29 records)
-    if (records && !rows && m->mat_kernel != 1 && out.cap < ((int64_t)1 << 29) - 64 && c.stg.side_cap > 0) {
-        launch_materialise_lin(c.d_whole, t->status.p, c.stg, out, a, s, m->n_cus, 0);
+    if (records && !rows && lin_kernel_serves(t, out)) {
+        launch_materialise_lin(c.d_whole, t->status.p, c.stg, out, a, s, m->n_cus, queue);
         if (tally) t->last_record_kernel = 3;
         return RT_SUCCESS;
     }
+    if (queue) { set_error("records in completion order need k_materialise_lin"); return RT_ERR_INVALID; }
     if (tally) t->last_record_kernel = rows && !records ? 4 : 2;
     if (records && rows)
         hipLaunchKernelGGL((rt::k_materialise<true, true>), dim3(blocks), dim3(256), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
@@ -819,12 +834,13 @@ int launch_materialise(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool re
 
 // k_finish behind a tallying k_materialise: exact Σℓ of the listed tracks; copies the control block to the host.
 void launch_finish(rt_tracks *t, const rt::DOut &out, hipStream_t s, bool from_rows, bool scale_volumes, double n_azim_2,
-                   unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq) {
+                   unsigned long long *d_ctl, unsigned long long *h_res_dev, unsigned long long seq, bool completion_order) {
     const rt_tracks::CompactPlan &c = t->cplan;
     hipLaunchKernelGGL(rt::k_finish, dim3(1), dim3(rt::kFinishThreads), 0, s, c.d_whole, (const int32_t *)t->counts.p, t->status.p,
                        (const int64_t *)t->offsets.p, from_rows ? (const double *)nullptr : (const double *)t->sell.p, out.cap, c.stg,
                        from_rows ? (const double *)t->sw_ell.p : (const double *)nullptr, c.rtol, t->marg.p,
-                       scale_volumes ? t->volumes.p : (double *)nullptr, t->vacc.p, t->mesh->n_cells, n_azim_2, d_ctl, h_res_dev, seq);
+                       scale_volumes ? t->volumes.p : (double *)nullptr, t->vacc.p, t->mesh->n_cells, n_azim_2, d_ctl, h_res_dev, seq,
+                       completion_order ? (const int64_t *)t->off_slot.p : (const int64_t *)nullptr);
 }
 
 // Staged rows -> compact CSR records for the plan of the last single-pass call: k_compact3 over (q, ±cell) rows, or — codes —
@@ -848,6 +864,13 @@ int ensure_compacted(rt_tracks *t) {
     rt::DOut out{};
     if (int rc = reserve_records(t, t->total, out)) return rc;
     out.delta_s = rt::as_global(t->delta_s.p);
+    if (t->completion_order && t->n > 0) {
+        // The last call left its records in completion order (the per-track table: rt_device_table); whoever asks for the CSR
+        // layout gets it here, once: the CSR offsets in slot order, and the record kernel again over the staged words.
+        hipLaunchKernelGGL(rt::k_offsets_to_slots, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, t->mesh->stream, (const int64_t *)t->offsets.p,
+                           (const int32_t *)t->iperm.p, t->n, t->off_slot.p);
+        t->completion_order = false;
+    }
     launch_compaction(t, out, t->mesh->stream);
     RT_HIP(hipStreamSynchronize(t->mesh->stream));
     RT_HIP(hipGetLastError());
@@ -874,9 +897,10 @@ void launch_prologue(hipStream_t s, unsigned long long *ctl, double *volumes, in
 }
 
 void launch_scan_fused(hipStream_t s, rt_tracks *t, int64_t n_tiles, unsigned long long *d_ctl, const int32_t *tile_acc, int32_t *tile_acc_next,
-                       unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next) {
+                       unsigned long long *ctl_next, int32_t first_chunk_next, int32_t side_first_next, bool write_slots) {
     hipLaunchKernelGGL(rt::k_scan_fused, dim3((unsigned)n_tiles), dim3(rt::kScanBlock), 0, s, (const int32_t *)t->counts.p, t->n, tile_acc,
-                       tile_acc_next, n_tiles, reinterpret_cast<int64_t *>(d_ctl + 16), t->offsets.p, (const int32_t *)t->iperm.p, t->off_slot.p,
+                       tile_acc_next, n_tiles, reinterpret_cast<int64_t *>(d_ctl + 16), t->offsets.p,
+                       write_slots ? (const int32_t *)t->iperm.p : (const int32_t *)nullptr, t->off_slot.p,
                        d_ctl, ctl_next, first_chunk_next, side_first_next);
 }
 

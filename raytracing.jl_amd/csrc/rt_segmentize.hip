@@ -188,6 +188,7 @@ void free_tracks(rt_tracks *t) {
     t->dbg.release();
 #endif
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
+    if (t->cq_started) (void)hipHostFree(t->cq_started);
     if (t->pin_off) (void)hipHostFree(t->pin_off);
     if (t->pin_st) (void)hipHostFree(t->pin_st);
     pin_release_to_cache(t);
@@ -512,6 +513,7 @@ int32_t rt_set_option(rt_mesh *mesh, const char *name, int64_t value) {
     if (!strcmp(name, "mat_kernel")) { mesh->mat_kernel = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "march_waves")) { mesh->march_waves = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "topo")) { mesh->topo = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
+    if (!strcmp(name, "record_order")) { mesh->record_order = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "lean")) { mesh->lean = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RT_SUCCESS; }
     if (!strcmp(name, "serve_blocks")) { mesh->serve_blocks = (int)value; return RT_SUCCESS; }
     if (!strcmp(name, "cheap_per_cu")) { mesh->cheap_per_cu = (int)value; return RT_SUCCESS; }
@@ -782,6 +784,8 @@ struct SegmentizeCall {
     bool topo = false;        // cheap steps: the two-phase march
     bool lean = false;        // ... in three kernels: k_first, k_cheap, k_serve (DLean)
     int cheap_waves = 4;      // waves per workgroup of k_cheap
+    bool completion = false;  // the records in completion order, written beside the march (DStage::cq)
+    uint32_t cq_epoch = 0;
     rt::DLean dl{};
     int fuse_waves = 4;
     size_t hist_bytes = 0, fuse_smem = 0;
@@ -892,6 +896,7 @@ struct SegmentizeCall {
         out.fused_volumes = (m->volumes_mode == 1 && !m->single_pass) ? 1 : 0;
         out.dbg = m->compact_debug;
         t->compacted = false;
+        t->completion_order = false;
         t->sw_ell_valid = false;
         t->sw_rowsc_valid = false;
         t->cplan = rt_tracks::CompactPlan{};
@@ -934,6 +939,17 @@ struct SegmentizeCall {
             }
         }
         t->last_lean = lean ? m->lean : 0;
+        // Records in completion order: the record kernel beside the march, on the mesh's second stream.  Automatic ("record_order"
+        // 1) for batches whose march workgroups are all resident at once — where the march's second half leaves the chip half idle
+        // (profiles/r06/exp_fused_tail.log) —, "record_order" 2 for any two-phase call that writes records.  Not with events between
+        // the kernels (option "timing"), not with calls that return early ("async").
+        {
+            const int64_t march_blocks = (n_waves + fuse_waves - 1) / fuse_waves;
+            const int64_t resident = (int64_t)m->n_cus * (fuse_waves == 4 ? 2 : 1);  // (218 VGPRs: two waves per SIMD)
+            completion = topo && !lean && do_compact && m->record_order > 0 && !t->completion_gave_up && m->side_stream && !m->timing &&
+                         !m->async_calls && m->mat_kernel != 1 && n > 0 && march_blocks < (1 << 30) / (4 * fuse_waves) &&
+                         (m->record_order == 2 || march_blocks <= resident);
+        }
         if (split) {
             sp.vorder = as_global(t->vorder.p); sp.vw_wave = as_global(t->vw_wave.p); sp.vw_k = as_global(t->vw_k.p);
             sp.w_base = as_global(t->w_base.p); sp.w_P = as_global(t->w_P.p);
@@ -951,16 +967,17 @@ struct SegmentizeCall {
     // copy_out: k_scan_tile_sums' last block also writes the control block to the pinned host copy; scale: k_scan_write also
     // applies volumes ./= n_azim_2 (fused fill_volumes only: `volumes` is final once the march has ended); reset_other: the
     // scan's last block also resets the OTHER control block for the next call (single-pass calls)
-    int scan_counts(bool copy_out, bool scale, bool reset_other, bool slot_order = false) {
+    // write_slots = false (records in completion order): off_slot holds the tracks' places in completion order — the scan leaves it alone
+    int scan_counts(bool copy_out, bool scale, bool reset_other, bool slot_order = false, bool write_slots = true) {
         if (n > 0 && slot_order && tile_acc_cur) {  // (two-phase calls: the march has left the tile sums)
             ++t->call_seq;
             launch_scan_fused(s, t, n_tiles, d_ctl, tile_acc_cur, reset_other ? tile_acc_other : (int32_t *)nullptr,
-                              reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk, side_first);
+                              reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk, side_first, write_slots);
             if (reset_other) t->tile_acc_clean[1 - cb] = true;
         } else if (n > 0) {
             launch_scan(s, t, n_tiles, d_ctl, copy_out ? h_res_dev : (unsigned long long *)nullptr,
                         reset_other ? d_ctl_other : (unsigned long long *)nullptr, first_chunk, side_first, ++t->call_seq,
-                        scale ? t->volumes.p : (double *)nullptr, (double)n_azim_2, slot_order);
+                        scale ? t->volumes.p : (double *)nullptr, (double)n_azim_2, slot_order && write_slots);
         } else {
             RT_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
             RT_HIP(hipMemsetAsync(t->offsets.p, 0, sizeof(int64_t), s));
@@ -1140,13 +1157,33 @@ struct SegmentizeCall {
                 t->lean_q_clean = true;
             }
         }
+        stg.cq = nullptr; stg.tab_off = nullptr; stg.cq_started = nullptr; stg.cq_epoch = 0; stg.cq_blocks = 0;
+        if (completion) {
+            const int64_t march_blocks = (n_waves + fuse_waves - 1) / fuse_waves;
+            RT_HIP(t->tab_off.reserve((size_t)n + 1));
+            if (t->cq.cap < (size_t)march_blocks) {
+                RT_HIP(t->cq.reserve((size_t)march_blocks));
+                RT_HIP(hipMemsetAsync(t->cq.p, 0, t->cq.cap * sizeof(unsigned long long), s));  // (epoch 0 is never used)
+            }
+            if (!t->cq_started) {
+                RT_HIP(hipHostMalloc((void **)&t->cq_started, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+                for (int i = 0; i < 8; ++i) t->cq_started[i] = 0;
+            }
+            // the epoch of this attempt: entries and start flags of earlier calls / attempts never match it
+            cq_epoch = (uint32_t)(++t->cq_epoch_last);
+            if (cq_epoch == 0) cq_epoch = (uint32_t)(++t->cq_epoch_last);
+            unsigned long long *started_dev = nullptr;
+            RT_HIP(hipHostGetDevicePointer((void **)&started_dev, t->cq_started, 0));
+            stg.cq = as_global(t->cq.p); stg.tab_off = as_global(t->tab_off.p); stg.cq_started = started_dev;
+            stg.cq_epoch = cq_epoch; stg.cq_blocks = (int32_t)march_blocks;
+        }
         stg_pieces = stg;
         d_whole = t->d;
         {
             rt_tracks::CompactPlan &c = t->cplan;
             c.stg = stg; c.stg_pieces = stg_pieces; c.d_whole = d_whole; c.sp = sp; c.corder = corder;
             c.n_whole_waves = n_waves; c.split = split; c.split_all = split; c.staged = false;
-            c.codes = topo; c.rtol = rtol;
+            c.codes = topo; c.rtol = rtol; c.march_waves = fuse_waves;
         }
         // fused fill_volumes accumulates into `vacc` (zero between calls: k_scan_write leaves it so); otherwise the separate
         // pass adds into `volumes`, zeroed by the prologue.  The reset kernel runs only when the control block or the accumulator
@@ -1188,6 +1225,7 @@ struct SegmentizeCall {
             else rc = march(rt::kStage, 1, false, widek, false, (unsigned)n_waves, one_wave_smem, d_whole, stg);
             if (rc) return rc;
         }
+        if (completion) return enqueue_completion();
         if (int rc = rec(2)) return rc;
         if (int rc = scan_counts(!topo, fuse && !topo, true, topo)) return rc;  // (two-phase: k_finish scales the volumes, behind k_materialise)
         if (int rc = rec(3)) return rc;  // every event record costs ≈4 µs of stream time: none is recorded twice
@@ -1203,6 +1241,37 @@ struct SegmentizeCall {
         if (int rc = launch_volumes()) return rc;
         volumes_pass = !(fuse && n > 0);
         if (volumes_pass) { if (int rc = rec(6)) return rc; }
+        return RT_SUCCESS;
+    }
+
+    // Records in completion order: behind the march (already on the call's stream) the record kernel goes to the mesh's SECOND
+    // stream — launched only when the march's last workgroups are seen to have started (DStage::cq_started: they then all have
+    // their slots, or the batch's last residency round has begun; a record workgroup that waits for its march workgroup can no
+    // longer keep one off the chip) —, the offsets' scan (CSR offsets for whoever asks for that layout later, the statistics, the
+    // other control block's reset) behind the march on the call's stream, and k_finish behind both.
+    int enqueue_completion() {
+        hipStream_t s2 = m->side_stream;
+        {
+            const int nflags = (int)std::min<int64_t>(8, stg.cq_blocks);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 0;; ++spin) {
+                bool all = true;
+                for (int i = 0; i < nflags; ++i) all = all && __atomic_load_n(&t->cq_started[i], __ATOMIC_ACQUIRE) == (unsigned long long)cq_epoch;
+                if (all) break;
+                if ((spin & 1023u) == 1023u) {
+                    if (hipStreamQuery(s) != hipErrorNotReady) break;  // (the march is over — or failed: the record kernel simply runs behind it)
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+                }
+            }
+        }
+        if (int rc = launch_materialise(t, out, s2, true, false, true, d_ctl, true)) return rc;
+        if (int rc = scan_counts(false, false, true, true, false)) return rc;
+        RT_HIP(hipEventRecord(m->side_ev[0], s));
+        RT_HIP(hipStreamWaitEvent(s2, m->side_ev[0], 0));
+        launch_finish(t, out, s2, false, fuse, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq, true);
+        RT_HIP(hipEventRecord(m->side_ev[1], s2));
+        RT_HIP(hipStreamWaitEvent(s, m->side_ev[1], 0));
+        volumes_pass = false;
         return RT_SUCCESS;
     }
 
@@ -1240,6 +1309,15 @@ struct SegmentizeCall {
             choose_plan();
             return kRetry;
         }
+        if (completion && h_res[rt::kCtlCq + 2] != 0) {
+            // the record kernel beside the march waited in vain (the march never published): not a result — this handle keeps CSR order
+            t->completion_gave_up = true; t->marg_clean = false;
+            if (attempt >= 3) { set_error("rt_segmentize: the completion queue was not served"); return RT_ERR_HIP; }
+            RT_HIP(hipStreamSynchronize(m->side_stream));
+            RT_HIP(hipStreamSynchronize(s));
+            choose_plan();
+            return kRetry;
+        }
         const bool pools_ok = !cur[1] && !cur[3];
         if (do_compact && pools_ok && total > out.cap) {
             // the estimate was short: grow the outputs and compact again (staging pool and offsets are still valid)
@@ -1247,7 +1325,7 @@ struct SegmentizeCall {
             launch_compaction(t, out, s);
             if (topo && h_res[rt::kCtlDeferred] != 0) {
                 // tracks whose exact Σℓ k_finish could not form from the truncated records: once more, from the complete ones
-                launch_finish(t, out, s, false, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq);
+                launch_finish(t, out, s, false, false, (double)n_azim_2, d_ctl, h_res_dev, t->call_seq, completion);
                 RT_HIP(hipStreamSynchronize(s));
                 memcpy(fi, h_res, sizeof(fi));
             }
@@ -1280,7 +1358,7 @@ struct SegmentizeCall {
         }
         if (pools_ok) {
             t->cplan.staged = true;
-            if (do_compact) t->compacted = true;
+            if (do_compact) { t->compacted = !completion; t->completion_order = completion; }
             if (topo && !do_compact) t->sw_ell_valid = true;  // (k_materialise left the (ℓ, cell) rows)
             if (n > 0) {  // this call's scan has reset the other control block and (fused) left the accumulator zero
                 t->ctl_clean[1 - cb] = true; t->ctl_first_chunk[1 - cb] = reset_key;
@@ -1378,6 +1456,7 @@ struct SegmentizeCall {
         t->n_near_rtol = (int64_t)h_res[rt::kCtlNearRtol];
         t->n_exact_tally = (int64_t)h_res[rt::kCtlExactTally];
         t->n_restarts = m->single_pass ? (int64_t)h_res[rt::kCtlRestarts] : 0;
+        t->last_completion = completion ? 1 : 0;
         t->n_lean_queued = lean ? (int64_t)reinterpret_cast<const int32_t *>(h_res + rt::kLeanCtl)[0] : 0;
         t->n_failed = (int64_t)fi[0];
         t->first_failed_uid = fi[0] ? (int64_t)fi[1] : 0;
@@ -1648,6 +1727,52 @@ int32_t rt_device_pointers(rt_tracks *t, void **p) {
     return RT_SUCCESS;
 }
 
+// ---- records in completion order: the per-track table (include/rt_segmentize.h)
+int32_t rt_record_order(rt_tracks *t) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    return t->completion_order ? 1 : 0;
+}
+
+// the handle's records as they lie: in completion order, or — a call that left staged rows only — made now, in CSR order
+static int records_as_stored(rt_tracks *t) {
+    if (!t->segmentized) { set_error("rt_segmentize has not run"); return RT_ERR_NOT_SEGMENTIZED; }
+    if (int rc = finish_call(t)) return rc;
+    RT_HIP(hipSetDevice(t->mesh->device));
+    if (!t->completion_order)
+        if (int rc = ensure_compacted(t)) return rc;
+    return RT_SUCCESS;
+}
+
+int32_t rt_device_table(rt_tracks *t, void **p) {
+    if (!t || !p) { set_error("null argument"); return RT_ERR_INVALID; }
+    if (int rc = records_as_stored(t)) return rc;
+    p[0] = t->completion_order ? t->tab_off.p : t->offsets.p; p[1] = t->counts.p; p[2] = t->status.p;
+    p[3] = t->spx.p; p[4] = t->spy.p; p[5] = t->sqx.p; p[6] = t->sqy.p; p[7] = t->sell.p; p[8] = t->element.p; p[9] = t->volumes.p;
+    return RT_SUCCESS;
+}
+
+int32_t rt_fetch_table(rt_tracks *t, int64_t *seg_begin, int32_t *seg_count, int32_t *status) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (int rc = records_as_stored(t)) return rc;
+    if (t->n == 0) return RT_SUCCESS;
+    const void *src[3] = {t->completion_order ? t->tab_off.p : t->offsets.p, t->counts.p, t->status.p};
+    void *dst[3] = {seg_begin, seg_count, status};
+    const size_t bytes[3] = {sizeof(int64_t) * (size_t)t->n, sizeof(int32_t) * (size_t)t->n, sizeof(int32_t) * (size_t)t->n};
+    return fetch_pipelined(t, 3, src, dst, bytes);
+}
+
+int32_t rt_fetch_records(rt_tracks *t, double *px, double *py, double *qx, double *qy, double *ell, int32_t *element) {
+    if (!t) { set_error("null handle"); return RT_ERR_INVALID; }
+    if (int rc = records_as_stored(t)) return rc;
+    if (t->total == 0) return RT_SUCCESS;
+    const void *src[6] = {t->spx.p, t->spy.p, t->sqx.p, t->sqy.p, t->sell.p, t->element.p};
+    void *dst[6] = {px, py, qx, qy, ell, element};
+    const size_t bytes[6] = {8 * (size_t)t->total, 8 * (size_t)t->total, 8 * (size_t)t->total, 8 * (size_t)t->total, 8 * (size_t)t->total,
+                             4 * (size_t)t->total};
+    return fetch_pipelined(t, 6, src, dst, bytes);
+}
+
 int32_t rt_mesh_info(rt_mesh *m, double *info, int32_t n_info, char *note, int32_t note_cap) {
     if (!m || (n_info > 0 && !info) || n_info < 0 || note_cap < 0) { set_error("rt_mesh_info: bad argument"); return RT_ERR_INVALID; }
     const double v[RT_MESH_INFO_COUNT] = {
@@ -1680,6 +1805,7 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 20) stats[20] = t->last_topo ? t->n_exact_tally : 0;
     if (n > 21) stats[21] = t->last_lean;      // the lean plan of the last call (0: the march in one kernel)
     if (n > 22) stats[22] = t->n_lean_queued;  // ... and the lanes k_serve finished
+    if (n > 24) stats[24] = t->last_completion;  // 1: the call wrote its records beside the march, in completion order (option "record_order")
     if (n > 23) stats[23] = t->last_record_kernel;  // 1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows only
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results
         auto b = [](const auto &d) { return (int64_t)(d.cap * sizeof(*d.p)); };
