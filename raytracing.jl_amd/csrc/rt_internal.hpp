@@ -135,7 +135,7 @@ struct DStage {
     // ended takes the span of its tracks' records from the cursor in the control block (word kCtlCq), writes its tracks' offsets
     // (off_slot by march slot, tab_off by uid), releases and appends its index to this queue; the record kernel runs BESIDE the
     // march on a second stream and its workgroups take the units of the k-th march workgroup to finish.
-    RT_G unsigned long long *cq;       // [cq_blocks] (epoch << 32) | march workgroup; entries of earlier calls carry older epochs
+    RT_G unsigned long long *cq;       // [8][cq_blocks], one queue per XCD: (epoch << 32) | march workgroup; entries of earlier calls carry older epochs
     RT_G int64_t *tab_off;             // [n] first record of every track, uid order
     unsigned long long *cq_started;    // pinned host memory, [8]: the grid's last eight workgroups store the epoch when they start
     uint32_t cq_epoch;
@@ -161,8 +161,10 @@ constexpr int kCtlRefusal = 32;   // 32..40: cheap-step refusals by certificate 
 constexpr int kCtlRestarts = 41;  // tracks marched again with exact steps after cheap steps (their fused volumes were counted twice)
 constexpr int kCtlExactTally = 43;  // cheap records whose fill_volumes term k_materialise adds from the record's own length
 constexpr int kCtlNearRtol = 42;  // tracks whose Σℓ check (src/track.jl:171) sits within summation-order noise of its threshold
-constexpr int kCtlCq = 48;        // 48: records handed out to march workgroups (the completion-order cursor), 49: workgroups in the
-                                  // completion queue, 50: the record kernel beside the march gave up waiting (the attempt is void)
+constexpr int kCtlCq = 48;        // 48: records handed out to march workgroups (the completion-order cursor), 49: march workgroups that
+                                  // have ended and queued themselves, 50: the record kernel beside the march gave up waiting (the attempt is
+                                  // void), 51: units the record kernel has served
+constexpr int kCtlCqXcd = 52;     // 52..59, one word per XCD as two int32: [0] march workgroups queued on the XCD, [1] units taken there
 constexpr int kCtlDeferred = 27;      // k_finish: tracks whose exact Σℓ it could not form (their records lie beyond the arrays' capacity)
 // generic tiny steps in a row a lane takes on its own before the wave helps (k_march; 2 and 4 measured +30 % at
 // C3 — a lane that escalates waits for the rest of its wave — 8..32 equal)

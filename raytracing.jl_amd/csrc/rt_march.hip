@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         // workgroups have started — workgroups are dealt to the XCDs in turn and every XCD starts its share in order, so the last
         // eight starting means that every workgroup has its slots (or, a batch of several residency rounds, that the last round has
         // begun): the record kernel's waiting workgroups can then never keep a march workgroup off the chip.
+        if (TOPO && PHASE == 0 && (out.dbg & 32)) __builtin_amdgcn_s_setprio(3);  // (development, "compact_debug" 32)
         if (TOPO && PHASE == 0 && FUSE && sk->cq && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x)
             __hip_atomic_store(sk->cq_started + (gridDim.x - 1 - blockIdx.x), (unsigned long long)sk->cq_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
@@ -953,17 +954,23 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                     sk->tab_off[end_u] = off;
                     t.off_slot[((int64_t)blockIdx.x * WAVES + wib) * 64 + lane] = off;
                 }
-                // publish: every wave's stores (words, side list, counts, status, offsets) drained, then ONE agent-scope release —
-                // the write-back of this XCD's L2 — and the queue entry by an agent-scope store (cdna guide, guideline 16: plain
-                // payload, release, flag; the inline wait keeps the flag behind the write-back whatever the compiler knows of vmcnt)
+                // queue the workgroup ON ITS XCD: every wave's stores (words, side list, counts, status, offsets) drained — they are in
+                // this XCD's L2, where the record workgroups of this XCD (and only they: k_materialise_lin<QUEUE>) read them —, then the
+                // entry by an agent-scope store.  No release fence: a write-back of the XCD's L2 per ending workgroup cost the chains
+                // that were still marching half their speed.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (threadIdx.x == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long k = atomicAdd(march_ctl() + kCtlCq + 1, 1ull);
-                    if (k < (unsigned long long)sk->cq_blocks)
-                        __hip_atomic_store(sk->cq + k, ((unsigned long long)sk->cq_epoch << 32) | (unsigned long long)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned x;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+                    const int xcc = (int)(x & 7u);
+                    unsigned long long *ctl = march_ctl();
+                    const int32_t k = atomicAdd(reinterpret_cast<int32_t *>(ctl + kCtlCqXcd + xcc), 1);  // this XCD's tail
+                    if (k < sk->cq_blocks)
+                        __hip_atomic_store(sk->cq + (int64_t)xcc * sk->cq_blocks + k, ((unsigned long long)sk->cq_epoch << 32) | (unsigned long long)blockIdx.x,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail and the entry first: once every workgroup is counted, every tail is final)
+                    atomicAdd(ctl + kCtlCq + 1, 1ull);
                 }
             }
         }

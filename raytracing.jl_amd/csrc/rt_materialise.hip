@@ -110,6 +110,14 @@ __device__ __forceinline__ bool edge_exit_point_shared(double tA, double tB, dou
     return lin_range_ok(det) && (nx == 0.0 || lin_range_ok(nx)) && (ny == 0.0 || lin_range_ok(ny));
 }
 
+// A load of bytes the march wrote in THIS launch window (QUEUE: the march runs beside this kernel): agent scope — it bypasses the
+// CU's L1, which nothing refreshes (the XCD's L2, where the march workgroup of this XCD left them, serves it).
+template <bool QUEUE, typename T>
+__device__ __forceinline__ T ld_handoff(const RT_G T *p) {
+    if (QUEUE) return __hip_atomic_load((T *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 typedef double __attribute__((ext_vector_type(2))) lin_d2;
 typedef int32_t __attribute__((ext_vector_type(2))) lin_i2;
 typedef int32_t __attribute__((ext_vector_type(4))) lin_i4;
@@ -138,14 +146,20 @@ constexpr int kWaitVm0 = 0x0F70;  // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt a
 #define RT_LIN_OCC 4
 #endif
 
-// QUEUE (round 6, records in COMPLETION order): the kernel runs BESIDE the march, on a second stream.  Workgroup b does not know
-// its unit when it starts: it takes unit b mod (4 W) of the (b / (4 W))-th march workgroup to FINISH (DStage::cq; W waves per march
-// workgroup), which has by then taken its span of the result arrays from the cursor and written its tracks' offsets — off_slot is
-// then not the CSR offset but the track's place in completion order, and everything below is unchanged: the 64 W tracks of a march
-// workgroup are one run of records, every unit the usual single run group.  One lane polls the queue entry (relaxed agent-scope
-// loads, s_sleep between them), then ONE agent-scope acquire, a wait, the workgroup's barrier — and plain loads (cdna guide,
-// guideline 16).  A workgroup that waits far beyond any march (~0.3 s), or that sees another one's give-up flag, sets the flag in
-// the control block and leaves: the attempt is void, the host marches again in CSR order.
+// QUEUE (round 6, records in COMPLETION order): the kernel runs BESIDE the march, on a second stream, as PERSISTENT workgroups (four
+// per CU).  A march workgroup that ends has taken its span of the result arrays from the cursor, written its tracks' offsets —
+// off_slot is then not the CSR offset but the track's place in completion order; the 64 W tracks of a march workgroup (W waves) are
+// one run of records, every unit the usual single run group, and everything below is unchanged — and queued itself ON ITS XCD
+// (DStage::cq: one queue per XCD).  A workgroup here serves the queue of the XCD it runs on (HW_REG_XCC_ID): ticket t of the XCD's
+// head = unit t mod (4 W) of the (t / (4 W))-th march workgroup that ended on this XCD.  Producer and consumer share that XCD's L2:
+// the march workgroup only drains its stores (s_waitcnt) before it queues itself — no write-back of the L2, whose cost, paid by
+// every ending workgroup, slowed the march's remaining chains by half (the first build of this round: one queue for the chip and
+// an agent-scope release per march workgroup, march 146 -> 221 µs at C3) — and the consumer invalidates its CU's L1 (ONE agent-scope
+// acquire by the polling lane, a wait, the workgroup's barrier; cdna guide, guideline 16) and reads with plain loads.  Nothing here
+// assumes a placement: both sides read their XCD from the hardware.  A workgroup leaves when every march workgroup has ended and
+// its XCD's queue holds no further unit; one that waits far beyond any march (~0.3 s), or sees another one's give-up flag, sets
+// the flag in the control block and leaves: the attempt is void, the host marches again in CSR order.  The host also counts: a
+// call whose units were not all served (no record workgroup on some XCD: never observed) writes its records again, in CSR order.
 template <bool QUEUE>
 __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, int32_t *__restrict__ status, DStage stg, DOut out, DMat a) {
     __shared__ __attribute__((aligned(16))) int32_t s_meta[kLinCap];   // the round's words in output order (0: no record)
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     __shared__ LinHalf s_half[4][kLinHalfCap];   // per wave: half pairs for the epilogue
     __shared__ double s_fval[4][kLinFlagCap];    // per wave: fill_volumes terms of marked records (value, cell) for the epilogue
     __shared__ int32_t s_fcell[4][kLinFlagCap];
-    __shared__ int32_t s_qblock;
+    __shared__ int32_t s_qblock, s_qr;
     if (!QUEUE && (stg.cursor[1] != 0 || stg.cursor[3] != 0)) return;  // pool / side list overflow: this attempt is void
     // A workgroup's header phase (first trip to memory, run groups, transposition, up to the barrier behind it) issues with priority
     // over the other workgroups' store loops: its few instructions no longer queue behind four waves of FP64 work per SIMD, its
@@ -170,37 +184,61 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     // (profiles/r05/exp_issue_priority.log; priority kept until the loop or until behind the first gathers: 1-2 % less; the march
     // does not respond to priorities).  A/B: option "compact_debug" 8 switches it off.
     const bool hprio = !(out.dbg & 8);
+    int xcc = 0;
+    if (QUEUE) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcc = (int)(x & 7u);
+    }
+    for (;;) {  // QUEUE: one pass per unit this workgroup takes from its XCD's queue; else a single pass
     int64_t q_unit = 0;
     if (QUEUE) {
-        const int per = 4 * a.q_waves;
-        const int64_t e = (int64_t)blockIdx.x / per;
-        const int r = (int)((int64_t)blockIdx.x - e * per);
+        __syncthreads();  // (the previous unit's epilogue has read its tables; every wave has read s_qblock / s_qr)
+        __builtin_amdgcn_s_setprio(0);
         if (threadIdx.x == 0) {
-            int32_t mb = -1;
+            // ---- the next unit of THIS XCD: ticket t = unit t mod (4 W) of the (t / (4 W))-th march workgroup that ended here
+            const int per = 4 * a.q_waves;
+            int32_t *ht = reinterpret_cast<int32_t *>(a.ctl + kCtlCqXcd + xcc);  // [0] tail (march workgroups queued), [1] head (units taken)
+            const int32_t tk = atomicAdd(ht + 1, 1);
+            const int32_t e = tk / per;
+            const RT_G unsigned long long *entry = stg.cq + (int64_t)xcc * stg.cq_blocks + e;
             unsigned long long *gave_up = a.ctl + kCtlCq + 2;
-            for (unsigned spins = 0;; ++spins) {
-                const unsigned long long v = __hip_atomic_load(stg.cq + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(v >> 32) == stg.cq_epoch) { mb = (int32_t)(uint32_t)v; break; }
-                // an exit every workgroup reaches: the host launches this kernel when the march's last workgroups have started, and
-                // every march workgroup that ends appends itself — this fires only if the march never publishes (its argument guard)
-                if ((spins & 63u) == 63u && __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > 300000u) { __hip_atomic_store(gave_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                __builtin_amdgcn_s_sleep(32);
+            int32_t mb = -1;
+            if (e < stg.cq_blocks) {
+                for (unsigned spins = 0;; ++spins) {
+                    const unsigned long long v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 32) == stg.cq_epoch) { mb = (int32_t)(uint32_t)v; break; }
+                    // every march workgroup has ended and fewer than e + 1 of them on this XCD: no such unit — the workgroup is done
+                    // (the count of ended workgroups is added to behind the XCD's tail: once it is complete, the tail is final)
+                    if (__hip_atomic_load(a.ctl + kCtlCq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)stg.cq_blocks) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (__hip_atomic_load(ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= e) break;
+                    }
+                    // an exit every workgroup reaches: the host launches this kernel when the march's last workgroups have started and
+                    // every march workgroup that ends queues itself — this fires only if the march never does (its argument guard)
+                    if ((spins & 63u) == 63u && __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > 300000u) { __hip_atomic_store(gave_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(32);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // the march workgroup ran on THIS XCD: its stores are in this XCD's L2 (it drained them before it queued itself).  What
+            // remains is this CU's L1 — which every load of handed-off bytes below bypasses (ld_handoff / non-temporal loads: an
+            // acquire here, an invalidate of the L1 per unit, cost ≈7 µs of a unit's ≈14 at four workgroups per CU)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_qblock = mb;
+            if (mb >= 0) atomicAdd(a.ctl + kCtlCq + 3, 1ull);  // (the host counts: every unit of every march workgroup has to be taken)
+            s_qblock = mb; s_qr = tk - e * per;
         }
         __syncthreads();
         const int32_t mb = s_qblock;
         if (mb < 0) return;
+        const int r = s_qr;
         const int64_t wq = (int64_t)mb * a.q_waves + (r >> 2);
-        if (wq >= a.n_waves) return;  // (the batch's last march workgroup may hold fewer waves)
+        if (wq >= a.n_waves) continue;  // (the batch's last march workgroup may hold fewer waves)
         q_unit = 4 * wq + (r & 3);
-        // pool / side list overflow — flagged by a lane of the march workgroup itself before it published (vector loads behind the
-        // acquire: handed-off words stay off the scalar path)
+        // pool / side list overflow — flagged by a lane of the march workgroup itself before it queued itself (vector loads behind
+        // the acquire: handed-off words stay off the scalar path)
         if (__hip_atomic_load(&stg.cursor[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-            __hip_atomic_load(&stg.cursor[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            __hip_atomic_load(&stg.cursor[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;
     }
     if (hprio) __builtin_amdgcn_s_setprio(3);
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (kw in a scalar register: uniform loops)
@@ -211,7 +249,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
 #endif
     const int64_t unit = QUEUE ? q_unit : (int64_t)blockIdx.x;  // (a unit on the XCD whose march workgroup staged its words was tried: no difference — the words come from the
                                       //  memory-side cache either way, profiles/r05/exp_materialise_variants.log)
-    if (unit >= a.n_units) return;
+    if (unit >= a.n_units) { if (QUEUE) continue; return; }
     // the result arrays as buffer resources (raw, no stride, bounds = the arrays' capacity; the host takes this kernel only for
     // arrays below 4 GB): see the stores
     const int nb8 = (int)(uint32_t)((uint64_t)out.cap << 3), nb4 = (int)(uint32_t)((uint64_t)out.cap << 2);
@@ -245,7 +283,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
     // need them); wave 0 the table: lane (field rr, track tl) reads field rr of (A, B, C, ℓ) and of (δs, first record's p.x, p.y, q.x)
     int32_t cnt = 0;
     int64_t off = 0;
-    if (have) { cnt = t.cnt_slot[slot]; off = t.off_slot[slot]; }
+    if (have) { cnt = ld_handoff<QUEUE>(&t.cnt_slot[slot]); off = ld_handoff<QUEUE>(&t.off_slot[slot]); }
     int32_t ve[2][8];
     bool spec[2];
 #pragma unroll
@@ -272,12 +310,12 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             s_trk[tl].g0[rr] = pg0[sc];
         } else if (kw == 1) {
             const RT_G double *pg1 = rr == 0 ? (const RT_G double *)t.w_slot : (rr == 1 ? (const RT_G double *)stg.s_px : (rr == 2 ? (const RT_G double *)stg.s_py : (const RT_G double *)stg.s_qx));
-            s_trk[tl].g1[rr] = pg1[rr == 0 ? sc : ss];
+            s_trk[tl].g1[rr] = ld_handoff<QUEUE>(&pg1[rr == 0 ? sc : ss]);
         } else if (kw == 2) {
             const RT_G double *pg2 = rr == 0 ? (const RT_G double *)stg.s_qy : (rr == 1 ? t.Dxs : t.Dys);
-            s_trk[tl].g2[rr] = pg2[rr == 0 ? ss : sc];
+            s_trk[tl].g2[rr] = ld_handoff<QUEUE>(&pg2[rr == 0 ? ss : sc]);
         } else if (lane < 16) {
-            s_trk[tl].el0 = stg.s_el[ss]; s_gap[tl] = 0.0;
+            s_trk[tl].el0 = ld_handoff<QUEUE>(&stg.s_el[ss]); s_gap[tl] = 0.0;
         }
     }
     int32_t gmax = cnt;
@@ -408,7 +446,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             if (__builtin_expect(wp < 0, 0)) {
                 const int64_t idx = (-(int64_t)wp - 1) & (kWordLast - 1);
                 if (idx == slot0 + tp) { carry_x = s_trk[tp].g1[3]; carry_y = s_trk[tp].g2[0]; }
-                else { carry_x = stg.s_qx[idx]; carry_y = stg.s_qy[idx]; __builtin_amdgcn_s_waitcnt(kWaitVm0); }
+                else { carry_x = ld_handoff<QUEUE>(&stg.s_qx[idx]); carry_y = ld_handoff<QUEUE>(&stg.s_qy[idx]); __builtin_amdgcn_s_waitcnt(kWaitVm0); }
             }
         }
         int n_half = 0, n_flag = 0;  // (wave-uniform: the lists' fill)
@@ -469,12 +507,14 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                     if (w0 < 0 && (int64_t)i0 != slot0 + t0) {
                         gap0 = true;
                         const int32_t idx = i0;
-                        q0x = stg.s_qx[idx]; q0y = stg.s_qy[idx]; o0x = stg.s_px[idx]; o0y = stg.s_py[idx]; cell0 = stg.s_el[idx];
+                        q0x = ld_handoff<QUEUE>(&stg.s_qx[idx]); q0y = ld_handoff<QUEUE>(&stg.s_qy[idx]); o0x = ld_handoff<QUEUE>(&stg.s_px[idx]);
+                        o0y = ld_handoff<QUEUE>(&stg.s_py[idx]); cell0 = ld_handoff<QUEUE>(&stg.s_el[idx]);
                     }
                     if (w1 < 0 && (int64_t)i1 != slot0 + t1) {
                         gap1 = true;
                         const int32_t idx = i1;
-                        q1x = stg.s_qx[idx]; q1y = stg.s_qy[idx]; o1x = stg.s_px[idx]; o1y = stg.s_py[idx]; cell1 = stg.s_el[idx];
+                        q1x = ld_handoff<QUEUE>(&stg.s_qx[idx]); q1y = ld_handoff<QUEUE>(&stg.s_qy[idx]); o1x = ld_handoff<QUEUE>(&stg.s_px[idx]);
+                        o1y = ld_handoff<QUEUE>(&stg.s_py[idx]); cell1 = ld_handoff<QUEUE>(&stg.s_el[idx]);
                     }
                     __builtin_amdgcn_s_waitcnt(kWaitVm0);  // (waited for here, not at the join with the hot path: that wait would cover the gathers in flight)
                 }
@@ -663,7 +703,7 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
                 if (e < a.marg_cap) a.marg[1 + e] = (int32_t)slot;  // (marg_cap = every march slot: cannot overflow)
             } else if (cs == 1) {  // src/track.jl:171-175
                 const int32_t u = t.perm[slot];
-                if (status[u] == RT_TRACK_OK) {
+                if (ld_handoff<QUEUE>((const RT_G int32_t *)&status[u]) == RT_TRACK_OK) {
                     status[u] = RT_TRACK_LENGTH_MISMATCH;
                     atomicAdd(&a.ctl[0], 1ull);
                     atomicMin(&a.ctl[1], (unsigned long long)(u + 1));
@@ -671,6 +711,8 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             }
         }
     }
+    if (!QUEUE) break;
+    }  // for (;;): the units of a QUEUE workgroup
 }
 
 }  // namespace rt
@@ -679,7 +721,7 @@ namespace rtx {
 
 // The launch of k_materialise_lin for the plan of the last two-phase call (records only; rows for rt_sweep: k_materialise).
 void launch_materialise_lin(const rt::DTracks &d, int32_t *status, const rt::DStage &stg, const rt::DOut &out, const rt::DMat &a_in, hipStream_t s,
-                            int /*n_cus*/, bool queue) {
+                            int n_cus, bool queue) {
     rt::DMat a = a_in;
     const unsigned blocks = (unsigned)a.n_units;
 #ifdef RT_LIN_TIMING
@@ -692,8 +734,8 @@ void launch_materialise_lin(const rt::DTracks &d, int32_t *status, const rt::DSt
     a.dbg = dbg;
 #endif
     if (queue) {
-        // one workgroup per unit of every march workgroup (the last one's missing waves leave at once)
-        const unsigned qblocks = (unsigned)stg.cq_blocks * 4u * (unsigned)a.q_waves;
+        // persistent workgroups: as many as fit on the chip at once (four per CU), never more than there are units
+        const unsigned qblocks = (unsigned)std::min<int64_t>((int64_t)std::max(1, n_cus) * RT_LIN_OCC, a.n_units);
         hipLaunchKernelGGL(rt::k_materialise_lin<true>, dim3(qblocks), dim3(256), 0, s, d, status, stg, out, a);
     } else {
         hipLaunchKernelGGL(rt::k_materialise_lin<false>, dim3(blocks), dim3(256), 0, s, d, status, stg, out, a);

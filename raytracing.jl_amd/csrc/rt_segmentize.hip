@@ -1161,8 +1161,8 @@ struct SegmentizeCall {
         if (completion) {
             const int64_t march_blocks = (n_waves + fuse_waves - 1) / fuse_waves;
             RT_HIP(t->tab_off.reserve((size_t)n + 1));
-            if (t->cq.cap < (size_t)march_blocks) {
-                RT_HIP(t->cq.reserve((size_t)march_blocks));
+            if (t->cq.cap < 8 * (size_t)march_blocks) {
+                RT_HIP(t->cq.reserve(8 * (size_t)march_blocks));
                 RT_HIP(hipMemsetAsync(t->cq.p, 0, t->cq.cap * sizeof(unsigned long long), s));  // (epoch 0 is never used)
             }
             if (!t->cq_started) {
@@ -1309,8 +1309,10 @@ struct SegmentizeCall {
             choose_plan();
             return kRetry;
         }
-        if (completion && h_res[rt::kCtlCq + 2] != 0) {
-            // the record kernel beside the march waited in vain (the march never published): not a result — this handle keeps CSR order
+        if (completion && n > 0 && !cur[1] && !cur[3] &&
+            (h_res[rt::kCtlCq + 2] != 0 || h_res[rt::kCtlCq + 3] != (unsigned long long)stg.cq_blocks * 4ull * (unsigned long long)fuse_waves)) {
+            // the record kernel beside the march waited in vain (the march never queued itself), or units were left untaken (an XCD
+            // without a record workgroup): not a result — this handle keeps CSR order
             t->completion_gave_up = true; t->marg_clean = false;
             if (attempt >= 3) { set_error("rt_segmentize: the completion queue was not served"); return RT_ERR_HIP; }
             RT_HIP(hipStreamSynchronize(m->side_stream));
