@@ -203,7 +203,6 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
         // workgroups have started — workgroups are dealt to the XCDs in turn and every XCD starts its share in order, so the last
         // eight starting means that every workgroup has its slots (or, a batch of several residency rounds, that the last round has
         // begun): the record kernel's waiting workgroups can then never keep a march workgroup off the chip.
-        if (TOPO && PHASE == 0 && (out.dbg & 32)) __builtin_amdgcn_s_setprio(3);  // (development, "compact_debug" 32)
         if (TOPO && PHASE == 0 && FUSE && sk->cq && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x)
             __hip_atomic_store(sk->cq_started + (gridDim.x - 1 - blockIdx.x), (unsigned long long)sk->cq_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
