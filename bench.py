@@ -204,6 +204,35 @@ def two_in_flight(tg, aq, dmesh, dt, steps, segments_per_step):
         return {"error": repr(e)}
 
 
+def completion_order_calls(rt, tg, aq, dmesh, steps, segments_per_step):
+    """Extra, not `value`: the same K steps on a handle of its own with the option "record_order" 2 — a march workgroup that ends
+    takes its tracks' span of the result arrays from an atomic cursor and the record kernel runs BESIDE the rest of the march
+    (every track's records contiguous, the tracks in completion order, a per-track table: rt_device_table).  Built and measured in
+    round 6: no gain inside one call (profiles/r06/exp_completion_order.log) — the line carries the number so that the driver's
+    box says so too."""
+    try:
+        from raytracing_jl_amd import _capi
+        dm2 = _capi.DeviceMesh(tg.mesh, dmesh.device)
+        dm2.set_option("record_order", 2)
+        dt2 = _capi.DeviceTracks(dm2, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
+        seg = lambda: dt2.segmentize(tg.tiny_step, 5, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        for _ in range(3):
+            seg()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            seg()
+        el = time.perf_counter() - t0
+        st = dt2.stats()
+        out = {"steps": steps, "ms_per_step": el / steps * 1e3, "value": segments_per_step * steps / el, "unit": "segments/s",
+               "records_in_completion_order": bool(st.get("completion_order")), "record_order_after_call": dt2.record_order(),
+               "note": "rt_set_option record_order=2: records written beside the march, tracks in completion order + per-track table; not the headline value"}
+        dt2.close()
+        dm2.close()
+        return out
+    except Exception as e:  # pragma: no cover
+        return {"error": repr(e)}
+
+
 def stream_ordered_calls(rt, tg, aq, dmesh, dt, steps, segments_per_step):
     """Extra, not `value`: the same K steps with the option "async" — rt_segmentize returns once the host knows total, status
     summary and offsets (after the scan) while the compaction still runs, and the next call queues behind it: the ≈25 µs of host
@@ -927,6 +956,7 @@ def _main(real_stdout):
         if world == 1 and not dist_on and not args.no_concurrent:
             out["two_batches_in_flight"] = two_in_flight(tg, aq, dmesh, dt, args.steps, local_total)
             out["stream_ordered_calls"] = stream_ordered_calls(rt, tg, aq, dmesh, dt, args.steps, local_total)
+            out["completion_order_calls"] = completion_order_calls(rt, tg, aq, dmesh, args.steps, local_total)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tg)
         with line_lock:

@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
     LOAD(rt_mesh_create) LOAD(rt_mesh_destroy) LOAD(rt_mesh_info) LOAD(rt_tracks_create) LOAD(rt_tracks_destroy)
     LOAD(rt_segmentize) LOAD(rt_failed_tracks) LOAD(rt_fetch_offsets) LOAD(rt_fetch_segments_pinned) LOAD(rt_fetch_pinned) LOAD(rt_fetch_volumes)
     LOAD(rt_result_alloc) LOAD(rt_result_fetch) LOAD(rt_result_free)
+    LOAD(rt_set_option) LOAD(rt_record_order) LOAD(rt_fetch_table) LOAD(rt_fetch_records)
     LOAD(rt_multi_create) LOAD(rt_multi_destroy) LOAD(rt_multi_segmentize) LOAD(rt_multi_failed_tracks) LOAD(rt_multi_fetch_offsets)
     LOAD(rt_multi_fetch_segments) LOAD(rt_multi_fetch_volumes) LOAD(rt_multi_shards)
     LOAD(rt_sweep_set_links) LOAD(rt_sweep) LOAD(rt_sweep_fetch) LOAD(rt_sweep_info)
@@ -97,7 +98,7 @@ int main(int argc, char **argv) {
     double *volumes = malloc(sizeof(double) * n_cells);
     void *hp[6];
     double sweep_phi = 0.0, sweep_psi = 0.0;
-    int32_t sweep_input = 0;
+    int32_t sweep_input = 0, table_order = -1, table_ok = -1;
     rt_mesh *hm = NULL;
     rt_tracks *ht = NULL;
     rt_multi *mm = NULL;
@@ -154,6 +155,33 @@ int main(int argc, char **argv) {
         p_rt_result_free(hr);
     }
     if (p_rt_fetch_volumes(ht, volumes)) { fprintf(stderr, "rt_fetch_volumes: %s\n", p_rt_last_error()); return 1; }
+    {   /* ---- the same call with the records in COMPLETION order (option "record_order"; whole tracks: "split" 0): a second mesh
+         *      handle, and every track's records through the per-track table against the CSR arrays above, byte for byte */
+        rt_mesh *hm2 = p_rt_mesh_create(0, x, y, n_nodes, cell_nodes, n_cells, nc_ptrs, nc_data, bb);
+        if (!hm2) { fprintf(stderr, "rt_mesh_create (2): %s\n", p_rt_last_error()); return 1; }
+        p_rt_set_option(hm2, "record_order", 2);
+        p_rt_set_option(hm2, "split", 0);
+        rt_tracks *ht2 = p_rt_tracks_create(hm2, n, px, py, phi, cs, sn, A, B, C, ell, azim);
+        if (!ht2) { fprintf(stderr, "rt_tracks_create (2): %s\n", p_rt_last_error()); return 1; }
+        const int64_t total2 = p_rt_segmentize(ht2, 1e-8, 5, rtol, delta_s, n2);
+        table_order = p_rt_record_order(ht2);
+        int64_t *beg = malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+        int32_t *cnt = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)), *st2 = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        void *rp[6];
+        for (int a = 0; a < 6; ++a) rp[a] = malloc((size_t)(total2 > 0 ? total2 : 1) * (a < 5 ? sizeof(double) : sizeof(int32_t)));
+        if (p_rt_fetch_table(ht2, beg, cnt, st2)) { fprintf(stderr, "rt_fetch_table: %s\n", p_rt_last_error()); return 1; }
+        if (p_rt_fetch_records(ht2, rp[0], rp[1], rp[2], rp[3], rp[4], rp[5])) { fprintf(stderr, "rt_fetch_records: %s\n", p_rt_last_error()); return 1; }
+        table_ok = total2 == total && !memcmp(st2, status, sizeof(int32_t) * (size_t)n);
+        for (int64_t u = 0; u < n && table_ok; ++u) {
+            table_ok = cnt[u] == offs[u + 1] - offs[u] && beg[u] >= 0 && beg[u] + cnt[u] <= total;
+            for (int a = 0; a < 6 && table_ok; ++a) {
+                const size_t w = a < 5 ? sizeof(double) : sizeof(int32_t);
+                table_ok = !memcmp((const char *)rp[a] + (size_t)beg[u] * w, (const char *)hp[a] + (size_t)offs[u] * w, (size_t)cnt[u] * w);
+            }
+        }
+        p_rt_tracks_destroy(ht2);
+        p_rt_mesh_destroy(hm2);
+    }
     /* ---- a consumer that stays on the device: one transport sweep over the cyclic tracks with the linking rt_trace produced
      *      (next_track_fwd / next_track_bwd, dir_next_track_*, bc_*: src/trackgenerator.jl:231-348), two groups */
     {
@@ -190,11 +218,11 @@ int main(int argc, char **argv) {
            ", \"first_uid\": %" PRId64 ", \"first_status\": %d, \"message\": \"%s\", \"walk_enabled\": %d, "
            "\"sum_offsets\": %" PRIu64 ", \"sum_status\": %" PRIu64 ", \"px\": %" PRIu64 ", \"py\": %" PRIu64 ", \"qx\": %" PRIu64
            ", \"qy\": %" PRIu64 ", \"ell\": %" PRIu64 ", \"element\": %" PRIu64 ", \"volumes_sum\": %.17g, \"tracks_px\": %" PRIu64
-           ", \"sweep_phi_sum\": %.17g, \"sweep_psi_out_sum\": %.17g, \"sweep_input\": %d}\n",
+           ", \"sweep_phi_sum\": %.17g, \"sweep_psi_out_sum\": %.17g, \"sweep_input\": %d, \"table_order\": %d, \"table_ok\": %d}\n",
            n, total, walked, n_failed, first_uid, first_status, message, (int)walk_enabled,
            sum_bits64(offs, n + 1), sum_bits32(status, n), sum_bits64(hp[0], total), sum_bits64(hp[1], total), sum_bits64(hp[2], total),
            sum_bits64(hp[3], total), sum_bits64(hp[4], total), sum_bits32((const int32_t *)hp[5], total), vsum, sum_bits64(px, n),
-           sweep_phi, sweep_psi, (int)sweep_input);
+           sweep_phi, sweep_psi, (int)sweep_input, (int)table_order, (int)table_ok);
     if (mm) p_rt_multi_destroy(mm);
     if (ht) p_rt_tracks_destroy(ht);
     if (hm) p_rt_mesh_destroy(hm);

@@ -63,6 +63,8 @@ def test_c_caller_matches_checker(rt, orc, n_azim, delta, shards):
         assert got[k] == _bits64(ref[k]), k
     assert got["element"] == _bits32(ref["element"])
     assert abs(got["volumes_sum"] - vol.sum()) < 1e-10
+    if not shards:  # the records in completion order through the per-track table (a second handle, option "record_order" 2)
+        assert got["table_ok"] == 1 and got["table_order"] == 1, got
     if not shards:  # the sweep the C caller ran on the device against a sequential sweep over the checker's records
         import sweep_ref
 

@@ -2,8 +2,9 @@
 of every run printed (rt_mesh_info / rt_last_stats).  Same cases as tools/fuzz_cpu.py (every mesh class of
 tests/meshgen.py incl. the threshold-aimed ones, nφ up to 1024, k in {1, 2, 3, 5, 8, 12}); walk step on with exact steps only, off,
 on with cheap steps as the library gates them, on with cheap steps FORCED (option "topo" = 2: no 90 % gate, no hand-back of
-often-refused waves — every record that carries a cheap certificate is decided by it), and the library's defaults (pieces for
-small batches).  Prints the share of cheap steps and the refusals by certificate term per mesh class.
+often-refused waves — every record that carries a cheap certificate is decided by it), the library's defaults (pieces for
+small batches), and cheap steps forced with the records in COMPLETION order (option "record_order" 2: the per-track table against
+the checker, then the CSR layout on demand).  Prints the share of cheap steps and the refusals by certificate term per mesh class.
 usage (GPU box): [FUZZ_TINY=1] [FUZZ_SHUFFLE=1] python tools/fuzz_many.py [first_seed] [count]"""
 import os
 import sys
@@ -49,6 +50,7 @@ def tuned_rtols(L, E):
 
 bad = 0
 n_tuned = 0
+n_completion = 0
 t0 = time.time()
 seg_total = walk_total = cheap_total = 0
 per = {}
@@ -74,15 +76,29 @@ for seed in range(first, first + count):
     vol = om.fill_volumes(ref["offsets"], tg.azim_idx, aq.delta_s, aq.n_azim_2)
     regime = ""
     cheap_n = forced_n = 0
-    for opts in (dict(walk=1, split=0, topo=0), dict(walk=0, split=0), dict(walk=1, split=0, topo=1), dict(walk=1, split=0, topo=2), dict(walk=1)):
+    for opts in (dict(walk=1, split=0, topo=0), dict(walk=0, split=0), dict(walk=1, split=0, topo=1), dict(walk=1, split=0, topo=2), dict(walk=1),
+                 dict(walk=1, split=0, topo=2, record_order=2)):
         dm = _capi.DeviceMesh(tg.mesh, 0)
         for kk, v in opts.items():
             dm.set_option(kk, v)
         dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
         total = dt.segmentize(tg.tiny_step, k, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
+        ok_tab = True
+        if total == ref["total"] and dt.record_order() == 1:
+            # records in completion order: every track's records through the per-track table, bit for bit; the spans tile [0, total)
+            n_completion += 1
+            beg, cnt, st_t = dt.fetch_table()
+            rec = dt.fetch_records()
+            roff = np.asarray(ref["offsets"], np.int64)
+            ok_tab = np.array_equal(cnt, np.diff(roff)) and np.array_equal(st_t, ref["status"])
+            if ok_tab and total:
+                b, e = np.sort(beg[cnt > 0]), np.sort((beg + cnt)[cnt > 0])
+                idx = np.repeat(beg - roff[:-1], cnt) + np.arange(total)
+                ok_tab = bool(b[0] == 0 and e[-1] == total and np.array_equal(b[1:], e[:-1])) and np.array_equal(rec["element"][idx], ref["element"]) and \
+                    all(np.array_equal(rec[f][idx], ref[f]) for f in FIELDS)
         off, st = dt.fetch_offsets()
-        seg = dt.fetch_segments()
-        ok = total == ref["total"] and np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and \
+        seg = dt.fetch_segments()  # (a handle in completion order: the CSR layout on demand)
+        ok = ok_tab and total == ref["total"] and np.array_equal(st, ref["status"]) and np.array_equal(off, ref["offsets"]) and \
             np.array_equal(seg["element"], ref["element"]) and all(np.array_equal(seg[f], ref[f]) for f in FIELDS) and \
             np.allclose(dt.fetch_volumes(), vol, rtol=1e-10, atol=1e-300)
         if not ok:
@@ -127,8 +143,8 @@ for kind, a in sorted(per.items()):
     print("class %-11s: %4d meshes, %10d segments, %5.1f %% by cheap steps as gated, %5.1f %% forced; refusals when forced: %s" %
           (kind, a["meshes"], a["segs"], 100.0 * a["cheap"] / max(a["segs"], 1), 100.0 * a["forced"] / max(a["segs"], 1),
            ", ".join("%s %d" % kv for kv in a["refusals"].items() if kv[1])))
-print("status at tuned tolerances: %d calls" % n_tuned)
-print("done: %d meshes x 5 modes, %d mismatches, %d segments, %.1f %% of them by the walk step, %.1f %% by cheap steps as gated, %.1f %% forced" %
+print("status at tuned tolerances: %d calls; records in completion order (per-track table): %d calls" % (n_tuned, n_completion))
+print("done: %d meshes x 6 modes, %d mismatches, %d segments, %.1f %% of them by the walk step, %.1f %% by cheap steps as gated, %.1f %% forced" %
       (count, bad, seg_total, 100.0 * walk_total / max(seg_total, 1), 100.0 * cheap_total / max(seg_total, 1),
        100.0 * sum(a["forced"] for a in per.values()) / max(seg_total, 1)))
 sys.exit(1 if bad else 0)
