@@ -959,7 +959,9 @@ __global__ __launch_bounds__(64 * WAVES, (SPLIT && MODE == kStage && WAVES > 1) 
                 // that were still marching half their speed.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) {
+                // ("compact_debug" 64, tests: the workgroup does NOT queue itself — the record kernel beside the march must give up
+                //  by itself and the host fall back to CSR order)
+                if (threadIdx.x == 0 && !(out.dbg & 64)) {
                     unsigned x;
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
                     const int xcc = (int)(x & 7u);

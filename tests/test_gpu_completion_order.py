@@ -164,3 +164,18 @@ def test_completion_order_at_the_headline_configuration(rt, traced, oracle_run):
         assert _check_table(dt, ref, ref["volumes"], ("C3", call)) == 1
     _check_csr(dt, ref, "C3")
     dt.close(); dm.close()
+
+
+def test_completion_order_gives_up_and_falls_back(rt, traced, oracle_run):
+    """The exit every waiting record workgroup reaches: march workgroups that never queue themselves ("compact_debug" 64, a test switch)
+    leave the record kernel beside the march waiting — it gives up on its own bound (≈0.3 s), the attempt is void, and the call is
+    made again in CSR order: same results, and the handle stays with CSR order from then on."""
+    tg = traced(32, 5e-3)
+    ref = oracle_run(tg)
+    dm, dt = _handles(rt, tg, dict(split=0, record_order=2, compact_debug=64))
+    for call in range(2):
+        assert _seg(rt, tg, dt) == ref["total"]
+        assert dt.stats()["completion_order"] == 0 and dt.record_order() == 0
+        assert _check_table(dt, ref, ref["volumes"], ("gave up", call)) == 0
+        _check_csr(dt, ref, ("gave up", call))
+    dt.close(); dm.close()
