@@ -98,7 +98,7 @@ def kernel_names(stats):
                                                               "true" if cheap else "false"),
             # (the record kernel by what the call launched — rt_last_stats[23]: a two-phase call falls back to k_materialise for
             #  arrays of 2^29 records or with option "mat_kernel" 1)
-            "compact": (stats.get("record_kernel") or ("rt::k_materialise_lin" if cheap else "rt::k_compact3")) +
+            "compact": (stats.get("record_kernel") or ("rt::k_materialise_lin<false>" if cheap else "rt::k_compact3")) +
                        ("<%s>" % ("true" if sp else "false") if (stats.get("record_kernel") or ("" if cheap else "rt::k_compact3")) == "rt::k_compact3" else ""),
             "scan": "rt::k_scan_fused" if cheap else "rt::k_scan_write"}
 

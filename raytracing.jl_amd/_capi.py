@@ -567,7 +567,7 @@ class DeviceTracks:
                     cheap_records=int(v[8]), cheap_refusals={k: int(v[9 + i]) for i, k in enumerate(self.REFUSAL_TERMS)},
                     tracks_near_rtol=int(v[18]), tracks_restarted=int(v[19]), records_tallied_from_lengths=int(v[20]),
                     lean=int(v[21]), lean_queued=int(v[22]), completion_order=int(v[24]),
-                    record_kernel={0: None, 1: "rt::k_compact3", 2: "rt::k_materialise<true, false>", 3: "rt::k_materialise_lin",
+                    record_kernel={0: None, 1: "rt::k_compact3", 2: "rt::k_materialise<true, false>", 3: "rt::k_materialise_lin<true>" if int(v[24]) else "rt::k_materialise_lin<false>",
                                    4: "rt::k_materialise<false, true>"}.get(int(v[23])))
 
     # the nine terms of the cheap step's certificate (rt_device.hpp, topo_certified), in rt_last_stats' order

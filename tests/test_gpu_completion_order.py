@@ -73,7 +73,7 @@ def test_completion_order_on_the_pincell(rt, traced, oracle_run):
         for call in range(3):
             assert _seg(rt, tg, dt) == ref["total"]
             s = dt.stats()
-            assert s["completion_order"] == 1 and s["record_kernel"] == "rt::k_materialise_lin", (opts, s)
+            assert s["completion_order"] == 1 and s["record_kernel"] == "rt::k_materialise_lin<true>", (opts, s)
             assert _check_table(dt, ref, ref["volumes"], (opts, call)) == 1
             if call == 1:
                 _check_csr(dt, ref, (opts, call))
