@@ -328,7 +328,9 @@ int32_t rt_last_timing(rt_tracks *tracks, double *ms, int32_t n);
  * would not be within 4e-11 of it — DESIGN.md §2).
  * stats[21] the lean plan of the call's march (option "lean"; 0: one kernel), stats[22] the lanes its k_serve finished; stats[23] the
  * kernel that wrote the call's records (1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows);
- * stats[24] 1 if the call wrote its records beside the march, in completion order (option "record_order").
+ * stats[24] 1 if the call wrote its records beside the march, in completion order (option "record_order"); stats[25] side-list entries
+ * the call used beyond the one reserved per track, stats[26] side-list entries allocated, stats[27] attempts the call took (> 1: a staging
+ * pool, side list or result array that was too small on the first one, or a fall-back to another plan).
  * n = capacity of stats (>= 4). */
 int32_t rt_last_stats(rt_tracks *tracks, int64_t *stats, int32_t n);
 

@@ -560,13 +560,13 @@ class DeviceTracks:
 
     def stats(self) -> dict:
         """``rt_last_stats``: records of the last call and how many of them the literal step produced."""
-        v = (C.c_int64 * 25)()
-        _check(lib().rt_last_stats(self._h, v, 25))
+        v = (C.c_int64 * 28)()
+        _check(lib().rt_last_stats(self._h, v, 28))
         return dict(records=int(v[0]), generic_records=int(v[1]), walk_records=int(v[0]) - int(v[1]),
                     chunks_used=int(v[2]), chunks_allocated=int(v[3]), march_waves=int(v[4]), split=int(v[5]), wide_k=int(v[6]), device_bytes=int(v[7]),
                     cheap_records=int(v[8]), cheap_refusals={k: int(v[9 + i]) for i, k in enumerate(self.REFUSAL_TERMS)},
                     tracks_near_rtol=int(v[18]), tracks_restarted=int(v[19]), records_tallied_from_lengths=int(v[20]),
-                    lean=int(v[21]), lean_queued=int(v[22]), completion_order=int(v[24]),
+                    lean=int(v[21]), lean_queued=int(v[22]), completion_order=int(v[24]), side_entries_used=int(v[25]), side_entries_allocated=int(v[26]), attempts=int(v[27]),
                     record_kernel={0: None, 1: "rt::k_compact3", 2: "rt::k_materialise<true, false>", 3: "rt::k_materialise_lin<true>" if int(v[24]) else "rt::k_materialise_lin<false>",
                                    4: "rt::k_materialise<false, true>"}.get(int(v[23])))
 

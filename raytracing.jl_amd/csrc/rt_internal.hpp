@@ -476,6 +476,7 @@ struct rt_tracks {
     DevBuf<unsigned long long> cq;     // [march workgroups] the completion queue (DStage::cq)
     unsigned long long *cq_started = nullptr;  // pinned, [8]
     unsigned long long cq_epoch_last = 0;
+    int32_t last_attempts = 0;         // rt_last_stats: attempts of the last call
     int32_t last_completion = 0;       // rt_last_stats: the last call wrote its records beside the march
     bool in_flight = false;  // option "async": the last rt_segmentize returned while its compaction was still on the stream
     unsigned long long call_seq = 0;  // sequence number the scan writes behind its host copy of the control block

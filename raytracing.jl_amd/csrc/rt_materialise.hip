@@ -226,19 +226,22 @@ __global__ __launch_bounds__(256, RT_LIN_OCC) void k_materialise_lin(DTracks t, 
             // acquire here, an invalidate of the L1 per unit, cost ≈7 µs of a unit's ≈14 at four workgroups per CU)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (mb >= 0) atomicAdd(a.ctl + kCtlCq + 3, 1ull);  // (the host counts: every unit of every march workgroup has to be taken)
+            // pool / side list overflow — flagged by a lane of the march workgroup itself before it queued itself (its chunk ids or
+            // side-list references are then void).  ONE lane decides for the workgroup: the flags can change while this kernel runs
+            // (another march workgroup overflowing), and 256 loads of them could disagree — threads of one workgroup on either side of
+            // a `continue` meet different barriers.  (Round 6, fuzz seed 830802: a memory access fault from exactly that.)
+            if (mb >= 0 && (__hip_atomic_load(&stg.cursor[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                            __hip_atomic_load(&stg.cursor[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) mb = -2;
             s_qblock = mb; s_qr = tk - e * per;
         }
         __syncthreads();
         const int32_t mb = s_qblock;
-        if (mb < 0) return;
+        if (mb == -1) return;
+        if (mb < 0) continue;  // (a void unit: the attempt is void, the host re-runs it)
         const int r = s_qr;
         const int64_t wq = (int64_t)mb * a.q_waves + (r >> 2);
         if (wq >= a.n_waves) continue;  // (the batch's last march workgroup may hold fewer waves)
         q_unit = 4 * wq + (r & 3);
-        // pool / side list overflow — flagged by a lane of the march workgroup itself before it queued itself (vector loads behind
-        // the acquire: handed-off words stay off the scalar path)
-        if (__hip_atomic_load(&stg.cursor[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-            __hip_atomic_load(&stg.cursor[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;
     }
     if (hprio) __builtin_amdgcn_s_setprio(3);
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (kw in a scalar register: uniform loops)

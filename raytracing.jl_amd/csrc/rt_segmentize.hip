@@ -1505,6 +1505,7 @@ static int64_t segmentize_impl(rt_tracks *t, double tiny_step, int32_t k, double
             }
 #endif
             const int r = c.after_attempt(attempt);
+            t->last_attempts = attempt + 1;
             if (r < 0) return r;
             if (r == SegmentizeCall::kRestartWhole) return segmentize_impl(t, tiny_step, k, rtol, delta_s, n_azim_2);
             if (r == SegmentizeCall::kDone) break;
@@ -1807,6 +1808,9 @@ int32_t rt_last_stats(rt_tracks *t, int64_t *stats, int32_t n) {
     if (n > 20) stats[20] = t->last_topo ? t->n_exact_tally : 0;
     if (n > 21) stats[21] = t->last_lean;      // the lean plan of the last call (0: the march in one kernel)
     if (n > 22) stats[22] = t->n_lean_queued;  // ... and the lanes k_serve finished
+    if (n > 27) stats[27] = t->last_attempts;   // attempts of the last call (> 1: a staging pool / side list that was too small, a fall-back)
+    if (n > 26) stats[26] = t->side_cap;        // side-list entries allocated (one reserved per march slot + the dynamic part)
+    if (n > 25) stats[25] = t->side_needed_last;  // ... and used beyond the reserved ones
     if (n > 24) stats[24] = t->last_completion;  // 1: the call wrote its records beside the march, in completion order (option "record_order")
     if (n > 23) stats[23] = t->last_record_kernel;  // 1 k_compact3, 2 k_materialise, 3 k_materialise_lin, 4 k_materialise writing (ℓ, cell) rows only
     if (n > 7) {  // device memory held by this handle: inputs, staging pools, tables, results

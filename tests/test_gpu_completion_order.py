@@ -179,3 +179,21 @@ def test_completion_order_gives_up_and_falls_back(rt, traced, oracle_run):
         assert _check_table(dt, ref, ref["volumes"], ("gave up", call)) == 0
         _check_csr(dt, ref, ("gave up", call))
     dt.close(); dm.close()
+
+
+def test_completion_order_overflow_while_the_record_kernel_runs(rt, traced, oracle_run):
+    """A staging pool / side list that runs out in the MIDDLE of a large batch: the overflow flag appears while the record kernel
+    beside the march is serving units (fuzz seed 830802, round 6: 256 threads of a record workgroup read the flag for themselves,
+    disagreed, and met different barriers — a memory access fault).  One lane decides per unit now; the attempt is void, the call
+    runs again with larger pools and ends in completion order with the checker's records."""
+    tg = traced(128, 1e-3)
+    ref = oracle_run(tg)
+    for opts in (dict(record_order=2, topo=2, side_entries_hint=100), dict(record_order=2, pool_chunks_hint=3000),
+                 dict(record_order=2, topo=2, side_entries_hint=200, pool_chunks_hint=4000)):
+        for rep in range(2):
+            dm, dt = _handles(rt, tg, opts)
+            assert _seg(rt, tg, dt) == ref["total"]
+            s = dt.stats()
+            assert s["completion_order"] == 1 and s["attempts"] >= 2, (opts, s)
+            assert _check_table(dt, ref, ref["volumes"], (opts, rep)) == 1
+            dt.close(); dm.close()
