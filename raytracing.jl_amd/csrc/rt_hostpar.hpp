@@ -22,17 +22,31 @@
 #if defined(__linux__)
 #include <sys/mman.h>
 #endif
+#if defined(__x86_64__) && defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 namespace rthostpar {
 
 // A few host threads that stay: starting a thread costs ≈30 µs and rt_tracks_create makes four passes over the track arrays — with
 // threads per pass that was a third of the call at the headline configuration.  One job at a time; a caller that finds the team
 // busy (rt_multi_create uploads its shards from several threads) does its work alone.
+// Round 6: the workers stay HOT between the jobs of a burst.  A fetch hands the team one job per 16-MB piece, every ≈0.3 ms; a
+// worker asleep on a condition variable wakes in 20-60 µs on a quiet box and in milliseconds on a busy one (one straggler per piece
+// is the piece's time: the C3 fetch's 30 pieces lost 2 ms to wake-ups on a good run and 3-8 ms on a bad one).  A worker that has
+// finished a part now polls the job generation for kHotUs before it sleeps, and the caller polls the pending count before it
+// sleeps: inside a burst nobody sleeps, outside the team costs nothing.
+inline void cpu_relax() {
+#if (defined(__x86_64__) || defined(__i386__)) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_pause();
+#endif
+}
 class WorkerTeam {
   public:
+    static constexpr int kHotUs = 600;
     ~WorkerTeam() {
         if (pid_ != getpid()) return;  // (a forked child never had the threads)
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; stop_a_.store(true, std::memory_order_release); }
         cv_.notify_all();
         for (auto &t : *th_) t.join();
     }
@@ -51,27 +65,53 @@ class WorkerTeam {
             }
             parts = std::min<unsigned>(parts, (unsigned)th_->size() + 1);
             call_ = [&f, &err](unsigned k) { try { f(k); } catch (...) { err[k] = std::current_exception(); } };
-            parts_ = parts; pending_ = parts - 1; ++gen_;
+            parts_ = parts;
+            pending_.store(parts - 1, std::memory_order_relaxed);
+            ++gen_;
+            gen_a_.store(gen_, std::memory_order_release);  // (what the hot workers poll; the job itself is read under the mutex)
         }
         cv_.notify_all();
         call_(0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
+        // the caller waits the same way: a poll first (the parts are of equal size: the others end within microseconds), then the
+        // condition variable
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0; pending_.load(std::memory_order_acquire) != 0; ++spin) {
+            cpu_relax();
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) {
+                std::unique_lock<std::mutex> lk(m_);
+                done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+                break;
+            }
+        }
         return true;
     }
   private:
     void loop(unsigned id) {
         unsigned long seen = 0;
         for (;;) {
-            std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-            if (stop_) return;
-            seen = gen_;
-            if (id >= parts_) continue;
-            lk.unlock();
+            // hot: poll for the next job of a burst
+            bool hot = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 0;; ++spin) {
+                if (gen_a_.load(std::memory_order_acquire) != seen) { hot = true; break; }
+                if (stop_a_.load(std::memory_order_acquire)) return;
+                cpu_relax();
+                if ((spin & 127u) == 127u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kHotUs)) break;
+            }
+            unsigned my_parts;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                if (!hot) cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                my_parts = parts_;
+            }
+            if (id >= my_parts) continue;
             call_(id);
-            lk.lock();
-            if (--pending_ == 0) done_.notify_one();
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(m_);  // (the caller may be about to sleep on done_: the notify must not fall between its check and its wait)
+                done_.notify_one();
+            }
         }
     }
     std::mutex m_, job_;
@@ -79,9 +119,12 @@ class WorkerTeam {
     std::vector<std::thread> *th_ = new std::vector<std::thread>;
     pid_t pid_ = getpid();
     std::function<void(unsigned)> call_;
-    unsigned parts_ = 0, pending_ = 0;
+    unsigned parts_ = 0;
+    std::atomic<unsigned> pending_{0};
     unsigned long gen_ = 0;
+    std::atomic<unsigned long> gen_a_{0};
     bool stop_ = false;
+    std::atomic<bool> stop_a_{false};
 };
 inline WorkerTeam g_team;
 
@@ -244,6 +287,11 @@ struct ResultBlock {
     size_t front_units = 0, next_unit = 0, n_units = 0;
     bool stop = false;
     long small_units = 0;                        // units that fell back to 4-KB pages
+    // development (RT_RESULT_TIMING=1: rt_result_fetch prints them): the slowest first touch of a unit, when the last unit was done,
+    // how long the fetch waited for the front
+    double max_unit_ms = 0.0, done_at_ms = 0.0, waited_ms = 0.0;
+    int slow_units = 0;                          // first touches above 0.5 ms
+    std::chrono::steady_clock::time_point t_map;
     double stall_ms = 2.0;                       // a 2-MB unit whose first touch takes longer than this is a stall
     ~ResultBlock() { release(); }
     static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -267,6 +315,7 @@ struct ResultBlock {
         n_units = bytes / kUnit;
         done.assign(n_units, 0);
         front_units = next_unit = 0; stop = false; small_units = 0;
+        max_unit_ms = done_at_ms = waited_ms = 0.0; slow_units = 0; t_map = std::chrono::steady_clock::now();
         return true;
 #else
         (void)n_tracks_; (void)cap_records_; (void)huge;
@@ -280,6 +329,11 @@ struct ResultBlock {
         const auto t0 = std::chrono::steady_clock::now();
         p[0] = 0;
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (ms > max_unit_ms) max_unit_ms = ms;
+            if (ms > 0.5) ++slow_units;
+        }
 #if defined(__linux__) && defined(MADV_NOHUGEPAGE)
         if (ms > stall_ms) {
             // (the fault had to wait for a huge page: the units still to come take 4-KB pages — many small faults in parallel beat a
@@ -306,6 +360,7 @@ struct ResultBlock {
                 std::lock_guard<std::mutex> lk(m);
                 done[u] = 1;
                 while (front_units < n_units && done[front_units]) ++front_units;
+                if (front_units == n_units) done_at_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_map).count();
             }
             cv.notify_all();
         }
@@ -331,7 +386,10 @@ struct ResultBlock {
     void wait_front(size_t upto) {
         const size_t need = std::min(n_units, (upto + kUnit - 1) / kUnit);
         std::unique_lock<std::mutex> lk(m);
+        if (front_units >= need) return;
+        const auto t0 = std::chrono::steady_clock::now();
         cv.wait(lk, [&] { return front_units >= need; });
+        waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     void join() {
         for (auto &t : th) if (t.joinable()) t.join();
@@ -360,8 +418,32 @@ inline void unhint_huge_pages(char *dst, size_t bytes) {
 
 // A fetched piece from its half of the staging block into the caller's array (the threads also take the page faults of a fresh
 // destination in parallel).
+// (Streaming stores: the destination is hundreds of megabytes that nobody reads before the fetch is over — written around the
+//  caches, a piece costs its 16 MB of reads and 16 MB of writes, not a third 16 MB of read-for-ownership.)
+inline void stream_copy(char *dst, const char *src, size_t n) {
+#if defined(__x86_64__) && defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (n >= ((size_t)64 << 10)) {
+        const size_t head = (size_t)(-(intptr_t)dst) & 15;
+        if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+        const size_t blocks = n / 64;
+        for (size_t i = 0; i < blocks; ++i) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + 64 * i)), b = _mm_loadu_si128((const __m128i *)(src + 64 * i + 16));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(src + 64 * i + 32)), d = _mm_loadu_si128((const __m128i *)(src + 64 * i + 48));
+            _mm_stream_si128((__m128i *)(dst + 64 * i), a);
+            _mm_stream_si128((__m128i *)(dst + 64 * i + 16), b);
+            _mm_stream_si128((__m128i *)(dst + 64 * i + 32), c);
+            _mm_stream_si128((__m128i *)(dst + 64 * i + 48), d);
+        }
+        _mm_sfence();
+        const size_t done = blocks * 64;
+        if (n > done) memcpy(dst + done, src + done, n - done);
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
 inline void copy_into_place(char *dst, const char *src, size_t bytes) {
-    par_ranges(bytes, (size_t)1 << 20, [&](size_t b0, size_t b1) { memcpy(dst + b0, src + b0, b1 - b0); });
+    par_ranges(bytes, (size_t)1 << 20, [&](size_t b0, size_t b1) { stream_copy(dst + b0, src + b0, b1 - b0); });
 }
 
 }  // namespace rthostpar

@@ -307,13 +307,21 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
     bool huge_stalled = false;
     struct Piece { char *d; size_t bytes; int h; char *rest; size_t rest_bytes; };
     Piece prev{nullptr, 0, 0, nullptr, 0};
+    // development (RT_RESULT_TIMING=1): where the fetch's time goes — waiting for a piece to arrive, moving it into place
+    static const bool ftime = getenv("RT_RESULT_TIMING") != nullptr;
+    double f_wait = 0, f_copy = 0, f_wait_max = 0, f_copy_max = 0, f_enq = 0;
+    int f_pieces = 0;
+    auto fnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto drain = [&](const Piece &pc) -> int {  // the piece has arrived in its half: into place
         if (!pc.d) return RT_SUCCESS;
+        const double tw0 = ftime ? fnow() : 0.0;
         RT_HIP(hipEventSynchronize(stage.ev[pc.h]));
+        if (ftime) { const double d = fnow() - tw0; f_wait += d; f_wait_max = std::max(f_wait_max, d); ++f_pieces; }
         const char *hb = (const char *)stage.p + (size_t)pc.h * half;
         if (blk) blk->wait_front((size_t)(pc.d + pc.bytes - blk->base));
         const auto t0 = std::chrono::steady_clock::now();
         rthostpar::copy_into_place(pc.d, hb, pc.bytes);
+        if (ftime) { const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); f_copy += d; f_copy_max = std::max(f_copy_max, d); }
         if (huge_hint && !huge_stalled && pc.bytes >= ((size_t)4 << 20)) {
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if ((double)pc.bytes / sec < 2.0e9) {
@@ -331,8 +339,10 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
             const size_t nbp = std::min(half, bytes[a] - o);
             const int h = k & 1;
             // (half h was drained two pieces ago: `prev` is the piece in the OTHER half)
+            const double te0 = ftime ? fnow() : 0.0;
             RT_HIP(hipMemcpyAsync((char *)stage.p + (size_t)h * half, (const char *)src[a] + o, nbp, hipMemcpyDeviceToHost, s));
             RT_HIP(hipEventRecord(stage.ev[h], s));
+            if (ftime) f_enq += fnow() - te0;
             if (int rc = drain(prev)) return rc;
             if (huge_stalled && huge_hint) rthostpar::unhint_huge_pages((char *)dst[a] + o, bytes[a] - o);  // (a later array of a stalled fetch)
             prev = Piece{(char *)dst[a] + o, nbp, h, (char *)dst[a] + o + nbp, bytes[a] - o - nbp};
@@ -340,6 +350,9 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
     }
     const int rc = drain(prev);
     rel.ok = rc == RT_SUCCESS;
+    if (ftime)
+        fprintf(stderr, "[rt fetch] %d pieces: enqueue %.2f ms, waited for arrivals %.2f ms (longest %.2f), moved into place %.2f ms (longest %.2f)\n", f_pieces, f_enq,
+                f_wait, f_wait_max, f_copy, f_copy_max);
     return rc;
 }
 
@@ -1579,7 +1592,16 @@ int32_t rt_result_fetch(rt_tracks *t, rt_result *r, void **host_ptrs, int64_t *t
     for (int a = 0; a < 8; ++a) dst[a] = b.base + b.off[a];
     const size_t nt = (size_t)t->n, nr = (size_t)t->total;
     const size_t bytes[8] = {8 * (nt + 1), 4 * nt, 8 * nr, 8 * nr, 8 * nr, 8 * nr, 8 * nr, 4 * nr};
+    const auto tf0 = std::chrono::steady_clock::now();
     if (int rc = fetch_pipelined(t, 8, src, dst, bytes, &b)) return rc;
+    if (getenv("RT_RESULT_TIMING")) {  // development: where a slow fetch into the library's block spent its time
+        std::lock_guard<std::mutex> lk(b.m);
+        fprintf(stderr, "[rt result] %zu units of 2 MB; fetch started %.2f ms after the block was mapped and took %.2f ms; last unit faulted at %.2f ms; slowest first "
+                        "touch %.2f ms, %d above 0.5 ms, %ld units on 4-KB pages; the copy waited %.2f ms for the front\n",
+                b.n_units, std::chrono::duration<double, std::milli>(tf0 - b.t_map).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count(), b.done_at_ms, b.max_unit_ms, b.slow_units,
+                b.small_units, b.waited_ms);
+    }
     r->total = t->total;
     if (host_ptrs) for (int a = 0; a < 8; ++a) host_ptrs[a] = dst[a];
     if (total) *total = t->total;

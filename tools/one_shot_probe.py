@@ -28,9 +28,23 @@ aq = tg.azimuthal_quadrature
 dm = _capi.DeviceMesh(tg.mesh, 0)
 for k, v in extra.items():
     dm.set_option(k, int(v))
+def cpustat():
+    d = dict(l.split() for l in cat("/sys/fs/cgroup/cpu.stat").split("\n") if len(l.split()) == 2)
+    return int(d.get("usage_usec", 0)), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+
+
+def faults():
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return ru.ru_minflt, ru.ru_majflt, ru.ru_nvcsw, ru.ru_nivcsw
+
+
 for r in range(reps):
+    c0, f0 = cpustat(), faults()
     s = bench.one_shot_sequence(rt, _capi, dm, tg, aq)
-    print("rep %d: alloc %.2f  h2d %.2f  segmentize %.2f  fetch %.2f  wall %.2f ms" % (r, s["result_alloc_ms"], s["tracks_h2d_ms"], s["segmentize_first_call_ms"],
-                                                                                     s["fetch_result_ms"], s["wall_ms"]), flush=True)
-    time.sleep(0.2)
+    c1, f1 = cpustat(), faults()
+    print("rep %d: alloc %.2f  h2d %.2f  segmentize %.2f  fetch %.2f  wall %.2f ms | cgroup cpu %.1f ms, throttled periods +%d (%.1f ms) | minor faults +%d, ctx switches +%d / +%d" %
+          (r, s["result_alloc_ms"], s["tracks_h2d_ms"], s["segmentize_first_call_ms"], s["fetch_result_ms"], s["wall_ms"], (c1[0] - c0[0]) / 1e3, c1[1] - c0[1],
+           (c1[2] - c0[2]) / 1e3, f1[0] - f0[0], f1[2] - f0[2], f1[3] - f0[3]), flush=True)
+    time.sleep(float(os.environ.get("PROBE_SLEEP", "0.2")))
 print("cpu.stat", cat("/sys/fs/cgroup/cpu.stat").replace("\n", " "))
