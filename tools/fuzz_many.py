@@ -5,7 +5,8 @@ on with cheap steps as the library gates them, on with cheap steps FORCED (optio
 often-refused waves — every record that carries a cheap certificate is decided by it), the library's defaults (pieces for
 small batches), and cheap steps forced with the records in COMPLETION order (option "record_order" 2: the per-track table against
 the checker, then the CSR layout on demand).  Prints the share of cheap steps and the refusals by certificate term per mesh class.
-usage (GPU box): [FUZZ_TINY=1] [FUZZ_SHUFFLE=1] python tools/fuzz_many.py [first_seed] [count]"""
+FUZZ_SMALL_POOLS=1: every handle starts with pools and result arrays that are too small — every call's first attempt is void or short.
+usage (GPU box): [FUZZ_TINY=1] [FUZZ_SHUFFLE=1] [FUZZ_SMALL_POOLS=1] python tools/fuzz_many.py [first_seed] [count]"""
 import os
 import sys
 import time
@@ -81,6 +82,14 @@ for seed in range(first, first + count):
         dm = _capi.DeviceMesh(tg.mesh, 0)
         for kk, v in opts.items():
             dm.set_option(kk, v)
+        if os.environ.get("FUZZ_SMALL_POOLS"):
+            # every handle starts with a staging pool, a side list and result arrays that are too small (by a seeded amount): the first
+            # attempt of every call is void or short, the re-run paths of every mode run on every mesh — with the record kernel beside
+            # the march (sixth mode) the pools run out WHILE it serves units
+            rs = np.random.default_rng(seed * 7 + len(opts))
+            dm.set_option("pool_chunks_hint", int(rs.integers(2, 400)))
+            dm.set_option("side_entries_hint", int(rs.integers(1, 3000)))
+            dm.set_option("test_out_records", int(rs.integers(100, 200000)))
         dt = _capi.DeviceTracks(dm, tg.px, tg.py, tg.phi, tg.cos_phi, tg.sin_phi, tg.A, tg.B, tg.C, tg.ell, tg.azim_idx)
         total = dt.segmentize(tg.tiny_step, k, rt.RTOL_DEFAULT, aq.delta_s, aq.n_azim_2)
         ok_tab = True
