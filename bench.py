@@ -389,29 +389,52 @@ def sweep_bench(rt, tg, aq, dmesh, dt, total, steps, G=7):
     return out
 
 
+def cpu_share():
+    """CPUs this process may use: the cgroup's quota (cpu.max) where there is one, else the hardware threads."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(round(float(q) / float(p)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(tg):
     """Oracle (C port of the reference's algorithm, libm trig per advance_step as the
-    reference does) on the host cores.  Checker code used as a reported baseline only."""
+    reference does) on the host cores.  Checker code used as a reported baseline only.
+    The reference's segmentize! is one thread (src/trackgenerator.jl:362-364: a plain loop over tracks_by_uid): `single_core` is the
+    like-for-like number; `value` is the port parallelised over tracks with OpenMP, at the thread count that does best among the
+    box's CPU share (a GPU box gives a job a cgroup quota of 16 CPUs of its 256 hardware threads: 256 threads burn a period's quota
+    in an eighth of it and are throttled for the rest), four times the share, and all hardware threads — `legs` has all three.  Timed:
+    the march into the port's own per-track storage (every record materialised), not the serial copy into numpy arrays behind it."""
     from oracle import oracle as orc
 
     orc.build()
-    cores = orc.num_threads()
+    hw = int(orc.num_threads())
+    share = cpu_share()
     om = orc.OracleMesh.from_mesh(tg.mesh, omp=True)
-    # all-core leg: the full workload once (≈10–30 core-seconds on this box class)
-    t0 = time.perf_counter()
-    r = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, tiny_step=tg.tiny_step, n_threads=0)
-    dt_all = time.perf_counter() - t0
+    legs = []
+    for nt in sorted({min(hw, share), min(hw, 4 * share), hw}):
+        t0 = time.perf_counter()
+        r = om.segmentize(tg.px, tg.py, tg.phi, tg.A, tg.B, tg.C, tg.ell, tiny_step=tg.tiny_step, n_threads=nt, fetch=False)
+        dt = time.perf_counter() - t0
+        legs.append({"threads": nt, "value": r["total"] / dt, "seconds": dt})
+        time.sleep(0.25)  # (a fresh quota period for the next leg)
+    best = max(legs, key=lambda l: l["value"])
     # single-core leg: every 4th track (bounded)
     sel = np.arange(0, tg.n_total_tracks, 4)
     om1 = orc.OracleMesh.from_mesh(tg.mesh, omp=False)
     t0 = time.perf_counter()
     r1 = om1.segmentize(tg.px[sel], tg.py[sel], tg.phi[sel], tg.A[sel], tg.B[sel], tg.C[sel], tg.ell[sel],
-                        tiny_step=tg.tiny_step, n_threads=1)
+                        tiny_step=tg.tiny_step, n_threads=1, fetch=False)
     dt_1 = time.perf_counter() - t0
     return {
-        "value": r["total"] / dt_all, "unit": "segments/s", "cores": int(cores), "kind": "port",
-        "sample": "full workload once (%d tracks, %d segments), OpenMP over tracks, %.2f s wall"
-                  % (tg.n_total_tracks, r["total"], dt_all),
+        "value": best["value"], "unit": "segments/s", "cores": int(best["threads"]), "kind": "port",
+        "sample": "full workload once per leg (%d tracks, %d segments), OpenMP over tracks, best of %d thread counts: %d threads, %.2f s wall"
+                  % (tg.n_total_tracks, r["total"], len(legs), best["threads"], best["seconds"]),
+        "cpu_share": share, "hardware_threads": hw, "legs": legs,
         "single_core": {"value": r1["total"] / dt_1, "unit": "segments/s", "cores": 1,
                         "sample": "every 4th track (%d tracks, %d segments), %.2f s" % (len(sel), r1["total"], dt_1)},
     }

@@ -127,8 +127,9 @@ class OracleMesh:
         return rc, pq
 
     def segmentize(self, px, py, phi, A, B, Cc, ell, cos_phi=None, sin_phi=None, tiny_step=1e-8, k=5,
-                   rtol=RTOL_DEFAULT, iter_cap=0, n_threads=1):
-        """Returns dict(offsets, status, n_iters, px, py, qx, qy, ell, element)."""
+                   rtol=RTOL_DEFAULT, iter_cap=0, n_threads=1, fetch=True):
+        """Returns dict(offsets, status, n_iters, px, py, qx, qy, ell, element); fetch=False: without the six record arrays (they
+        stay inside the C handle — bench.py's cpu_baseline times the march alone, not a serial copy into numpy arrays)."""
         n = len(px)
         a = lambda v: np.ascontiguousarray(v, np.float64)
         offsets = np.zeros(n + 1, np.int64)
@@ -142,6 +143,9 @@ class OracleMesh:
             sn.ctypes.data_as(C.c_void_p) if sn is not None else None,
             a(A), a(B), a(Cc), a(ell), tiny_step, k, rtol, iter_cap, n_threads, offsets, status, n_iters)
         out = dict(offsets=offsets, status=status, n_iters=n_iters, total=int(total))
+        self._last_total = int(total)
+        if not fetch:
+            return out
         for name in ("px", "py", "qx", "qy", "ell"):
             out[name] = np.zeros(total, np.float64)
         out["element"] = np.zeros(total, np.int32)
