@@ -228,6 +228,33 @@ bool staging_new_block(StagingBlock &b, int device) {
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(b.p); b.p = nullptr; return false; }
     return true;
 }
+// The runtime creates its copy-engine queues lazily: the FIRST device-to-host copy that finds the engine it would have used busy
+// is given another engine, whose queue is created on the spot — 6.5-7.5 ms inside that hipMemcpyAsync (and ≈4,100 page faults: a
+// 16-MB ring).  A pipelined fetch keeps two copies in flight, so the first fetch of a process paid that in its second or third
+// piece — `e2e.one_shot_ms` 17-22 ms instead of 10.5 in the driver's bench lines of rounds 4-6 (profiles/r06/exp_one_shot_spread.log).
+// Here, on the thread that page-locks the process's first staging block beside rt_mesh_create: a burst of overlapping copies in
+// both directions through the block, so that the queues exist before anybody waits for them.  (RT_NO_ENGINE_WARMUP=1: off.)
+static void warm_copy_engines(const StagingBlock &b) {
+    if (getenv("RT_NO_ENGINE_WARMUP")) return;
+    void *d = nullptr;
+    const size_t piece = (size_t)4 << 20, n = kStageBytes / piece;
+    if (hipMalloc(&d, kStageBytes) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipStream_t st[2] = {nullptr, nullptr};
+    bool ok = hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) == hipSuccess;
+    // host to device first (the device block gets defined contents), then device to host — what a fetch does —, each direction as
+    // eight 4-MB copies on two streams at once, twice
+    for (int round = 0; ok && round < 4; ++round) {
+        for (size_t i = 0; ok && i < n; ++i) {
+            if (round == 0) ok = hipMemcpyAsync((char *)d + i * piece, (const char *)b.p + i * piece, piece, hipMemcpyHostToDevice, st[i & 1]) == hipSuccess;
+            else ok = hipMemcpyAsync((char *)b.p + i * piece, (const char *)d + i * piece, piece, hipMemcpyDeviceToHost, st[i & 1]) == hipSuccess;
+        }
+        for (hipStream_t q : st) if (q) (void)hipStreamSynchronize(q);
+    }
+    for (hipStream_t q : st) if (q) (void)hipStreamDestroy(q);
+    (void)hipFree(d);
+    (void)hipGetLastError();
+}
+
 // The process's first block is page-locked (≈1.4 ms) by a thread that rt_mesh_create starts — a mesh always precedes its track sets,
 // and its own preprocessing and upload take longer than that — so that the first rt_tracks_create does not wait for it.
 struct StagingPrefetch {
@@ -242,6 +269,7 @@ struct StagingPrefetch {
                     StagingBlock b;
                     if (!staging_new_block(b, device)) return;
                     memset(b.p, 0, kStageBytes);  // (the host's first touch of its pages, here rather than in the first upload)
+                    warm_copy_engines(b);
                     std::lock_guard<std::mutex> lk(g_staging_mutex);
                     g_staging.push_back(b);
                 });
@@ -309,8 +337,8 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
     Piece prev{nullptr, 0, 0, nullptr, 0};
     // development (RT_RESULT_TIMING=1): where the fetch's time goes — waiting for a piece to arrive, moving it into place
     static const bool ftime = getenv("RT_RESULT_TIMING") != nullptr;
-    double f_wait = 0, f_copy = 0, f_wait_max = 0, f_copy_max = 0, f_enq = 0;
-    int f_pieces = 0;
+    double f_wait = 0, f_copy = 0, f_wait_max = 0, f_copy_max = 0, f_enq = 0, f_enq_max = 0;
+    int f_pieces = 0, f_enq_max_at = -1, f_enq_max_what = 0;
     auto fnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto drain = [&](const Piece &pc) -> int {  // the piece has arrived in its half: into place
         if (!pc.d) return RT_SUCCESS;
@@ -341,8 +369,14 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
             // (half h was drained two pieces ago: `prev` is the piece in the OTHER half)
             const double te0 = ftime ? fnow() : 0.0;
             RT_HIP(hipMemcpyAsync((char *)stage.p + (size_t)h * half, (const char *)src[a] + o, nbp, hipMemcpyDeviceToHost, s));
+            const double te1 = ftime ? fnow() : 0.0;
             RT_HIP(hipEventRecord(stage.ev[h], s));
-            if (ftime) f_enq += fnow() - te0;
+            if (ftime) {
+                const double te2 = fnow();
+                f_enq += te2 - te0;
+                if (te1 - te0 > f_enq_max) { f_enq_max = te1 - te0; f_enq_max_at = k; f_enq_max_what = 1; }
+                if (te2 - te1 > f_enq_max) { f_enq_max = te2 - te1; f_enq_max_at = k; f_enq_max_what = 2; }
+            }
             if (int rc = drain(prev)) return rc;
             if (huge_stalled && huge_hint) rthostpar::unhint_huge_pages((char *)dst[a] + o, bytes[a] - o);  // (a later array of a stalled fetch)
             prev = Piece{(char *)dst[a] + o, nbp, h, (char *)dst[a] + o + nbp, bytes[a] - o - nbp};
@@ -351,8 +385,8 @@ static int fetch_pipelined(rt_tracks *t, int n_arrays, const void *const *src, v
     const int rc = drain(prev);
     rel.ok = rc == RT_SUCCESS;
     if (ftime)
-        fprintf(stderr, "[rt fetch] %d pieces: enqueue %.2f ms, waited for arrivals %.2f ms (longest %.2f), moved into place %.2f ms (longest %.2f)\n", f_pieces, f_enq,
-                f_wait, f_wait_max, f_copy, f_copy_max);
+        fprintf(stderr, "[rt fetch] %d pieces: enqueue %.2f ms (longest call %.2f ms: %s of piece %d), waited for arrivals %.2f ms (longest %.2f), moved into place %.2f ms (longest %.2f)\n",
+                f_pieces, f_enq, f_enq_max, f_enq_max_what == 1 ? "hipMemcpyAsync" : "hipEventRecord", f_enq_max_at, f_wait, f_wait_max, f_copy, f_copy_max);
     return rc;
 }
 
