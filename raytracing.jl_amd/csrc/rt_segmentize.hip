@@ -255,6 +255,17 @@ static void warm_copy_engines(const StagingBlock &b) {
     (void)hipGetLastError();
 }
 
+static void warm_copy_engines_once(const StagingBlock &b) {  // once per device and process
+    static std::mutex m;
+    static std::vector<int> done;
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (std::find(done.begin(), done.end(), b.device) != done.end()) return;
+        done.push_back(b.device);
+    }
+    warm_copy_engines(b);
+}
+
 // The process's first block is page-locked (≈1.4 ms) by a thread that rt_mesh_create starts — a mesh always precedes its track sets,
 // and its own preprocessing and upload take longer than that — so that the first rt_tracks_create does not wait for it.
 struct StagingPrefetch {
@@ -269,7 +280,7 @@ struct StagingPrefetch {
                     StagingBlock b;
                     if (!staging_new_block(b, device)) return;
                     memset(b.p, 0, kStageBytes);  // (the host's first touch of its pages, here rather than in the first upload)
-                    warm_copy_engines(b);
+                    warm_copy_engines_once(b);
                     std::lock_guard<std::mutex> lk(g_staging_mutex);
                     g_staging.push_back(b);
                 });
@@ -293,6 +304,7 @@ int staging_acquire(StagingBlock *out, int device) {
     }
     StagingBlock b;
     if (!staging_new_block(b, device)) return -1;  // (page-locking takes a millisecond: not under the lock)
+    warm_copy_engines_once(b);  // (a device's first block that the prefetch thread did not make: rt_multi's other devices)
     b.busy = true;
     std::lock_guard<std::mutex> lk(g_staging_mutex);
     g_staging.push_back(b);
