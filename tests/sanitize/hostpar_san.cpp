@@ -223,8 +223,26 @@ static void test_result_block(int64_t n_tracks, int64_t n_records, bool huge) {
     if (b.base) fail("result block: release");
 }
 
+// the streaming copy of a fetched piece (head to 16-B alignment, 64-B blocks of non-temporal stores, tail): every alignment of the
+// destination and the source, sizes around its thresholds — against memcpy, with guard bytes on either side
+static void test_stream_copy() {
+    std::vector<unsigned char> src((2u << 20) + 256), dst((2u << 20) + 512), ref((2u << 20) + 512);
+    std::mt19937 r(99);
+    for (auto &v : src) v = (unsigned char)r();
+    for (size_t n : {(size_t)0, (size_t)1, (size_t)65535, (size_t)65536, (size_t)65537, (size_t)70001, ((size_t)1 << 20) + 13, (size_t)2 << 20})
+        for (size_t da = 0; da < 33; da += (n > (1u << 20) ? 7 : 1))
+            for (size_t sa : {(size_t)0, (size_t)1, (size_t)8, (size_t)15}) {
+                std::fill(dst.begin(), dst.end(), (unsigned char)0xa5);
+                std::fill(ref.begin(), ref.end(), (unsigned char)0xa5);
+                rthostpar::stream_copy((char *)dst.data() + 64 + da, (const char *)src.data() + sa, n);
+                memcpy(ref.data() + 64 + da, src.data() + sa, n);
+                if (dst != ref) { fail("stream_copy differs from memcpy (or wrote outside its range)"); return; }
+            }
+}
+
 int main() {
     std::mt19937 rng(20261004);
+    test_stream_copy();
     test_result_block(1000, 300000, true);
     test_result_block(1, 1, false);
     test_result_block(130456, 1200000, true);
